@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+TEST INFRASTRUCTURE -- runs only in the build container, where
+/root/reference exists.  It imports the reference package read-only, with the
+NumPy/SciPy stand-ins of oracle/standins/ for the two absent third-party
+modules (jax, emcee), feeds it seeded inputs and stores
+inputs + outputs as small .npz/.json fixtures.  Nothing here is imported by
+gpyrn_amd, and the GPU box never sees the reference in any form.
+
+    python oracle/gen_golden.py [--big]     # --big adds N=2048 and N=4096 cases
+
+Reference entry points exercised (all in /root/reference/gpyrn):
+  covfunc.*.__call__ via inference._KMatrix          meanfield.py:413-434
+  inference._initMuVar / _u_to_fhatW                 meanfield.py:473-510
+  inference._updateSigMu/_entropy/_expectedLogPrior/_expectedLogLike
+                                                     meanfield.py:713-1093
+  inference.ELBOaux / ELBOcalc                       meanfield.py:561-710
+"""
+import json
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get('GPYRN_REFERENCE', '/root/reference')
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(HERE, 'standins'))
+os.environ.setdefault('MPLBACKEND', 'Agg')
+
+import numpy as np  # noqa: E402
+
+if not hasattr(np, 'float'):
+    np.float = float  # meanfield.py:177 uses the removed alias
+
+import gpyrn  # noqa: E402  (the reference)
+from gpyrn import covfunc as rcov, meanfunc as rmean  # noqa: E402
+from gpyrn.meanfield import inference as rinference  # noqa: E402
+
+sys.path.insert(0, REPO)
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location(
+    'synth', os.path.join(REPO, 'gpyrn_amd', 'synth.py'))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+# ----------------------------------------------------------------- kernels
+KERNEL_CASES = [
+    ('Constant', [1.3]),
+    ('WhiteNoise', [0.7]),
+    ('SquaredExponential', [1.2, 7.5]),
+    ('Periodic', [0.9, 11.0, 0.8]),
+    ('QuasiPeriodic', [1.1, 30.0, 12.5, 0.6]),
+    ('RationalQuadratic', [1.4, 0.8, 9.0]),
+    ('RQP', [1.2, 0.9, 20.0, 13.0, 0.7]),
+    ('Cosine', [0.8, 9.5]),
+    ('Exponential', [1.1, 6.0]),
+    ('Matern32', [1.3, 8.0]),
+    ('Matern52', [0.7, 5.0]),
+    ('GammaExp', [1.2, 1.5, 6.0]),
+    ('Piecewise', [14.0]),
+    ('Paciorek', [1.1, 5.0, 9.0]),
+    ('NewPeriodic', [1.2, 0.9, 10.0, 0.8]),
+    ('QuasiNewPeriodic', [1.1, 0.7, 25.0, 10.0, 0.9]),
+    ('CosPeriodic', [1.3, 11.0, 0.9]),
+    ('QuasiCosPeriodic', [0.9, 22.0, 9.0, 0.8]),
+    ('Polynomial', [1.0, 0.01, 1.5, 2.0]),
+    ('HarmonicPeriodic', [2, 1.1, 13.0, 0.9]),
+    ('QuasiHarmonicPeriodic', [2, 1.2, 25.0, 11.0, 0.8]),
+]
+COMPOSITE_CASES = [
+    # (tag, python expression over `c` = covfunc module)
+    ('SE_plus_M32', 'c.SquaredExponential(1.1, 8.0) + c.Matern32(0.4, 3.0)'),
+    ('SE_times_P', 'c.SquaredExponential(1.0, 10.0) * c.Periodic(1.0, 20.0, 0.5)'),
+    ('sum_of_prod', 'c.SquaredExponential(0.9, 12.0) * c.Periodic(1.0, 7.0, 0.9) + c.Exponential(0.3, 4.0)'),
+    ('dSE', 'c.Derivative(c.SquaredExponential(1.2, 6.0))'),
+    ('dP', 'c.Derivative(c.Periodic(0.9, 11.0, 0.8))'),
+    ('dQP', 'c.Derivative(c.QuasiPeriodic(1.1, 30.0, 12.5, 0.6))'),
+]
+
+
+def gen_kernels():
+    rng = np.random.RandomState(11)
+    t = np.sort(rng.uniform(0, 60, 24))
+    dummy = rinference(1, t, np.zeros(24), np.ones(24))
+    out = {'time': t}
+    meta = {'simple': KERNEL_CASES, 'composite': COMPOSITE_CASES}
+    for name, pars in KERNEL_CASES:
+        k = getattr(rcov, name)(*pars)
+        out['K_' + name] = dummy._KMatrix(k, t)
+    for tag, expr in COMPOSITE_CASES:
+        k = eval(expr, {'c': rcov})
+        out['K_' + tag] = dummy._KMatrix(k, t)
+    # rectangular evaluation (non-square r) pins WhiteNoise's other branch
+    r = t[:5, None] - t[None, :]
+    out['rect_r'] = r
+    out['rect_WhiteNoise'] = rcov.WhiteNoise(0.7)(r)
+    out['rect_QuasiPeriodic'] = rcov.QuasiPeriodic(1.1, 30.0, 12.5, 0.6)(r)
+    np.savez_compressed(os.path.join(OUT, 'kernels.npz'), **out)
+    with open(os.path.join(OUT, 'kernels.json'), 'w') as f:
+        json.dump(meta, f, indent=1)
+    print('kernels: %d matrices' % (len(out) - 1))
+
+
+# --------------------------------------------------------- model problems
+def model_spec(p, q, node_kind, nonzero_means):
+    nodes, weights, means, jitters = synth.component_spec(p, q, node_kind)
+    if nonzero_means:
+        choices = [('Constant', [0.7]), ('Linear', [0.01, -0.4]),
+                   ('Sine', [0.8, 17.0, 0.3]), None]
+        means = [choices[i % len(choices)] for i in range(p)]
+        jitters = [0.3 + 0.25 * i for i in range(p)]
+    return nodes, weights, means, jitters
+
+
+def make_ref(N, p, q, spec, seed=0):
+    t, ys, es = synth.rv_series(N, p, seed)
+    args = []
+    for y, e in zip(ys, es):
+        args += [y, e]
+    g = rinference(q, t, *args)
+    nodes, weights, means, jitters = synth.build_components(rcov, rmean, spec)
+    g.set_components(nodes, weights, means, jitters)
+    return g, t, ys, es
+
+
+def setup_like_elbocalc(g):
+    """The setup block of ELBOcalc, meanfield.py:618-624."""
+    from gpyrn.meanfield import _cholNugget
+    j2 = np.array(g.jitters) ** 2
+    Kf = np.array([g._KMatrix(i, g.time) for i in g.nodes])
+    Kw = np.array([g._KMatrix(j, g.time) for j in g.weights])
+    Lf = np.array([_cholNugget(j)[0] for j in Kf])
+    Lw = np.array([_cholNugget(j)[0] for j in Kw])
+    y = np.concatenate(g.y) - g._mean(g.means)
+    y = np.array(np.array_split(y, g.p))
+    return Kf, Kw, Lf, Lw, y, j2
+
+
+def gen_step_case(tag, N, p, q, node_kind, nonzero_means, nsweeps, full_calc,
+                  keep_matrices=False, seed=0):
+    t0 = time.time()
+    spec = model_spec(p, q, node_kind, nonzero_means)
+    g, t, ys, es = make_ref(N, p, q, spec, seed)
+    out = {'time': t, 'y': np.array(ys), 'yerr': np.array(es)}
+    meta = {'N': N, 'p': p, 'q': q, 'seed': seed,
+            'nodes': spec[0], 'weights': spec[1], 'means': spec[2],
+            'jitters': spec[3], 'nsweeps': nsweeps}
+
+    mu0, var0 = g._initMuVar(g.nodes, g.weights, g.jitters)
+    out['mu_init'], out['var_init'] = mu0, var0
+    f, w = g._u_to_fhatW(mu0)
+    out['mu_init_f'], out['mu_init_w'] = f, w
+
+    Kf, Kw, Lf, Lw, y, j2 = setup_like_elbocalc(g)
+    out['y_resid'] = y
+    out['logdiag_Lf'] = np.array([np.sum(np.log(np.diag(L))) for L in Lf])
+    out['logdiag_Lw'] = np.array([np.sum(np.log(np.diag(L))) for L in Lw])
+    if keep_matrices:
+        out['Kf'], out['Kw'] = Kf, Kw
+
+    # forced sweeps, each split into its parts (ELBOaux body, meanfield.py:682-710)
+    mu, var = mu0, var0
+    elbo, parts = [], []
+    for s in range(nsweeps):
+        muF, muW = g._u_to_fhatW(mu.flatten())
+        varF, varW = g._u_to_fhatW(var.flatten())
+        sigF, muFn, sigW, muWn = g._updateSigMu(Kf, Kw, Lf, Lw, y, j2,
+                                                muF, varF, muW, varW)
+        muFn3 = muFn.reshape(1, g.q, g.N)
+        ent = float(g._entropy(sigF, sigW))
+        logp = float(g._expectedLogPrior(Kf, Kw, Lf, Lw, sigF, muFn3, sigW, muWn))
+        logl = float(g._expectedLogLike(y, j2, sigF, muFn3, sigW, muWn))
+        E, mu, var, sF, sW = g.ELBOaux(Kf, Kw, Lf, Lw, y, j2, mu, var)
+        assert abs(float(E) - (logl + logp + ent) / g.q) <= 1e-9 * abs(float(E))
+        elbo.append(float(E))
+        parts.append([logl, logp, ent])
+        if s == 0 and keep_matrices:
+            out['sigmaF_1'], out['sigmaW_1'] = sF, sW
+        if s == 0:
+            out['mu_1'], out['var_1'] = mu, var
+    out['elbo_sweeps'] = np.array(elbo)
+    out['parts_sweeps'] = np.array(parts)
+    out['mu_final'], out['var_final'] = mu, var
+
+    if full_calc:
+        rec = []
+        orig = g.ELBOaux
+
+        def spy(*a, **k):
+            r = orig(*a, **k)
+            rec.append(float(r[0]))
+            return r
+        g.ELBOaux = spy
+        try:
+            E, muc, varc, it = g.ELBOcalc()
+            out['calc_elbo'] = np.array(float(E))
+            out['calc_mu'], out['calc_var'] = muc, varc
+            out['calc_iter'] = np.array(it)
+            out['calc_elbo_array'] = np.array(rec)
+            # warm start, as nELBO does (meanfield.py:1102-1104)
+            rec.clear()
+            E2, mu2, var2, it2 = g.ELBOcalc(mu='previous', var='previous')
+            out['warm_elbo'] = np.array(float(E2))
+            out['warm_iter'] = np.array(it2)
+            out['warm_elbo_array'] = np.array(rec)
+        except np.linalg.LinAlgError:
+            # NumPy raises where jax would return NaN: the
+            # reference's explicitly formed Sigma lost positive-definiteness to
+            # round-off, so there is no finite reference value to pin.
+            meta['calc_failed_after'] = len(rec)
+            out['calc_elbo_array_partial'] = np.array(rec)
+            print('   %s: reference ELBOcalc hit a non-PD Sigma after %d ELBOaux calls'
+                  % (tag, len(rec)))
+        g.ELBOaux = orig
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **out)
+    with open(os.path.join(OUT, tag + '.json'), 'w') as fjs:
+        json.dump(meta, fjs, indent=1)
+    print('%s: N=%d p=%d q=%d sweeps=%d ELBO[0]=%.12g  (%.1fs)'
+          % (tag, N, p, q, nsweeps, elbo[0], time.time() - t0))
+
+
+def gen_api():
+    """Parameter plumbing contracts, meanfield.py:180-379."""
+    spec = model_spec(2, 2, 'QP', True)
+    spec = (spec[0], spec[1], [('Constant', [0.7]), ('Linear', [0.01, -0.4])], spec[3])
+    g, *_ = make_ref(16, 2, 2, spec)
+    out = {}
+    out['names'] = list(g.parameters_dict.keys())
+    out['values'] = [float(v) for v in g.parameters_dict.values()]
+    out['get_all'] = g.get_parameters(include_frozen=True).tolist()
+    out['n_parameters'] = int(g.n_parameters)
+    g.freeze_parameter(name='node1*')
+    g.freeze_parameter(index=9)
+    out['mask_after_freeze'] = g.frozen_mask.tolist()
+    out['get_free'] = g.get_parameters().tolist()
+    g.thaw_parameter(name='node1.P')
+    out['mask_after_thaw'] = g.frozen_mask.tolist()
+    newp = np.arange(1, g.n_parameters + 1, dtype=float) / 10
+    g.set_parameters(newp.copy())
+    out['after_set_all'] = g.get_parameters(include_frozen=True).tolist()
+    free = g.get_parameters()
+    g.set_parameters(free * 2)
+    out['after_set_free'] = g.get_parameters(include_frozen=True).tolist()
+    out['jitters_after'] = np.asarray(g.jitters).tolist()
+    with open(os.path.join(OUT, 'api.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('api: %d parameters' % out['n_parameters'])
+
+
+if __name__ == '__main__':
+    big = '--big' in sys.argv
+    only = [a for a in sys.argv[1:] if not a.startswith('--')]
+
+    def want(tag):
+        return not only or tag in only
+
+    if want('kernels'):
+        gen_kernels()
+    if want('api'):
+        gen_api()
+    cases = [
+        # tag, N, p, q, node, nonzero means, forced sweeps, full ELBOcalc, keep matrices
+        ('step_p1q1', 32, 1, 1, 'SE', True, 3, True, True),
+        ('step_p2q1', 32, 2, 1, 'QP', True, 3, True, False),
+        ('step_p1q2', 32, 1, 2, 'QP', True, 3, True, False),
+        ('step_p3q2', 32, 3, 2, 'QP', True, 3, True, True),
+        ('step_p2q3', 40, 2, 3, 'QP', True, 3, True, False),
+        ('cfg1_N200', 200, 1, 1, 'SE', False, 6, True, False),
+        ('mid_N300_p3q2', 300, 3, 2, 'QP', True, 4, True, False),
+        ('mid_N512_p3q2', 512, 3, 2, 'QP', False, 3, False, False),
+        ('mid_N1024_p1q1', 1024, 1, 1, 'QP', False, 3, False, False),
+    ]
+    if big:
+        cases += [
+            ('cfg2_N2048', 2048, 1, 1, 'QP', False, 3, False, False),
+            ('cfg3_N4096', 4096, 3, 2, 'QP', False, 2, False, False),
+        ]
+    for c in cases:
+        if want(c[0]):
+            gen_step_case(*c)
