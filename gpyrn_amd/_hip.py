@@ -1,0 +1,271 @@
+"""ctypes binding of libgprn_hip.so (C ABI: include/gprn_hip.h).
+
+Thin by design: NumPy arrays in, NumPy arrays out, status codes turned into
+exceptions.  There is no CPU fallback anywhere in this package -- if the
+library or a GPU is missing, `Context()` raises `BackendUnavailable`.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgprn_hip.so')
+
+GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM = -1, -2, -3, -4, -5
+M_K, M_KLINV, M_SIGMA = 0, 1, 2
+T_NAMES = ('fill', 'build_B', 'diag', 'panel', 'update', 'lauum', 'vec')
+TILE = 128
+
+_dp = POINTER(c_double)
+
+
+class BackendUnavailable(RuntimeError):
+    """libgprn_hip.so is not built, or there is no MI355X to run it on."""
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+# every exported entry point: name -> (restype, argtypes).  tests/test_abi.py
+# checks this table against include/gprn_hip.h and the built library.
+SIGNATURES = {
+    'gprn_device_count': (c_int, []),
+    'gprn_create': (c_int, [POINTER(c_void_p), c_int]),
+    'gprn_destroy': (None, [c_void_p]),
+    'gprn_last_error': (c_char_p, [c_void_p]),
+    'gprn_last_info_gp': (c_int, [c_void_p]),
+    'gprn_set_data': (c_int, [c_void_p, c_int, c_int, c_int, _dp, _dp, _dp]),
+    'gprn_comm_unique_id': (c_int, [POINTER(c_char)]),
+    'gprn_comm_init': (c_int, [c_void_p, c_int, c_int, POINTER(c_char)]),
+    'gprn_set_owners': (c_int, [c_void_p, POINTER(c_int)]),
+    'gprn_comm_barrier_max': (c_int, [c_void_p, _dp]),
+    'gprn_set_kernel': (c_int, [c_void_p, c_int, POINTER(c_int32), c_int, _dp, c_int, c_int]),
+    'gprn_upload_K': (c_int, [c_void_p, c_int, _dp]),
+    'gprn_set_y_resid': (c_int, [c_void_p, _dp]),
+    'gprn_set_jitters': (c_int, [c_void_p, _dp]),
+    'gprn_factor_priors': (c_int, [c_void_p]),
+    'gprn_set_muvar': (c_int, [c_void_p, _dp, _dp]),
+    'gprn_get_muvar': (c_int, [c_void_p, _dp, _dp]),
+    'gprn_sweep': (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
+    'gprn_keep_sigma': (c_int, [c_void_p, c_int]),
+    'gprn_get_matrix': (c_int, [c_void_p, c_int, c_int, _dp]),
+    'gprn_get_logdet_K': (c_int, [c_void_p, _dp]),
+    'gprn_profile_enable': (c_int, [c_void_p, c_int]),
+    'gprn_profile_read': (c_int, [c_void_p, _dp, POINTER(c_int64), c_int]),
+    'gprn_test_gemm': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _dp, _dp, _dp]),
+    'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
+    'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendUnavailable(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; '
+            f'g.build()"` (or make -C gpyrn_amd/csrc)')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:
+        raise BackendUnavailable(f'cannot load {LIB_PATH}: {exc}') from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return int(load_library().gprn_device_count())
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f'expected shape {tuple(shape)}, got {a.shape}')
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    rc = load_library().gprn_comm_unique_id(buf)
+    if rc:
+        raise BackendError(f'gprn_comm_unique_id failed ({rc}): is librccl present?')
+    return buf.raw
+
+
+class Context:
+    """One GPU.  Mirrors the C handle; methods map 1:1 onto the C entry points."""
+
+    def __init__(self, device=0):
+        self._h = None
+        self._lib = load_library()
+        h = c_void_p()
+        rc = self._lib.gprn_create(byref(h), int(device))
+        if rc == GPRN_E_NODEV:
+            raise BackendUnavailable('no HIP device visible: gpyrn_amd has no CPU path '
+                                     '(the NumPy oracle lives in oracle/, for tests only)')
+        if rc:
+            raise BackendError(f'gprn_create({device}) failed with {rc}')
+        self._h = h
+        self.device = int(device)
+        self.N = self.p = self.q = self.G = 0
+        self.world, self.rank = 1, 0
+
+    def close(self):
+        if self._h is not None:
+            self._lib.gprn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- status ------------------------------------------------------------
+    def _check(self, rc, what):
+        """Negative codes raise; a positive code is a LAPACK-style info and is returned."""
+        if rc < 0:
+            msg = self._lib.gprn_last_error(self._h)
+            raise BackendError(f'{what}: {msg.decode() if msg else rc} (code {rc})')
+        return rc
+
+    @property
+    def last_info_gp(self):
+        return int(self._lib.gprn_last_info_gp(self._h))
+
+    # -- problem -----------------------------------------------------------
+    def set_data(self, time, y, yerr, q):
+        time = _f64(time)
+        y = _f64(y)
+        yerr = _f64(yerr, y.shape)
+        p, N = y.shape
+        if time.shape != (N,):
+            raise ValueError('time and y disagree')
+        self._check(self._lib.gprn_set_data(self._h, N, p, int(q), _ptr(time), _ptr(y), _ptr(yerr)),
+                    'set_data')
+        self.N, self.p, self.q, self.G = N, p, int(q), int(q) * (p + 1)
+
+    def comm_init(self, world, rank, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128) if unique_id else None
+        self._check(self._lib.gprn_comm_init(self._h, int(world), int(rank), buf), 'comm_init')
+        self.world, self.rank = int(world), int(rank)
+
+    def set_owners(self, owner):
+        arr = (c_int * self.G)(*[int(o) for o in owner])
+        self._check(self._lib.gprn_set_owners(self._h, arr), 'set_owners')
+
+    def barrier_max(self, value=0.0):
+        v = c_double(float(value))
+        self._check(self._lib.gprn_comm_barrier_max(self._h, byref(v)), 'barrier_max')
+        return v.value
+
+    def set_kernel(self, gp, ops, params, add_nugget):
+        flat = np.ascontiguousarray(np.asarray(ops, dtype=np.int32).reshape(-1, 3))
+        par = _f64(np.atleast_1d(params))
+        self._check(self._lib.gprn_set_kernel(
+            self._h, int(gp), flat.ctypes.data_as(POINTER(c_int32)), flat.shape[0],
+            _ptr(par), par.size, int(bool(add_nugget))), 'set_kernel')
+
+    def upload_K(self, gp, K):
+        K = _f64(K, (self.N, self.N))
+        self._check(self._lib.gprn_upload_K(self._h, int(gp), _ptr(K)), 'upload_K')
+
+    def set_y_resid(self, y):
+        y = _f64(y, (self.p, self.N))
+        self._check(self._lib.gprn_set_y_resid(self._h, _ptr(y)), 'set_y_resid')
+
+    def set_jitters(self, jitters):
+        j = _f64(np.atleast_1d(jitters), (self.p,))
+        self._check(self._lib.gprn_set_jitters(self._h, _ptr(j)), 'set_jitters')
+
+    def factor_priors(self):
+        return self._check(self._lib.gprn_factor_priors(self._h), 'factor_priors')
+
+    def set_muvar(self, mu, var):
+        d = self.N * self.q * (self.p + 1)
+        mu = _f64(np.ravel(mu), (d,))
+        var = _f64(np.ravel(var), (d,))
+        self._check(self._lib.gprn_set_muvar(self._h, _ptr(mu), _ptr(var)), 'set_muvar')
+
+    def get_muvar(self):
+        shape = (self.p + 1, self.q, self.N)
+        mu, var = np.empty(shape), np.empty(shape)
+        self._check(self._lib.gprn_get_muvar(self._h, _ptr(mu), _ptr(var)), 'get_muvar')
+        return mu, var
+
+    def sweep(self, n=1, commit=True):
+        """n x ELBOaux.  Returns (elbo[n], parts[n,3] = LogL, LogP, Ent, info)."""
+        elbo = np.empty(n)
+        parts = np.empty((n, 3))
+        info = self._check(self._lib.gprn_sweep(self._h, int(n), int(bool(commit)),
+                                                _ptr(elbo), _ptr(parts)), 'sweep')
+        return elbo, parts, info
+
+    def keep_sigma(self, on=True):
+        self._check(self._lib.gprn_keep_sigma(self._h, int(bool(on))), 'keep_sigma')
+
+    def get_matrix(self, which, gp):
+        out = np.empty((self.N, self.N))
+        self._check(self._lib.gprn_get_matrix(self._h, int(which), int(gp), _ptr(out)), 'get_matrix')
+        return out
+
+    def get_logdet_K(self):
+        out = np.empty(self.G)
+        self._check(self._lib.gprn_get_logdet_K(self._h, _ptr(out)), 'get_logdet_K')
+        return out
+
+    # -- timing --------------------------------------------------------------
+    def profile_enable(self, families=T_NAMES):
+        mask = 0
+        for f in families or ():
+            mask |= 1 << T_NAMES.index(f)
+        self._check(self._lib.gprn_profile_enable(self._h, mask), 'profile_enable')
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(len(T_NAMES))
+        n = np.zeros(len(T_NAMES), dtype=np.int64)
+        self._check(self._lib.gprn_profile_read(self._h, _ptr(ms), n.ctypes.data_as(POINTER(c_int64)),
+                                                int(bool(reset))), 'profile_read')
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(T_NAMES)}
+
+    # -- diagnostics -----------------------------------------------------------
+    def test_gemm(self, A, B, C, a_mode, b_mode, c_mode):
+        A, B = _f64(A), _f64(B)
+        C = _f64(C).copy()
+        M, K = A.shape
+        K2, N = B.shape
+        assert K == K2 and C.shape == (M, N)
+        self._check(self._lib.gprn_test_gemm(self._h, M, N, K, a_mode, b_mode, c_mode,
+                                             _ptr(A), _ptr(B), _ptr(C)), 'test_gemm')
+        return C
+
+    def test_factor_invert(self, A):
+        A = _f64(A)
+        if A.ndim == 2:
+            A = A[None]
+        batch, n, _ = A.shape
+        L, X = np.empty_like(A), np.empty_like(A)
+        info = self._check(self._lib.gprn_test_factor_invert(self._h, n, batch, _ptr(A), _ptr(L), _ptr(X)),
+                           'test_factor_invert')
+        return L, X, info
+
+    def test_lauum(self, X):
+        X = _f64(X)
+        out = np.empty_like(X)
+        self._check(self._lib.gprn_test_lauum(self._h, X.shape[0], _ptr(X), _ptr(out)), 'test_lauum')
+        return out

@@ -1,0 +1,890 @@
+// C ABI of libgprn_hip.so (include/gprn_hip.h): context, setup, the sweep loop.
+#include "gprn_internal.h"
+#include "vecops.h"
+
+#include <dlfcn.h>
+#include <math.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <algorithm>
+
+// ------------------------------------------------------------------ profiler
+static hipEvent_t prof_event(gprn_ctx* c)
+{
+    if (!c->prof.pool.empty()) {
+        hipEvent_t e = c->prof.pool.back();
+        c->prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+void prof_begin(gprn_ctx* c, int fam)
+{
+    if (!c->prof.on || !((c->prof_mask >> fam) & 1)) { c->prof_open = false; return; }
+    Profiler::Rec r{fam, prof_event(c), prof_event(c)};
+    hipEventRecord(r.a, c->stream);
+    c->prof.pending.push_back(r);
+    c->prof_open = true;
+}
+
+void prof_end(gprn_ctx* c)
+{
+    if (!c->prof_open) return;
+    hipEventRecord(c->prof.pending.back().b, c->stream);
+    c->prof_open = false;
+}
+
+static void prof_collect(gprn_ctx* c)
+{
+    hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof.pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            c->prof.ms[r.fam] += ms;
+            c->prof.n[r.fam] += 1;
+        }
+        c->prof.pool.push_back(r.a);
+        c->prof.pool.push_back(r.b);
+    }
+    c->prof.pending.clear();
+}
+
+extern "C" int gprn_profile_enable(gprn_ctx* c, int mask)
+{
+    if (!c) return GPRN_E_ARG;
+    prof_collect(c);
+    c->prof.on = mask != 0;
+    c->prof_mask = mask;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_profile_read(gprn_ctx* c, double* ms, int64_t* launches, int reset)
+{
+    if (!c) return GPRN_E_ARG;
+    prof_collect(c);
+    for (int i = 0; i < GPRN_T_COUNT; ++i) {
+        if (ms) ms[i] = c->prof.ms[i];
+        if (launches) launches[i] = c->prof.n[i];
+        if (reset) { c->prof.ms[i] = 0; c->prof.n[i] = 0; }
+    }
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ helpers
+template <typename T>
+static int dev_alloc(gprn_ctx* c, T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        c->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? GPRN_E_NOMEM : GPRN_E_HIP;
+    }
+    return GPRN_OK;
+}
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+
+template <typename T>
+static void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
+
+static int bad(gprn_ctx* c, const char* msg) { if (c) c->err = msg; return GPRN_E_ARG; }
+
+static void free_problem(gprn_ctx* c)
+{
+    dev_free(c->d_time); dev_free(c->d_yraw); dev_free(c->d_yerr2); dev_free(c->d_yres);
+    dev_free(c->d_variance); dev_free(c->d_mu); dev_free(c->d_var);
+    dev_free(c->d_mu_save); dev_free(c->d_var_save);
+    for (auto& p : c->K) dev_free(p);
+    for (auto& p : c->KLinv) dev_free(p);
+    for (auto& p : c->Kinv) dev_free(p);
+    for (auto& p : c->Sig) dev_free(p);
+    for (auto& p : c->wsB) dev_free(p);
+    for (auto& p : c->wsX) dev_free(p);
+    c->K.clear(); c->KLinv.clear(); c->Kinv.clear(); c->Sig.clear(); c->wsB.clear(); c->wsX.clear();
+    dev_free(c->d_logdetK);
+    dev_free(c->tab_node); dev_free(c->tab_weight); dev_free(c->tab_setup);
+    dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
+    dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
+    dev_free(c->d_cs); dev_free(c->d_ct); dev_free(c->d_part);
+    dev_free(c->d_scal); dev_free(c->d_out); dev_free(c->d_info);
+    c->d_ptrs = nullptr;
+    c->nslot = 0; c->out_cap = 0;
+    c->factored = c->have_yres = c->have_jit = c->have_muvar = false;
+    c->tables_ready = false;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int gprn_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gprn_create(gprn_ctx** out, int device_id)
+{
+    if (!out) return GPRN_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return GPRN_E_NODEV;
+    if (device_id < 0 || device_id >= n) return GPRN_E_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
+    gprn_ctx* c = new gprn_ctx();
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return GPRN_E_HIP;
+    }
+    *out = c;
+    return GPRN_OK;
+}
+
+static void comm_teardown(gprn_ctx* c);
+
+extern "C" void gprn_destroy(gprn_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->prof.pool) hipEventDestroy(e);
+    comm_teardown(c);
+    free_problem(c);
+    dev_free(c->d_tasks);
+    dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* gprn_last_error(const gprn_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" int gprn_last_info_gp(const gprn_ctx* c) { return c ? c->info_gp : -1; }
+
+// ------------------------------------------------------------------ problem
+extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* time,
+                             const double* y, const double* yerr)
+{
+    if (!c || N <= 0 || p <= 0 || q <= 0 || !time || !y || !yerr) return bad(c, "set_data: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_problem(c);
+    c->N = N; c->p = p; c->q = q; c->G = q + q * p;
+    c->ld = ((N + GPRN_TILE - 1) / GPRN_TILE) * GPRN_TILE;
+    c->T = c->ld / GPRN_TILE;
+    c->kspec.assign(c->G, KernelSpec());
+    c->K.assign(c->G, nullptr);
+    c->KLinv.assign(c->G, nullptr);
+    c->Kinv.assign(q, nullptr);
+    c->Sig.assign(c->G, nullptr);
+    if (c->world == 1) c->owner.assign(c->G, 0);
+    else c->owner.clear();                      // gprn_set_owners must follow
+    const size_t pn = (size_t)p * N, dn = (size_t)(p + 1) * q * N;
+    TRY(dev_alloc(c, &c->d_time, N));
+    TRY(dev_alloc(c, &c->d_yraw, pn));
+    TRY(dev_alloc(c, &c->d_yerr2, pn));
+    TRY(dev_alloc(c, &c->d_yres, pn));
+    TRY(dev_alloc(c, &c->d_variance, pn));
+    TRY(dev_alloc(c, &c->d_mu, dn));
+    TRY(dev_alloc(c, &c->d_var, dn));
+    TRY(dev_alloc(c, &c->d_mu_save, dn));
+    TRY(dev_alloc(c, &c->d_var_save, dn));
+    TRY(dev_alloc(c, &c->d_logdetK, c->G));
+    TRY(dev_alloc(c, &c->d_scal, 3 * c->G + q * q));
+    c->d_logdetB = c->d_scal;
+    c->d_trBinv = c->d_scal + c->G;
+    c->d_muKmu = c->d_scal + 2 * c->G;
+    c->d_q1 = c->d_scal + 3 * c->G;
+    std::vector<double> e2(pn);
+    for (size_t i = 0; i < pn; ++i) e2[i] = yerr[i] * yerr[i];
+    HIP_TRY(c, hipMemcpy(c->d_time, time, N * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yraw, y, pn * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_yerr2, e2.data(), pn * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_logdetK, 0, c->G * sizeof(double)));
+    c->h_yerr2 = e2;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_set_kernel(gprn_ctx* c, int gp, const int32_t* ops, int n_ops,
+                               const double* params, int n_params, int add_nugget)
+{
+    if (!c || !c->N) return bad(c, "set_kernel: call set_data first");
+    if (gp < 0 || gp >= c->G || !ops || n_ops <= 0 || n_ops > GPRN_MAX_OPS || n_params < 0 ||
+        n_params > GPRN_MAX_KPARAMS || (n_params && !params))
+        return bad(c, "set_kernel: bad argument");
+    int depth = 0;
+    for (int o = 0; o < n_ops; ++o) {
+        const int op = ops[3 * o], kid = ops[3 * o + 1], off = ops[3 * o + 2];
+        if (op == GPRN_OP_PUSH) {
+            if (kid < 0 || kid >= GPRN_K_COUNT || off < 0 || off > n_params) return bad(c, "set_kernel: bad push");
+            if (++depth > 8) return bad(c, "set_kernel: expression too deep");
+        } else if (op == GPRN_OP_ADD || op == GPRN_OP_MUL) {
+            if (--depth < 1) return bad(c, "set_kernel: malformed expression");
+        } else return bad(c, "set_kernel: unknown opcode");
+    }
+    if (depth != 1) return bad(c, "set_kernel: malformed expression");
+    KernelSpec& ks = c->kspec[gp];
+    ks.set = true; ks.uploaded = false;
+    ks.n_ops = n_ops; ks.n_params = n_params; ks.nugget = add_nugget ? 1 : 0;
+    memcpy(ks.ops, ops, 3 * n_ops * sizeof(int32_t));
+    if (n_params) memcpy(ks.params, params, n_params * sizeof(double));
+    c->factored = false;
+    return GPRN_OK;
+}
+
+static int ensure_gp_storage(gprn_ctx* c, int g)
+{
+    const size_t nn = (size_t)c->ld * c->ld;
+    if (!c->K[g]) TRY(dev_alloc(c, &c->K[g], nn));
+    if (!c->KLinv[g]) TRY(dev_alloc(c, &c->KLinv[g], nn));
+    return GPRN_OK;
+}
+
+extern "C" int gprn_upload_K(gprn_ctx* c, int gp, const double* Kh)
+{
+    if (!c || !c->N) return bad(c, "upload_K: call set_data first");
+    if (gp < 0 || gp >= c->G || !Kh) return bad(c, "upload_K: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    KernelSpec& ks = c->kspec[gp];
+    ks.set = true; ks.uploaded = true;
+    c->factored = false;
+    if (c->owner.empty()) return bad(c, "upload_K: call set_owners first");
+    if (c->owner[gp] != c->rank) return GPRN_OK;                    // not needed on this rank
+    TRY(ensure_gp_storage(c, gp));
+    // identity padding, then the N x N block
+    const int N = c->N, ld = c->ld;
+    std::vector<double> pad((size_t)ld * ld, 0.0);
+    for (int m = 0; m < ld; ++m) {
+        if (m < N) memcpy(&pad[(size_t)m * ld], Kh + (size_t)m * N, N * sizeof(double));
+        else pad[(size_t)m * ld + m] = 1.0;
+    }
+    HIP_TRY(c, hipMemcpy(c->K[gp], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+    return GPRN_OK;
+}
+
+extern "C" int gprn_set_y_resid(gprn_ctx* c, const double* y)
+{
+    if (!c || !c->N || !y) return bad(c, "set_y_resid: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_yres, y, (size_t)c->p * c->N * sizeof(double), hipMemcpyHostToDevice));
+    c->have_yres = true;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_set_jitters(gprn_ctx* c, const double* jit)
+{
+    if (!c || !c->N || !jit) return bad(c, "set_jitters: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<double> v((size_t)c->p * c->N);
+    for (int i = 0; i < c->p; ++i)
+        for (int n = 0; n < c->N; ++n)
+            v[(size_t)i * c->N + n] = jit[i] * jit[i] + c->h_yerr2[(size_t)i * c->N + n];
+    HIP_TRY(c, hipMemcpy(c->d_variance, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->have_jit = true;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_set_muvar(gprn_ctx* c, const double* mu, const double* var)
+{
+    if (!c || !c->N || !mu || !var) return bad(c, "set_muvar: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
+    HIP_TRY(c, hipMemcpy(c->d_mu, mu, dn, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_var, var, dn, hipMemcpyHostToDevice));
+    c->have_muvar = true;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_get_muvar(gprn_ctx* c, double* mu, double* var)
+{
+    if (!c || !c->N || !mu || !var) return bad(c, "get_muvar: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
+    HIP_TRY(c, hipMemcpy(mu, c->d_mu, dn, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(var, c->d_var, dn, hipMemcpyDeviceToHost));
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ sharding / RCCL
+struct RcclApi {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)();
+    ncclResult_t (*GroupEnd)();
+    const char* (*GetErrorString)(ncclResult_t);
+};
+static RcclApi g_rccl;
+static void* g_rccl_handle = nullptr;
+
+static int rccl_load(std::string* err)
+{
+    if (g_rccl_handle) return GPRN_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl_handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl_handle) break;
+    }
+    if (!g_rccl_handle) { if (err) *err = std::string("dlopen librccl: ") + dlerror(); return GPRN_E_COMM; }
+#define SYM(field, name)                                                             \
+    *(void**)(&g_rccl.field) = dlsym(g_rccl_handle, name);                           \
+    if (!g_rccl.field) { if (err) *err = std::string("dlsym ") + name; return GPRN_E_COMM; }
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(Broadcast, "ncclBroadcast");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return GPRN_OK;
+}
+
+#define NCCL_TRY(c, expr)                                                            \
+    do {                                                                             \
+        ncclResult_t r_ = (expr);                                                    \
+        if (r_ != ncclSuccess) {                                                     \
+            (c)->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r_);        \
+            return GPRN_E_COMM;                                                      \
+        }                                                                            \
+    } while (0)
+
+extern "C" int gprn_comm_unique_id(char* id128)
+{
+    if (!id128) return GPRN_E_ARG;
+    if (rccl_load(nullptr)) return GPRN_E_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return GPRN_E_COMM;
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return GPRN_OK;
+}
+
+static void comm_teardown(gprn_ctx* c)
+{
+    if (c->comm && g_rccl_handle) g_rccl.CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+}
+
+extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id128)
+{
+    if (!c || world < 1 || rank < 0 || rank >= world) return bad(c, "comm_init: bad argument");
+    if (c->N) return bad(c, "comm_init: call before set_data");
+    HIP_TRY(c, hipSetDevice(c->device));
+    comm_teardown(c);
+    c->world = world; c->rank = rank;
+    if (world == 1) return GPRN_OK;
+    if (!id128) return bad(c, "comm_init: id required");
+    TRY(rccl_load(&c->err));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    ncclComm_t comm;
+    NCCL_TRY(c, g_rccl.CommInitRank(&comm, world, id, rank));
+    c->comm = comm;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_set_owners(gprn_ctx* c, const int* owner)
+{
+    if (!c || !c->N || !owner) return bad(c, "set_owners: call set_data first");
+    for (int g = 0; g < c->G; ++g)
+        if (owner[g] < 0 || owner[g] >= c->world) return bad(c, "set_owners: rank out of range");
+    c->owner.assign(owner, owner + c->G);
+    c->factored = false;
+    c->tables_ready = false;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
+{
+    if (!c || !value) return GPRN_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->world > 1 && c->comm) {
+        double* d = nullptr;
+        TRY(dev_alloc(c, &d, 1));
+        HIP_TRY(c, hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        NCCL_TRY(c, g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipFree(d);
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return GPRN_OK;
+}
+
+// rows of the (p+1, q, N) state owned by other ranks arrive from their owners
+static int exchange_rows(gprn_ctx* c, bool weights)
+{
+    if (c->world == 1) return GPRN_OK;
+    const int g0 = weights ? c->q : 0, g1 = weights ? c->G : c->q;
+    NCCL_TRY(c, g_rccl.GroupStart());
+    for (int g = g0; g < g1; ++g) {
+        size_t row;
+        if (g < c->q) row = g;
+        else { const int kk = g - c->q, j = kk / c->p, i = kk % c->p; row = (size_t)(1 + i) * c->q + j; }
+        double* m = c->d_mu + row * c->N;
+        double* v = c->d_var + row * c->N;
+        NCCL_TRY(c, g_rccl.Broadcast(m, m, c->N, ncclDouble, c->owner[g], (ncclComm_t)c->comm, c->stream));
+        NCCL_TRY(c, g_rccl.Broadcast(v, v, c->N, ncclDouble, c->owner[g], (ncclComm_t)c->comm, c->stream));
+    }
+    NCCL_TRY(c, g_rccl.GroupEnd());
+    return GPRN_OK;
+}
+
+static int reduce_scalars(gprn_ctx* c)
+{
+    if (c->world == 1) return GPRN_OK;
+    const size_t n = 3 * (size_t)c->G + (size_t)c->q * c->q;
+    NCCL_TRY(c, g_rccl.AllReduce(c->d_scal, c->d_scal, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ tables
+static int upload_table(gprn_ctx* c, double** d_tab, const std::vector<double*>& rows)
+{
+    HIP_TRY(c, hipMemcpyAsync(d_tab, rows.data(), rows.size() * sizeof(double*),
+                              hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GPRN_OK;
+}
+
+static int build_tables(gprn_ctx* c)
+{
+    if (c->tables_ready) return GPRN_OK;
+    c->loc_nodes.clear(); c->loc_weights.clear();
+    for (int g = 0; g < c->q; ++g) if (c->owner[g] == c->rank) c->loc_nodes.push_back(g);
+    for (int g = c->q; g < c->G; ++g) if (c->owner[g] == c->rank) c->loc_weights.push_back(g);
+    const int want = std::max<size_t>(1, std::max(c->loc_nodes.size(), c->loc_weights.size()));
+    const size_t nn = (size_t)c->ld * c->ld;
+    if (want != c->nslot) {
+        for (auto& p : c->wsB) dev_free(p);
+        for (auto& p : c->wsX) dev_free(p);
+        c->wsB.assign(want, nullptr); c->wsX.assign(want, nullptr);
+        for (int s = 0; s < want; ++s) {
+            TRY(dev_alloc(c, &c->wsB[s], nn));
+            TRY(dev_alloc(c, &c->wsX[s], nn));
+        }
+        dev_free(c->tab_node); dev_free(c->tab_weight); dev_free(c->tab_setup);
+        dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
+        dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
+        dev_free(c->d_cs); dev_free(c->d_ct); dev_free(c->d_part); dev_free(c->d_info);
+        const size_t tab = (size_t)want * GPRN_NBUF, vec = (size_t)want * c->ld;
+        TRY(dev_alloc(c, &c->tab_node, tab)); TRY(dev_alloc(c, &c->tab_weight, tab));
+        TRY(dev_alloc(c, &c->tab_setup, tab));
+        TRY(dev_alloc(c, &c->d_slotgp_node, want)); TRY(dev_alloc(c, &c->d_slotgp_weight, want));
+        TRY(dev_alloc(c, &c->d_slotgp_setup, want));
+        TRY(dev_alloc(c, &c->d_d, vec)); TRY(dev_alloc(c, &c->d_s, vec)); TRY(dev_alloc(c, &c->d_pred, vec));
+        TRY(dev_alloc(c, &c->d_z, vec)); TRY(dev_alloc(c, &c->d_u, vec)); TRY(dev_alloc(c, &c->d_cs, vec));
+        TRY(dev_alloc(c, &c->d_ct, vec));
+        TRY(dev_alloc(c, &c->d_part, (size_t)want * c->T * 2 * c->ld));
+        TRY(dev_alloc(c, &c->d_info, 3 * (size_t)want));
+        c->nslot = want;
+    }
+    for (int g : c->loc_nodes) TRY(ensure_gp_storage(c, g));
+    for (int g : c->loc_weights) TRY(ensure_gp_storage(c, g));
+    std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
+    auto fill_rows = [&](const std::vector<int>& gps) {
+        std::fill(rows.begin(), rows.end(), nullptr);
+        for (size_t s = 0; s < gps.size(); ++s) {
+            rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
+            rows[s * GPRN_NBUF + BUF_X] = c->wsX[s];
+            rows[s * GPRN_NBUF + BUF_K] = c->K[gps[s]];
+            rows[s * GPRN_NBUF + BUF_KLINV] = c->KLinv[gps[s]];
+        }
+    };
+    fill_rows(c->loc_nodes);
+    TRY(upload_table(c, c->tab_node, rows));
+    fill_rows(c->loc_weights);
+    TRY(upload_table(c, c->tab_weight, rows));
+    if (!c->loc_nodes.empty())
+        HIP_TRY(c, hipMemcpy(c->d_slotgp_node, c->loc_nodes.data(), c->loc_nodes.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!c->loc_weights.empty())
+        HIP_TRY(c, hipMemcpy(c->d_slotgp_weight, c->loc_weights.data(), c->loc_weights.size() * sizeof(int), hipMemcpyHostToDevice));
+    c->tables_ready = true;
+    return GPRN_OK;
+}
+
+static int check_info(gprn_ctx* c, const int* d_info, const std::vector<int>& gps, int* first)
+{
+    std::vector<int> h(gps.size());
+    if (gps.empty()) return GPRN_OK;
+    HIP_TRY(c, hipMemcpy(h.data(), d_info, gps.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (size_t s = 0; s < gps.size(); ++s)
+        if (h[s] > 0 && *first == 0) { *first = h[s]; c->info_gp = gps[s]; }
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ setup
+// fill + chol(K) + chol(K)^-1 (+ K^-1 for the nodes that feed quirk Q1)
+extern "C" int gprn_factor_priors(gprn_ctx* c)
+{
+    if (!c || !c->N) return bad(c, "factor_priors: call set_data first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->owner.empty()) return bad(c, "factor_priors: call set_owners first");
+    for (int g = 0; g < c->G; ++g)
+        if (!c->kspec[g].set) return bad(c, "factor_priors: a latent GP has no kernel");
+    TRY(build_tables(c));
+    TRY(ensure_tasks(c));
+    c->info_gp = -1;
+    const size_t nn = (size_t)c->ld * c->ld;
+    HIP_TRY(c, hipMemsetAsync(c->d_logdetK, 0, c->G * sizeof(double), c->stream));
+
+    // which nodes need an explicit K_j^-1 here: j >= 1 with a local node k < j
+    std::vector<char> need_inv(c->q, 0);
+    if (c->q > 1 && !c->loc_nodes.empty())
+        for (int j = c->loc_nodes.front() + 1; j < c->q; ++j) need_inv[j] = 1;
+
+    struct Job { int g; bool owned; };
+    std::vector<Job> jobs;
+    for (int g : c->loc_nodes) jobs.push_back({g, true});
+    for (int g : c->loc_weights) jobs.push_back({g, true});
+    for (int j = 0; j < c->q; ++j)
+        if (need_inv[j] && c->owner[j] != c->rank) jobs.push_back({j, false});
+
+    int first_info = 0;
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += c->nslot) {
+        const int nb = (int)std::min<size_t>(c->nslot, jobs.size() - j0);
+        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
+        std::vector<int> gps(nb);
+        for (int s = 0; s < nb; ++s) {
+            const Job& jb = jobs[j0 + s];
+            gps[s] = jb.g;
+            double* Kdst = jb.owned ? c->K[jb.g] : c->wsB[s];
+            if (jb.owned && c->kspec[jb.g].uploaded) {
+                // already on the device
+            } else if (c->kspec[jb.g].uploaded) {
+                return bad(c, "factor_priors: a host-evaluated node kernel cannot feed another rank (q > 1, sharded)");
+            } else {
+                TRY(launch_fill(c, c->kspec[jb.g], Kdst));
+            }
+            if (jb.owned)
+                HIP_TRY(c, hipMemcpyAsync(c->wsB[s], c->K[jb.g], nn * sizeof(double),
+                                          hipMemcpyDeviceToDevice, c->stream));
+            rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
+            rows[s * GPRN_NBUF + BUF_X] = jb.owned ? c->KLinv[jb.g] : c->wsX[s];
+            rows[s * GPRN_NBUF + BUF_K] = Kdst;
+            rows[s * GPRN_NBUF + BUF_KLINV] = rows[s * GPRN_NBUF + BUF_X];
+        }
+        TRY(upload_table(c, c->tab_setup, rows));
+        HIP_TRY(c, hipMemcpy(c->d_slotgp_setup, gps.data(), nb * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+        c->d_ptrs = c->tab_setup;
+        c->d_info_cur = c->d_info;
+        TRY(factor_invert(c, nb));
+        // log det K: non-owned helper entries are dropped below, before the all-reduce
+        TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
+        TRY(check_info(c, c->d_info, gps, &first_info));
+        // K_j^-1 = X^T X for the nodes that need it (one at a time: output goes to Kinv[j])
+        for (int s = 0; s < nb; ++s) {
+            const int g = gps[s];
+            if (g >= c->q || !need_inv[g]) continue;
+            if (!c->Kinv[g]) TRY(dev_alloc(c, &c->Kinv[g], nn));
+            std::vector<double*> one((size_t)c->nslot * GPRN_NBUF, nullptr);
+            one[BUF_B] = c->Kinv[g];
+            one[BUF_X] = rows[s * GPRN_NBUF + BUF_X];
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            TRY(upload_table(c, c->tab_setup, one));
+            TRY(lauum_lower(c, 1));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            TRY(upload_table(c, c->tab_setup, rows));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    // non-owned helper factorizations wrote logdetK[j] too: keep only owned entries, then share
+    {
+        std::vector<double> h(c->G);
+        HIP_TRY(c, hipMemcpy(h.data(), c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
+        for (int g = 0; g < c->G; ++g) if (c->owner[g] != c->rank) h[g] = 0.0;
+        HIP_TRY(c, hipMemcpy(c->d_logdetK, h.data(), c->G * sizeof(double), hipMemcpyHostToDevice));
+        if (c->world > 1)
+            NCCL_TRY(c, g_rccl.AllReduce(c->d_logdetK, c->d_logdetK, c->G, ncclDouble, ncclSum,
+                                         (ncclComm_t)c->comm, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->factored = true;
+    return first_info;
+}
+
+// ------------------------------------------------------------------ sweep
+static int run_phase(gprn_ctx* c, bool weights)
+{
+    const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
+    const int ns = (int)gps.size();
+    const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
+    c->d_ptrs = weights ? c->tab_weight : c->tab_node;
+    c->d_info_cur = c->d_info + (weights ? 2 : 1) * (size_t)c->nslot;
+    if (ns) {
+        TRY(vec_prep(c, weights, slotgp, ns));
+        TRY(vec_matvec_z(c, ns));
+        TRY(vec_build_B(c, ns));
+        TRY(factor_invert(c, ns));
+        TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
+        TRY(vec_lower_matvec(c, BUF_X, c->d_z, c->ld, 0, slotgp, ns, c->d_u));
+        TRY(vec_colops(c, ns));
+        TRY(vec_finalize(c, slotgp, ns));
+        int n_inv = 0;                       // slots whose explicit B^-1 is needed
+        if (c->keep_sigma) n_inv = ns;
+        else if (!weights && c->q > 1) n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
+        if (n_inv) TRY(lauum_lower(c, n_inv));
+        if (!weights && c->q > 1) {
+            for (int s = 0; s < ns; ++s) {
+                const int k = gps[s];
+                for (int j = k + 1; j < c->q; ++j)
+                    TRY(vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld,
+                               c->d_q1 + (size_t)j * c->q + k));
+            }
+        }
+        if (c->keep_sigma) {
+            const size_t nn = (size_t)c->ld * c->ld;
+            for (int s = 0; s < ns; ++s) {
+                if (!c->Sig[gps[s]]) TRY(dev_alloc(c, &c->Sig[gps[s]], nn));
+                TRY(vec_sigma(c, c->wsB[s], c->d_s + (size_t)s * c->ld, c->Sig[gps[s]]));
+            }
+        }
+    }
+    return exchange_rows(c, weights);
+}
+
+static int mu_k_mu(gprn_ctx* c, bool weights)
+{
+    const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
+    const int ns = (int)gps.size();
+    if (!ns) return GPRN_OK;
+    const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
+    c->d_ptrs = weights ? c->tab_weight : c->tab_node;
+    // a = L_K^-1 m_g with m_g = state row g (nodes: mu_f[g]; weights: the raw-reshape row, quirk Q2)
+    TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, c->d_u));
+    return vec_dot_self(c, slotgp, ns, c->d_u, c->d_muKmu);
+}
+
+extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
+{
+    if (!c || n_sweeps <= 0 || !elbo_out) return bad(c, "sweep: bad argument");
+    if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
+        return bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_sweeps > c->out_cap) {
+        dev_free(c->d_out);
+        TRY(dev_alloc(c, &c->d_out, 4 * (size_t)n_sweeps));
+        c->out_cap = n_sweeps;
+    }
+    const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
+    if (!commit) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mu_save, c->d_mu, dn, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    for (int it = 0; it < n_sweeps; ++it) {
+        HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), c->stream));
+        TRY(run_phase(c, false));
+        TRY(run_phase(c, true));
+        TRY(mu_k_mu(c, false));
+        TRY(mu_k_mu(c, true));
+        TRY(reduce_scalars(c));
+        TRY(vec_elbo(c, c->d_out + 4 * (size_t)it));
+    }
+    if (!commit) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
+    }
+    std::vector<double> h(4 * (size_t)n_sweeps);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int it = 0; it < n_sweeps; ++it) {
+        elbo_out[it] = h[4 * it];
+        if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];
+    }
+    int first = 0;
+    c->info_gp = -1;
+    TRY(check_info(c, c->d_info + (size_t)c->nslot, c->loc_nodes, &first));
+    TRY(check_info(c, c->d_info + 2 * (size_t)c->nslot, c->loc_weights, &first));
+    return first;
+}
+
+// ------------------------------------------------------------------ read-back
+extern "C" int gprn_keep_sigma(gprn_ctx* c, int on)
+{
+    if (!c) return GPRN_E_ARG;
+    c->keep_sigma = on != 0;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
+{
+    if (!c || !c->N || gp < 0 || gp >= c->G || !out) return bad(c, "get_matrix: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double* src = nullptr;
+    if (which == GPRN_M_K) src = c->K[gp];
+    else if (which == GPRN_M_KLINV) src = c->KLinv[gp];
+    else if (which == GPRN_M_SIGMA) src = c->Sig[gp];
+    if (!src) return bad(c, "get_matrix: not available on this rank (or keep_sigma was off)");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy2D(out, (size_t)c->N * sizeof(double), src, (size_t)c->ld * sizeof(double),
+                           (size_t)c->N * sizeof(double), c->N, hipMemcpyDeviceToHost));
+    if (which == GPRN_M_KLINV)      // strictly-upper tiles are scratch: report a clean lower factor
+        for (int m = 0; m < c->N; ++m)
+            for (int n = m + 1; n < c->N; ++n) out[(size_t)m * c->N + n] = 0.0;
+    return GPRN_OK;
+}
+
+extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
+{
+    if (!c || !c->N || !out) return bad(c, "get_logdet_K: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ diagnostics
+static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch)
+{
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t nn = (size_t)ld * ld * batch;
+    for (int b = 0; b < 3; ++b) {
+        if (b < nbuf_needed && c->test_cap[b] < nn) {
+            dev_free(c->d_test[b]);
+            TRY(dev_alloc(c, &c->d_test[b], nn));
+            c->test_cap[b] = nn;
+        }
+    }
+    return GPRN_OK;
+}
+
+extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int b_mode, int c_mode,
+                              const double* A, const double* B, double* C)
+{
+    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || !A || !B || !C)
+        return bad(c, "test_gemm: bad argument");
+    const int ld = std::max(std::max(M, N), K);
+    TRY(test_setup(c, ld, 3, 1));
+    // place the operands in ld x ld row-major buffers exactly as the task modes address them
+    const size_t nn = (size_t)ld * ld;
+    std::vector<double> ha(nn, 0.0), hb(nn, 0.0), hc(nn, 0.0);
+    for (int m = 0; m < M; ++m)
+        for (int k = 0; k < K; ++k) {
+            const double v = A[(size_t)m * K + k];
+            if (a_mode == 0) ha[(size_t)m * ld + k] = v; else ha[(size_t)k * ld + m] = v;
+        }
+    for (int k = 0; k < K; ++k)
+        for (int n = 0; n < N; ++n) {
+            const double v = B[(size_t)k * N + n];
+            if (b_mode == 0) hb[(size_t)n * ld + k] = v; else hb[(size_t)k * ld + n] = v;
+        }
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) hc[(size_t)m * ld + n] = C[(size_t)m * N + n];
+    HIP_TRY(c, hipMemcpy(c->d_test[0], ha.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_test[1], hb.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_test[2], hc.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<TileTask> tasks;
+    for (int ti = 0; ti < M / GPRN_TILE; ++ti)
+        for (int tj = 0; tj < N / GPRN_TILE; ++tj) {
+            TileTask t;
+            t.c_off = (int64_t)ti * GPRN_TILE * ld + (int64_t)tj * GPRN_TILE;
+            t.a_off = a_mode == 0 ? (int64_t)ti * GPRN_TILE * ld : (int64_t)ti * GPRN_TILE;
+            t.b_off = b_mode == 0 ? (int64_t)tj * GPRN_TILE * ld : (int64_t)tj * GPRN_TILE;
+            t.klen = K;
+            t.c_buf = 2; t.a_buf = 0; t.b_buf = 1;
+            t.modes = tile_modes(c_mode, a_mode, b_mode);
+            tasks.push_back(t);
+        }
+    TileTask* d_t = nullptr;
+    double** d_p = nullptr;
+    TRY(dev_alloc(c, &d_t, tasks.size()));
+    TRY(dev_alloc(c, &d_p, GPRN_NBUF));
+    double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], c->d_test[2], nullptr};
+    HIP_TRY(c, hipMemcpy(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice));
+    int rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess)
+        e = hipMemcpy(hc.data(), c->d_test[2], nn * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(d_t); hipFree(d_p);
+    if (rc) return rc;
+    HIP_TRY(c, e);
+    for (int m = 0; m < M; ++m)
+        for (int n = 0; n < N; ++n) C[(size_t)m * N + n] = hc[(size_t)m * ld + n];
+    return GPRN_OK;
+}
+
+// run the library's own factorisation on caller matrices: temporarily a tiny "problem"
+static int test_factor_common(gprn_ctx* c, int n, int batch, const double* A, double* L,
+                              double* Linv, bool lauum, double* lauum_out)
+{
+    if (!c || n <= 0 || n % GPRN_TILE || batch <= 0 || !A) return bad(c, "test_factor: bad argument");
+    TRY(test_setup(c, n, 2, batch));
+    const size_t nn = (size_t)n * n;
+    HIP_TRY(c, hipMemcpy(c->d_test[0], A, nn * batch * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_test[1], 0, nn * batch * sizeof(double)));
+    // borrow the context's factorisation state
+    const int sN = c->N, sld = c->ld, sT = c->T, stT = c->tasks_T;
+    double** sptrs = c->d_ptrs;
+    int* sinfo = c->d_info_cur;
+    c->N = n; c->ld = n; c->T = n / GPRN_TILE;
+    double** d_p = nullptr;
+    int* d_i = nullptr;
+    int rc = dev_alloc(c, &d_p, (size_t)batch * GPRN_NBUF);
+    if (!rc) rc = dev_alloc(c, &d_i, batch);
+    std::vector<double*> hp((size_t)batch * GPRN_NBUF, nullptr);
+    for (int b = 0; b < batch; ++b) {
+        hp[(size_t)b * GPRN_NBUF + BUF_B] = c->d_test[0] + b * nn;
+        hp[(size_t)b * GPRN_NBUF + BUF_X] = c->d_test[1] + b * nn;
+    }
+    hipError_t e = hipSuccess;
+    int info0 = 0;
+    if (!rc) {
+        e = hipMemcpy(d_p, hp.data(), hp.size() * sizeof(double*), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_i, 0, batch * sizeof(int));
+        c->d_ptrs = d_p; c->d_info_cur = d_i;
+        c->tasks_T = -1;                       // force a task rebuild for this n
+        if (e == hipSuccess) rc = lauum ? GPRN_OK : factor_invert(c, batch);
+        if (lauum && e == hipSuccess) {
+            // X := A (lower), out -> BUF_B
+            e = hipMemcpy(c->d_test[1], A, nn * sizeof(double), hipMemcpyHostToDevice);
+            if (e == hipSuccess) rc = lauum_lower(c, 1);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && !rc) {
+            if (lauum) e = hipMemcpy(lauum_out, c->d_test[0], nn * sizeof(double), hipMemcpyDeviceToHost);
+            else {
+                e = hipMemcpy(L, c->d_test[0], nn * batch * sizeof(double), hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(Linv, c->d_test[1], nn * batch * sizeof(double), hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(&info0, d_i, sizeof(int), hipMemcpyDeviceToHost);
+                for (int b = 0; b < batch; ++b)           // the upper triangle still holds A
+                    for (int m = 0; m < n; ++m)
+                        for (int k2 = m + 1; k2 < n; ++k2) L[b * nn + (size_t)m * n + k2] = 0.0;
+            }
+        }
+    }
+    if (d_p) hipFree(d_p);
+    if (d_i) hipFree(d_i);
+    c->N = sN; c->ld = sld; c->T = sT; c->d_ptrs = sptrs; c->d_info_cur = sinfo;
+    c->tasks_T = -1;                           // the problem's own lists are rebuilt on demand
+    (void)stT;
+    if (rc) return rc;
+    HIP_TRY(c, e);
+    return info0;
+}
+
+extern "C" int gprn_test_factor_invert(gprn_ctx* c, int n, int batch, const double* A, double* L, double* Linv)
+{
+    if (!L || !Linv) return bad(c, "test_factor_invert: bad argument");
+    return test_factor_common(c, n, batch, A, L, Linv, false, nullptr);
+}
+
+extern "C" int gprn_test_lauum(gprn_ctx* c, int n, const double* X, double* out)
+{
+    if (!out) return bad(c, "test_lauum: bad argument");
+    return test_factor_common(c, n, 1, X, nullptr, nullptr, true, out);
+}

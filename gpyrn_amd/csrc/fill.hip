@@ -1,0 +1,201 @@
+// Fused pairwise-difference + covariance fill:  K[m][n] = k(t_m, t_n) (+ nugget).
+//
+// Replaces inference._KMatrix (meanfield.py:413-434) over covFunction.__call__
+// (covfunc.py, line numbers per kernel in include/gprn_hip.h): the reference
+// materialises r = t[:,None]-t[None,:] and 5-8 more N x N temporaries per
+// kernel; here each element is produced from two reads of the time vector
+// (L2 resident) and written once -- 8 N^2 bytes of HBM traffic per matrix.
+//
+// A kernel expression (Sum / Multiplication trees of built-ins, covfunc.py:65-77)
+// arrives as a postfix program evaluated per element on a tiny register stack.
+// Formulas follow the reference's operation order so host and device agree to
+// rounding (device libm vs NumPy: <= 2 ulp).
+#include "gprn_internal.h"
+
+#include <math.h>
+
+struct FillProgram {
+    int n_ops;
+    int nugget;
+    int32_t ops[3 * GPRN_MAX_OPS];
+    double par[GPRN_MAX_KPARAMS];
+};
+
+#define PI_D 3.141592653589793
+
+__device__ __forceinline__ void harmonic_terms(double Nh, double P, double t, double& s, double& u)
+{
+    // covfunc.py:599-605 with its precedence: sin(phase)/2*sin(half)
+    const double phase = (Nh + 0.5) * 2 * PI_D * t / P;
+    const double half = PI_D * t / P;
+    s = sin(phase) / 2 * sin(half);
+    u = 0.5 / tan(half) - cos(phase) / 2 * sin(half);
+}
+
+__device__ __forceinline__ double eval_kernel(int kid, const double* __restrict__ q,
+                                              double ti, double tj, bool diag)
+{
+    const double r = ti - tj;
+    switch (kid) {
+    case GPRN_K_CONSTANT: return q[0] * q[0];
+    case GPRN_K_WHITENOISE: return diag ? q[0] * q[0] : 0.0;
+    case GPRN_K_SE: return q[0] * q[0] * exp(-0.5 * (r * r) / (q[1] * q[1]));
+    case GPRN_K_PERIODIC: {
+        const double s = sin(PI_D * fabs(r) / q[1]);
+        return q[0] * q[0] * exp(-2 * (s * s) / (q[2] * q[2]));
+    }
+    case GPRN_K_QP: {
+        const double s = sin(PI_D * fabs(r) / q[2]);
+        const double per = -2 * (s * s) / (q[3] * q[3]);
+        const double dec = (r * r) / (2 * (q[1] * q[1]));
+        return q[0] * q[0] * exp(per - dec);
+    }
+    case GPRN_K_RQ:
+        return q[0] * q[0] * pow(1 + 0.5 * (r * r) / (q[1] * (q[2] * q[2])), -q[1]);
+    case GPRN_K_RQP: {
+        const double s = sin(PI_D * fabs(r) / q[3]);
+        const double per = exp(-2 * (s * s) / (q[4] * q[4]));
+        return q[0] * q[0] * per * pow(1 + (r * r) / (2 * q[1] * (q[2] * q[2])), -q[1]);
+    }
+    case GPRN_K_COSINE: return q[0] * q[0] * cos(2 * PI_D * fabs(r) / q[1]);
+    case GPRN_K_EXPONENTIAL: return q[0] * q[0] * exp(-fabs(r) / q[1]);
+    case GPRN_K_MATERN32: {
+        const double x = sqrt(3.0) * fabs(r) / q[1];
+        return q[0] * q[0] * (1.0 + x) * exp(-x);
+    }
+    case GPRN_K_MATERN52: {
+        const double a = fabs(r), ell = q[1];
+        const double poly = 1.0 + (3 * sqrt(5.0) * ell * a + 5 * (a * a)) / (3 * (ell * ell));
+        return q[0] * q[0] * poly * exp(-sqrt(5.0) * a / ell);
+    }
+    case GPRN_K_GAMMAEXP: return q[0] * q[0] * exp(-pow(fabs(r) / q[2], q[1]));
+    case GPRN_K_PIECEWISE: {
+        const double x = fabs(r / (0.5 * q[0]));
+        const double y = 1 - x;
+        return x > 1 ? 0.0 : (3 * x + 1) * (y * y * y);
+    }
+    case GPRN_K_PACIOREK: {
+        const double s = q[1] * q[1] + q[2] * q[2];
+        return q[0] * q[0] * sqrt(2 * q[1] * q[2] / s) * exp(-2 * r * r / s);
+    }
+    case GPRN_K_NEWPERIODIC: {
+        const double s = sin(PI_D * fabs(r) / q[2]);
+        return q[0] * q[0] * pow(1 + 2 * (s * s) / (q[1] * (q[3] * q[3])), -q[1]);
+    }
+    case GPRN_K_QUASINEWPERIODIC: {
+        const double s = sin(PI_D * fabs(r) / q[3]);
+        const double a = pow(1 + 2 * (s * s) / (q[1] * (q[4] * q[4])), -q[1]);
+        const double b = exp(-0.5 * (r * r) / (q[2] * q[2]));
+        return q[0] * q[0] * a * b;
+    }
+    case GPRN_K_COSPERIODIC: {
+        const double c = cos(PI_D * fabs(r) / q[1]);
+        return q[0] * q[0] * exp(-2 * (c * c) / (q[2] * q[2]));
+    }
+    case GPRN_K_QUASICOSPERIODIC: {
+        const double c = cos(PI_D * fabs(r) / q[2]);
+        return q[0] * q[0] * exp(-2 * (c * c) / (q[3] * q[3]) - (r * r) / (2 * (q[1] * q[1])));
+    }
+    case GPRN_K_POLYNOMIAL: return pow(q[0] * ti * tj + q[1], q[2]);
+    case GPRN_K_HARMONICPERIODIC: {
+        double s1, u1, s2, u2;
+        harmonic_terms(q[0], q[2], ti, s1, u1);
+        harmonic_terms(q[0], q[2], tj, s2, u2);
+        const double d2 = (s1 - s2) * (s1 - s2) + (u1 - u2) * (u1 - u2);
+        return q[1] * q[1] * exp(-0.5 * d2 / (q[3] * q[3]));
+    }
+    case GPRN_K_QUASIHARMONICPERIODIC: {
+        double s1, u1, s2, u2;
+        harmonic_terms(q[0], q[3], ti, s1, u1);
+        harmonic_terms(q[0], q[3], tj, s2, u2);
+        const double d2 = (s1 - s2) * (s1 - s2) + (u1 - u2) * (u1 - u2);
+        const double a = exp(-0.5 * d2 / (q[4] * q[4]));
+        const double b = exp(-0.5 * (r * r) / (q[2] * q[2]));
+        return q[1] * q[1] * a * b;
+    }
+    case GPRN_K_DSE: {
+        const double e2 = q[1] * q[1];
+        return (q[0] * q[0] / (e2 * e2)) * (e2 - r * r) * exp(-0.5 * (r * r) / e2);
+    }
+    case GPRN_K_DPERIODIC: {
+        const double x = PI_D * r / q[1];
+        const double sx = sin(x), cx = cos(x);
+        const double poly = q[2] * q[2] * cos(2 * x) - 4 * (sx * sx) * (cx * cx);
+        return 4 * (PI_D * PI_D) * (q[0] * q[0]) * poly * exp(-2 * (sx * sx) / (q[2] * q[2]));
+    }
+    case GPRN_K_DQP: {
+        const double th = q[0], le = q[1], P = q[2], lp = q[3];
+        const double P2 = P * P, lp2 = lp * lp, lp4 = lp2 * lp2, le2 = le * le, le4 = le2 * le2;
+        const double sx = sin(PI_D * r / P), cx = cos(PI_D * r / P);
+        const double scale = 2 * (th * th) / (P2 * lp4 * le4);
+        const double poly = P2 * lp4 * le2 - 2 * P2 * lp4 * (r * r)
+            - 4 * PI_D * P * lp2 * le2 * r * sin(2 * PI_D * r / P)
+            + 2 * (PI_D * PI_D) * lp2 * le4 * cos(2 * PI_D * r / P)
+            - 8 * (PI_D * PI_D) * le4 * (sx * sx) * (cx * cx);
+        const double env = exp(-(lp2 * (r * r) + 2 * le2 * (sx * sx)) / (lp2 * le2));
+        return scale * poly * env;
+    }
+    default: return 0.0;
+    }
+}
+
+__device__ __forceinline__ double eval_program(const FillProgram& pg, double ti, double tj, bool diag)
+{
+    double st[8];
+    int sp = 0;
+    for (int o = 0; o < pg.n_ops; ++o) {
+        const int op = pg.ops[3 * o];
+        if (op == GPRN_OP_PUSH) {
+            st[sp & 7] = eval_kernel(pg.ops[3 * o + 1], pg.par + pg.ops[3 * o + 2], ti, tj, diag);
+            ++sp;
+        } else {
+            const double b = st[(sp - 1) & 7], a = st[(sp - 2) & 7];
+            st[(sp - 2) & 7] = (op == GPRN_OP_ADD) ? a + b : a * b;
+            --sp;
+        }
+    }
+    return st[0];
+}
+
+// one block = 8 rows x 256 columns; each thread 8 rows x 1 column -> per row the
+// 256 threads write 2 KiB contiguous.  Padded region (>= N) becomes identity so
+// the blocked factorisation can run on whole tiles.
+__global__ __launch_bounds__(256)
+void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int m0 = blockIdx.y * 8;
+    if (n >= ld) return;
+    const double tn = (n < N) ? t[n] : 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + i;
+        if (m >= ld) break;
+        double v;
+        if (m < N && n < N) {
+            v = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, t[m], tn, m == n)
+                                : eval_program(pg, t[m], tn, m == n);
+            if (pg.nugget && m == n) v += 1e-6;
+        } else {
+            v = (m == n) ? 1.0 : 0.0;
+        }
+        K[(size_t)m * ld + n] = v;
+    }
+}
+
+int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K)
+{
+    FillProgram pg;
+    pg.n_ops = ks.n_ops;
+    pg.nugget = ks.nugget;
+    for (int i = 0; i < 3 * ks.n_ops; ++i) pg.ops[i] = ks.ops[i];
+    for (int i = 0; i < ks.n_params; ++i) pg.par[i] = ks.params[i];
+    for (int i = ks.n_params; i < GPRN_MAX_KPARAMS; ++i) pg.par[i] = 0.0;
+    for (int i = 3 * ks.n_ops; i < 3 * GPRN_MAX_OPS; ++i) pg.ops[i] = 0;
+    prof_begin(c, GPRN_T_FILL);
+    dim3 grid((c->ld + 255) / 256, (c->ld + 7) / 8);
+    hipLaunchKernelGGL(k_fill, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}

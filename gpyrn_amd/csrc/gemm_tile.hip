@@ -1,0 +1,146 @@
+// Batched 128x128 tile contraction on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// Every O(N^3) flop of the sweep goes through this one kernel: the trailing
+// SYRK of the blocked Cholesky, the row updates that build L^-1 alongside it,
+// the panel solves (as products with the inverted diagonal block) and the
+// X^T X product behind quirk Q1 (see factor.hip for the task lists).
+//
+// Work decomposition: one 256-thread workgroup (4 waves, 2x2) per 128x128
+// output tile, each wave a 64x64 sub-tile = 4x4 MFMA tiles of 16x16, i.e. 16
+// independent accumulators (128 VGPRs) -- enough to issue the 64-cycle f64 MFMA
+// back to back.  K is streamed in chunks of 16 through a double-buffered LDS
+// image (global -> registers -> LDS, one barrier per chunk); global loads of
+// chunk c+1 are in flight while chunk c is multiplied.
+//
+// LDS images (conflict-free for the one-f64-per-lane MFMA operand fetch,
+// ds_read_b64, banks = (addr/4)%64):
+//   operand stored k-contiguous in memory  -> image [row][k],  pitch 18 doubles
+//   operand stored row-contiguous in memory-> image [k][row],  pitch 144 doubles
+// both 2304 doubles per operand per stage; 4 x 18 KiB = 72 KiB per workgroup,
+// two workgroups per CU.
+#include "gprn_internal.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define OPER_DOUBLES 2304
+
+__global__ __launch_bounds__(256, 2)
+void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld)
+{
+    __shared__ __attribute__((aligned(16))) double lds[4 * OPER_DOUBLES];
+
+    const TileTask t = tasks[blockIdx.x];
+    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    const double* __restrict__ A = gp[t.a_buf] + t.a_off;
+    const double* __restrict__ B = gp[t.b_buf] + t.b_off;
+    double* __restrict__ C = gp[t.c_buf] + t.c_off;
+    const int c_mode = t.modes & 3;
+    const int a_mode = (t.modes >> 2) & 1;
+    const int b_mode = (t.modes >> 3) & 1;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- global -> LDS staging geometry (pairs of doubles along the contiguous dim)
+    const int a_shift = a_mode ? 6 : 3, b_shift = b_mode ? 6 : 3;
+    const int a_pitch = a_mode ? 144 : 18, b_pitch = b_mode ? 144 : 18;
+    const size_t a_step = a_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
+    const size_t b_step = b_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
+    size_t a_g[4], b_g[4];
+    int a_l[4], b_l[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pi = tid + 256 * it;
+        const int as = pi >> a_shift, af = pi & ((1 << a_shift) - 1);
+        const int bs = pi >> b_shift, bf = pi & ((1 << b_shift) - 1);
+        a_g[it] = (size_t)as * ld + 2 * af;
+        a_l[it] = as * a_pitch + 2 * af;
+        b_g[it] = (size_t)bs * ld + 2 * bf;
+        b_l[it] = bs * b_pitch + 2 * bf;
+    }
+    // ---- MFMA operand fetch geometry: lane holds A[row = l&15][k = l>>4], B[k = l>>4][col = l&15]
+    const int fr = lane & 15, fk = lane >> 4;
+    const int a_rs = a_mode ? 1 : 18, a_ks = a_mode ? 144 : 1;
+    const int b_rs = b_mode ? 1 : 18, b_ks = b_mode ? 144 : 1;
+    const int a_frag = (wr * 64 + fr) * a_rs + fk * a_ks;
+    const int b_frag = (wc * 64 + fr) * b_rs + fk * b_ks;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    const int nchunks = t.klen / GPRN_KC;
+    v2d ra[4], rb[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        ra[it] = *reinterpret_cast<const v2d*>(A + a_g[it]);
+        rb[it] = *reinterpret_cast<const v2d*>(B + b_g[it]);
+    }
+
+    for (int c = 0; c < nchunks; ++c) {
+        double* sA = lds + (c & 1) * 2 * OPER_DOUBLES;
+        double* sB = sA + OPER_DOUBLES;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it];
+            *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) {
+            A += a_step;
+            B += b_step;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                ra[it] = *reinterpret_cast<const v2d*>(A + a_g[it]);
+                rb[it] = *reinterpret_cast<const v2d*>(B + b_g[it]);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < GPRN_KC / 4; ++ks) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = sA[a_frag + i * 16 * a_rs + ks * 4 * a_ks];
+                bf[i] = sB[b_frag + i * 16 * b_rs + ks * 4 * b_ks];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
+    double* Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* pc = Cw + (size_t)(i * 16 + 4 * r) * ld + j * 16;
+                const double v = acc[i][j][r];
+                if (c_mode == CM_SET) *pc = v;
+                else if (c_mode == CM_SUB) *pc = *pc - v;
+                else *pc = -v;
+            }
+}
+
+int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
+                 int nbatch, int ld, int fam)
+{
+    if (ntasks == 0 || nbatch == 0) return GPRN_OK;
+    prof_begin(c, fam);
+    dim3 grid((unsigned)ntasks, (unsigned)nbatch);
+    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), 0, c->stream, d_tasks,
+                       (double* const*)d_ptrs, ld);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}

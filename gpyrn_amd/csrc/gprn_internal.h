@@ -1,0 +1,136 @@
+// Internal declarations shared by the HIP translation units of libgprn_hip.so.
+// Public C ABI: include/gprn_hip.h.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gprn_hip.h"
+
+#define GPRN_TILE 128          // tile edge of the blocked factorisation (nb)
+#define GPRN_KC 16             // K chunk staged through LDS per pipeline stage
+#define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
+
+// buffer slots of a tile task (index into the per-GP pointer table)
+enum { BUF_B = 0, BUF_X = 1, BUF_K = 2, BUF_KLINV = 3 };
+// c_mode of a tile task
+enum { CM_SET = 0, CM_SUB = 1, CM_SETNEG = 2 };
+
+// One 128x128 output tile of  C (op)= A . B  over klen, all operands tiles of
+// square row-major matrices with leading dimension ld.
+//   a_mode 0: A element (m,k) at a_off + m*ld + k     (k contiguous)
+//   a_mode 1: A element (m,k) at a_off + k*ld + m     (m contiguous, i.e. A^T stored)
+//   b_mode 0: B element (k,n) at b_off + n*ld + k     (k contiguous, "NT")
+//   b_mode 1: B element (k,n) at b_off + k*ld + n     (n contiguous, "NN")
+struct TileTask {
+    int64_t c_off, a_off, b_off;
+    int32_t klen;
+    uint8_t c_buf, a_buf, b_buf;
+    uint8_t modes;             // bits 0-1 c_mode, bit 2 a_mode, bit 3 b_mode
+};
+static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode) {
+    return (uint8_t)((c_mode & 3) | ((a_mode & 1) << 2) | ((b_mode & 1) << 3));
+}
+
+#define HIP_TRY(ctx, expr)                                                     \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);    \
+            return GPRN_E_HIP;                                                 \
+        }                                                                      \
+    } while (0)
+
+struct Profiler {
+    bool on = false;
+    struct Rec { int fam; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[GPRN_T_COUNT] = {0};
+    int64_t n[GPRN_T_COUNT] = {0};
+};
+
+struct KernelSpec {            // how latent GP g gets its K
+    bool set = false, uploaded = false;
+    int n_ops = 0, n_params = 0, nugget = 0;
+    int32_t ops[3 * GPRN_MAX_OPS];
+    double params[GPRN_MAX_KPARAMS];
+};
+
+struct gprn_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int info_gp = -1;
+    Profiler prof;
+    int prof_mask = 0;               // bit per GPRN_T_* family
+    bool prof_open = false;
+
+    // ---- problem
+    int N = 0, p = 0, q = 0, G = 0, ld = 0, T = 0;   // ld = N padded to GPRN_TILE, T = ld/TILE
+    double *d_time = nullptr, *d_yraw = nullptr, *d_yerr2 = nullptr;
+    double *d_yres = nullptr, *d_variance = nullptr;
+    std::vector<double> h_yerr2;
+    double *d_mu = nullptr, *d_var = nullptr;        // (p+1, q, N) each, reference layout
+    double *d_mu_save = nullptr, *d_var_save = nullptr;
+    bool have_yres = false, have_jit = false, have_muvar = false, factored = false;
+
+    // ---- sharding
+    int world = 1, rank = 0;
+    std::vector<int> owner;          // G entries (empty until known when world > 1)
+    std::vector<int> loc_nodes, loc_weights;   // latent GPs of this rank, ascending = slot order
+    void* comm = nullptr;            // ncclComm_t
+
+    // ---- per latent GP, persistent across sweeps (only for GPs this rank needs)
+    std::vector<KernelSpec> kspec;   // G
+    std::vector<double*> K;          // G   (ld x ld), null when not held
+    std::vector<double*> KLinv;      // G   chol(K)^-1 lower
+    std::vector<double*> Kinv;       // q   K_j^-1 lower, only for nodes j>=1 that feed quirk Q1
+    std::vector<double*> Sig;        // G   explicit Sigma of the last sweep (keep_sigma only)
+    bool keep_sigma = false;
+    double* d_logdetK = nullptr;     // G
+    // ---- workspaces: nslot pairs (B, X), nslot = max local GPs of a phase
+    int nslot = 0;
+    std::vector<double*> wsB, wsX;
+    double** d_ptrs = nullptr;       // the table the launchers use right now (one of the three below)
+    double **tab_node = nullptr, **tab_weight = nullptr, **tab_setup = nullptr;  // [nslot][GPRN_NBUF]
+    int *d_slotgp_node = nullptr, *d_slotgp_weight = nullptr, *d_slotgp_setup = nullptr;
+    bool tables_ready = false;
+    // per-slot vectors (ld each): d, s, pred, w(=K pred), z, u, colsq, colt
+    double *d_d = nullptr, *d_s = nullptr, *d_pred = nullptr, *d_w = nullptr,
+           *d_z = nullptr, *d_u = nullptr, *d_cs = nullptr, *d_ct = nullptr;
+    double* d_part = nullptr;        // partial column sums scratch [nslot][T][2][ld]
+    // per-GP scalars of the running sweep, one allocation (all-reduced as one message):
+    // logdetB[G], trBinv[G], muKmu[G], Q1 traces [q*q]
+    double* d_scal = nullptr;
+    double *d_logdetB = nullptr, *d_trBinv = nullptr, *d_muKmu = nullptr, *d_q1 = nullptr;
+    double* d_out = nullptr;         // per sweep: elbo, logl, logp, ent
+    int out_cap = 0;
+    int* d_info = nullptr;           // [3][nslot] first failing pivot per slot: setup, node phase, weight phase
+    int* d_info_cur = nullptr;       // the row factor_invert writes to
+    // scratch of the diagnostic entry points
+    double* d_test[3] = {nullptr, nullptr, nullptr};
+    size_t test_cap[3] = {0, 0, 0};
+    // tile-task lists for the factorisation at the current T (device)
+    TileTask* d_tasks = nullptr;
+    size_t tasks_cap = 0;
+    std::vector<TileTask> h_tasks;
+    struct StepRange { size_t panel0, npanel, upd0, nupd; };
+    std::vector<StepRange> steps;    // T entries
+    size_t lauum0 = 0, nlauum = 0;
+    int tasks_T = 0;
+};
+
+// ---- launchers (each enqueues on ctx->stream; no sync) ----
+void prof_begin(gprn_ctx* c, int fam);
+void prof_end(gprn_ctx* c);
+
+int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K);
+int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
+                 int nbatch, int ld, int fam);
+int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info);
+// factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
+int factor_invert(gprn_ctx* c, int nbatch);
+int lauum_lower(gprn_ctx* c, int nbatch);   // BUF_B = lower(X^T X), X in BUF_X
+int ensure_tasks(gprn_ctx* c);

@@ -1,0 +1,17 @@
+// Launchers of vecops.hip (all enqueue on ctx->stream against ctx->d_ptrs).
+#pragma once
+#include "gprn_internal.h"
+
+int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots);
+int vec_matvec_z(gprn_ctx* c, int nslots);
+int vec_build_B(gprn_ctx* c, int nslots);
+int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* out);
+int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, int vin_by_gp,
+                     const int* d_slot_gp, int nslots, double* out);
+int vec_colops(gprn_ctx* c, int nslots);
+int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots);
+int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
+           double* out_scalar);
+int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out);
+int vec_elbo(gprn_ctx* c, double* out4);
+int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);

@@ -1,0 +1,480 @@
+// O(N) and O(N^2) kernels around the factorisation: everything of one ELBOaux
+// (meanfield.py:651-710) that is not an N^3 contraction.  All batched over the
+// latent GPs of a phase ("slots") through grid.y / grid.z; HBM-bound.
+//
+//   k_prep_nodes / k_prep_weights   d, sqrt(d), right-hand side   meanfield.py:759-791, 838-864
+//   k_matvec_z                      z = s * (K pred)
+//   k_build_B                       B = I + D^1/2 K D^1/2 (lower tiles)
+//   k_logdet                        2 sum log diag(L)             meanfield.py:1029,1062,1088,1091
+//   k_lower_matvec                  y = M v, M lower triangular
+//   k_colops_partial / _reduce      colnorm^2(X) = diag(B^-1),  X^T u
+//   k_finalize                      new mu, new var = diag Sigma, tr(B^-1)
+//   k_q1_rows / k_sum_rows          <K_j^-1, Sigma_k> for the cumulative-trace quirk, :1039-1041
+//   k_dot_self                      a.a  (mu^T K^-1 mu via a = L_K^-1 mu, :1032,1050)
+//   k_elbo                          expected log-likelihood (:895-990) + assembly (:709)
+#include "gprn_internal.h"
+#include "vecops.h"
+
+#include <math.h>
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over a 256-thread block; result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sh /* >= 4 doubles */)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return r;
+}
+
+__global__ __launch_bounds__(256)
+void k_prep_nodes(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
+                  const double* __restrict__ mu, const double* __restrict__ var,
+                  const double* __restrict__ yres, const double* __restrict__ variance,
+                  double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred)
+{
+    const int slot = blockIdx.y, j = slot_gp[slot];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= ld) return;
+    double dsum = 1.0, psum = 0.0;
+    if (n < N) {
+        dsum = 0.0;
+        for (int i = 0; i < p; ++i) {
+            const double vi = variance[(size_t)i * N + n];
+            const size_t wrow = (size_t)(1 + i) * q;
+            const double mwj = mu[(wrow + j) * N + n];
+            const double vwj = var[(wrow + j) * N + n];
+            dsum += (mwj * mwj + vwj) / vi;
+            double other = 0.0;
+            for (int k = 0; k < q; ++k)
+                if (k != j) other += mu[(wrow + k) * N + n] * mu[(size_t)k * N + n];
+            psum += (yres[(size_t)i * N + n] - other) * mwj / vi;
+        }
+    }
+    const size_t o = (size_t)slot * ld + n;
+    d[o] = dsum;
+    s[o] = sqrt(dsum);
+    pred[o] = psum;
+}
+
+__global__ __launch_bounds__(256)
+void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
+                    const double* __restrict__ mu, const double* __restrict__ var,
+                    const double* __restrict__ yres, const double* __restrict__ variance,
+                    double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred)
+{
+    const int slot = blockIdx.y, kk = slot_gp[slot] - q;
+    const int j = kk / p, i = kk % p;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= ld) return;
+    double dv = 1.0, pv = 0.0;
+    if (n < N) {
+        const double vi = variance[(size_t)i * N + n];
+        const double mfj = mu[(size_t)j * N + n];
+        dv = (mfj * mfj + var[(size_t)j * N + n]) / vi;
+        const size_t wrow = (size_t)(1 + i) * q;
+        double other = 0.0;
+        for (int k = 0; k < q; ++k)
+            if (k != j) other += mu[(size_t)k * N + n] * mu[(wrow + k) * N + n];
+        pv = (yres[(size_t)i * N + n] - other) * mfj / vi;
+    }
+    const size_t o = (size_t)slot * ld + n;
+    d[o] = dv;
+    s[o] = sqrt(dv);
+    pred[o] = pv;
+}
+
+// z[m] = s[m] * sum_n K[m][n] pred[n]; one wave per row
+__global__ __launch_bounds__(256)
+void k_matvec_z(double* const* __restrict__ ptrs, int N, int ld,
+                const double* __restrict__ s, const double* __restrict__ pred,
+                double* __restrict__ z)
+{
+    const int slot = blockIdx.y;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= ld) return;
+    const double* K = ptrs[(size_t)slot * GPRN_NBUF + BUF_K] + (size_t)m * ld;
+    const double* v = pred + (size_t)slot * ld;
+    double acc = 0.0;
+    if (m < N) {
+        for (int n = 2 * lane; n < N; n += 128) {       // N even or odd: guard the tail
+            const v2d kv = *reinterpret_cast<const v2d*>(K + n);
+            acc += kv.x * v[n];
+            if (n + 1 < N) acc += kv.y * v[n + 1];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) z[(size_t)slot * ld + m] = (m < N) ? s[(size_t)slot * ld + m] * acc : 0.0;
+}
+
+// B = I + D^1/2 K D^1/2 on the lower tiles (diagonal tiles in full); identity padding
+__global__ __launch_bounds__(256)
+void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __restrict__ s)
+{
+    const int tj = blockIdx.x, ti = blockIdx.y, slot = blockIdx.z;
+    if (tj > ti) return;
+    const double* K = ptrs[(size_t)slot * GPRN_NBUF + BUF_K];
+    double* B = ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    const double* sv = s + (size_t)slot * ld;
+    const int n = tj * GPRN_TILE + 2 * (threadIdx.x & 63);
+    const double s0 = sv[n], s1 = sv[n + 1];
+    for (int it = 0; it < 32; ++it) {
+        const int m = ti * GPRN_TILE + (threadIdx.x >> 6) + 4 * it;
+        const size_t o = (size_t)m * ld + n;
+        v2d out;
+        if (m < N) {
+            const v2d kv = *reinterpret_cast<const v2d*>(K + o);
+            const double sm = sv[m];
+            out.x = (n < N) ? sm * s0 * kv.x : 0.0;
+            out.y = (n + 1 < N) ? sm * s1 * kv.y : 0.0;
+        } else {
+            out.x = 0.0;
+            out.y = 0.0;
+        }
+        if (m == n) out.x += 1.0;
+        if (m == n + 1) out.y += 1.0;
+        *reinterpret_cast<v2d*>(B + o) = out;
+    }
+}
+
+// out[idx(slot)] = 2 * sum_{n<N} log M[n][n]
+__global__ __launch_bounds__(256)
+void k_logdet(double* const* __restrict__ ptrs, int buf, int N, int ld,
+              const int* __restrict__ slot_gp, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    const int slot = blockIdx.x;
+    const double* M = ptrs[(size_t)slot * GPRN_NBUF + buf];
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) acc += log(M[(size_t)n * ld + n]);
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[slot_gp[slot]] = 2.0 * acc;
+}
+
+// out[slot][i] = sum_{c<=i} M[i][c] v[c]   (i < N), M = ptrs[slot][buf];
+// v = vin + (vin_by_gp ? slot_gp[slot] : slot) * vstride
+__global__ __launch_bounds__(256)
+void k_lower_matvec(double* const* __restrict__ ptrs, int buf, int N, int ld,
+                    const double* __restrict__ vin, size_t vstride, int vin_by_gp,
+                    const int* __restrict__ slot_gp, double* __restrict__ out)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= ld) return;
+    const double* M = ptrs[(size_t)slot * GPRN_NBUF + buf] + (size_t)i * ld;
+    const double* v = vin + (size_t)(vin_by_gp ? slot_gp[slot] : slot) * vstride;
+    double acc = 0.0;
+    if (i < N) {
+        for (int c = 2 * lane; c <= i; c += 128) {
+            const v2d mv = *reinterpret_cast<const v2d*>(M + c);
+            acc += mv.x * v[c];
+            if (c + 1 <= i) acc += mv.y * v[c + 1];
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[(size_t)slot * ld + i] = acc;
+}
+
+// partial column sums over one tile row (128 rows) of X: cs += x^2, ct += x*u[row]
+// grid (ld/64, T, nslots); tiles above the diagonal are skipped (and not read later)
+__global__ __launch_bounds__(256)
+void k_colops_partial(double* const* __restrict__ ptrs, int ld, int T,
+                      const double* __restrict__ u, double* __restrict__ part)
+{
+    __shared__ double shs[4][64], sht[4][64];
+    const int c0 = blockIdx.x * 64, ch = blockIdx.y, slot = blockIdx.z;
+    if (ch < (c0 >> 7)) return;
+    const double* X = ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    const double* uv = u + (size_t)slot * ld;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    double cs = 0.0, ct = 0.0;
+    for (int r = ch * GPRN_TILE + rl; r < (ch + 1) * GPRN_TILE; r += 4) {
+        const double x = X[(size_t)r * ld + c0 + cl];
+        cs += x * x;
+        ct += x * uv[r];
+    }
+    shs[rl][cl] = cs;
+    sht[rl][cl] = ct;
+    __syncthreads();
+    if (rl == 0) {
+        const size_t o = (((size_t)slot * T + ch) * 2) * ld + c0 + cl;
+        part[o] = (shs[0][cl] + shs[1][cl]) + (shs[2][cl] + shs[3][cl]);
+        part[o + ld] = (sht[0][cl] + sht[1][cl]) + (sht[2][cl] + sht[3][cl]);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_colops_reduce(int ld, int T, const double* __restrict__ part,
+                     double* __restrict__ cs, double* __restrict__ ct)
+{
+    const int slot = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ld) return;
+    double a = 0.0, b = 0.0;
+    for (int ch = c >> 7; ch < T; ++ch) {
+        const size_t o = (((size_t)slot * T + ch) * 2) * ld + c;
+        a += part[o];
+        b += part[o + ld];
+    }
+    cs[(size_t)slot * ld + c] = a;
+    ct[(size_t)slot * ld + c] = b;
+}
+
+// new mu = (X^T X z)/s, new var = (1 - diag B^-1)/d into the state rows of the GP;
+// trBinv[gp] = sum diag B^-1
+__global__ __launch_bounds__(256)
+void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
+                const double* __restrict__ d, const double* __restrict__ s,
+                const double* __restrict__ cs, const double* __restrict__ ct,
+                double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv)
+{
+    __shared__ double sh[4];
+    const int slot = blockIdx.x, gp = slot_gp[slot];
+    size_t row;
+    if (gp < q) row = gp;
+    else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
+    double tr = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const size_t o = (size_t)slot * ld + n;
+        const double binv = cs[o];
+        tr += binv;
+        mu[row * N + n] = ct[o] / s[o];
+        var[row * N + n] = (1.0 - binv) / d[o];
+    }
+    tr = block_sum(tr, sh);
+    if (threadIdx.x == 0) trBinv[gp] = tr;
+}
+
+// rowsum[m] = sum_{n<=m} w(m,n) Kinv[m][n] (delta_mn - Binv[m][n]) / (s_m s_n), w = 2 off-diagonal
+__global__ __launch_bounds__(256)
+void k_q1_rows(const double* __restrict__ Kinv, const double* __restrict__ Binv, int N, int ld,
+               const double* __restrict__ s, double* __restrict__ rowsum)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= N) return;
+    const double* kr = Kinv + (size_t)m * ld;
+    const double* br = Binv + (size_t)m * ld;
+    double acc = 0.0;
+    for (int n = lane; n < m; n += 64) acc -= kr[n] * br[n] / s[n];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const double sm = s[m];
+        rowsum[m] = 2.0 * acc / sm + kr[m] * (1.0 - br[m]) / (sm * sm);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_sum_to(const double* __restrict__ v, int n, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) *out = acc;
+}
+
+__global__ __launch_bounds__(256)
+void k_dot_self(const int* __restrict__ slot_gp, int N, int ld, const double* __restrict__ a,
+                double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    const int slot = blockIdx.x;
+    double acc = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const double x = a[(size_t)slot * ld + n];
+        acc += x * x;
+    }
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[slot_gp[slot]] = acc;
+}
+
+// Expected log-likelihood (meanfield.py:895-990; y_raw is the RAW data, quirk Q3)
+// and the final assembly  ELBO = (LogL + LogP + Ent) / q  (:709).
+// out[0..3] = ELBO, LogL, LogP, Ent.  One block.
+__global__ __launch_bounds__(256)
+void k_elbo(int N, int p, int q, const double* __restrict__ mu, const double* __restrict__ var,
+            const double* __restrict__ yraw, const double* __restrict__ variance,
+            const double* __restrict__ logdetK, const double* __restrict__ logdetB,
+            const double* __restrict__ trBinv, const double* __restrict__ muKmu,
+            const double* __restrict__ q1, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    const double TWO_PI = 6.283185307179586;
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        for (int i = 0; i < p; ++i) {
+            const double vi = variance[(size_t)i * N + n];
+            const size_t wrow = (size_t)(1 + i) * q;
+            t1 += log(TWO_PI * vi);
+            double fit = 0.0, cross = 0.0;
+            for (int j = 0; j < q; ++j) {
+                const double mf = mu[(size_t)j * N + n], vf = var[(size_t)j * N + n];
+                const double mw = mu[(wrow + j) * N + n], vw = var[(wrow + j) * N + n];
+                fit += mw * mf;
+                cross += vf * (mw * mw) + vw * (mf * mf) + vf * vw;
+            }
+            const double resid = yraw[(size_t)i * N + n] - fit;
+            t2 += resid * resid / vi;
+            t3 += cross / vi;
+        }
+    }
+    t1 = block_sum(t1, sh);
+    t2 = block_sum(t2, sh);
+    t3 = block_sum(t3, sh);
+    if (threadIdx.x == 0) {
+        const int G = q + q * p;
+        const double logl = -0.5 * t1 - 0.5 * t2 - 0.5 * t3;
+        double ent = 0.0, logp = 0.0;
+        for (int g = 0; g < G; ++g) {
+            ent += 0.5 * (logdetK[g] - logdetB[g]);
+            double tr = trBinv[g];
+            if (g < q)
+                for (int k = 0; k < g; ++k) tr += q1[g * q + k];   // cumulative sumSigmaF, quirk Q1
+            logp += -0.5 * logdetK[g] - 0.5 * (muKmu[g] + tr);
+        }
+        const double c = (double)q * (p + 1) * N;
+        ent += 0.5 * c * (1.0 + log(TWO_PI));
+        logp += -0.5 * c * log(TWO_PI);
+        out[0] = (logl + logp + ent) / q;
+        out[1] = logl;
+        out[2] = logp;
+        out[3] = ent;
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+#define LAUNCH_END(c) do { prof_end(c); HIP_TRY(c, hipGetLastError()); return GPRN_OK; } while (0)
+
+int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    dim3 grid((c->ld + 255) / 256, nslots);
+    if (weights)
+        hipLaunchKernelGGL(k_prep_weights, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
+                           c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
+                           c->d_d, c->d_s, c->d_pred);
+    else
+        hipLaunchKernelGGL(k_prep_nodes, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
+                           c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
+                           c->d_d, c->d_s, c->d_pred);
+    LAUNCH_END(c);
+}
+
+int vec_matvec_z(gprn_ctx* c, int nslots)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_matvec_z, dim3(c->ld / 4, nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s, c->d_pred, c->d_z);
+    LAUNCH_END(c);
+}
+
+int vec_build_B(gprn_ctx* c, int nslots)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_BUILD_B);
+    hipLaunchKernelGGL(k_build_B, dim3(c->T, c->T, nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s);
+    LAUNCH_END(c);
+}
+
+int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* out)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_logdet, dim3(nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, buf, c->N, c->ld, d_slot_gp, out);
+    LAUNCH_END(c);
+}
+
+int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, int vin_by_gp,
+                     const int* d_slot_gp, int nslots, double* out)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_lower_matvec, dim3(c->ld / 4, nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, buf, c->N, c->ld, vin, vstride, vin_by_gp,
+                       d_slot_gp, out);
+    LAUNCH_END(c);
+}
+
+int vec_colops(gprn_ctx* c, int nslots)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_colops_partial, dim3(c->ld / 64, c->T, nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, c->ld, c->T, c->d_u, c->d_part);
+    hipLaunchKernelGGL(k_colops_reduce, dim3((c->ld + 255) / 256, nslots), dim3(256), 0,
+                       c->stream, c->ld, c->T, c->d_part, c->d_cs, c->d_ct);
+    LAUNCH_END(c);
+}
+
+int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
+                       c->p, c->q, c->d_d, c->d_s, c->d_cs, c->d_ct, c->d_mu, c->d_var,
+                       c->d_trBinv);
+    LAUNCH_END(c);
+}
+
+int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
+           double* out_scalar)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_q1_rows, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, Kinv_j, Binv_k,
+                       c->N, c->ld, s_k, c->d_u /* scratch: slot 0 of u is free here */);
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, c->d_u, c->N, out_scalar);
+    LAUNCH_END(c);
+}
+
+int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_dot_self, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
+                       a, out);
+    LAUNCH_END(c);
+}
+
+int vec_elbo(gprn_ctx* c, double* out4)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_elbo, dim3(1), dim3(256), 0, c->stream, c->N, c->p, c->q, c->d_mu,
+                       c->d_var, c->d_yraw, c->d_variance, c->d_logdetK, c->d_logdetB,
+                       c->d_trBinv, c->d_muKmu, c->d_q1, out4);
+    LAUNCH_END(c);
+}
+
+// Sigma = D^-1/2 (I - B^-1) D^-1/2, full symmetric, from the lower triangle of B^-1
+__global__ __launch_bounds__(256)
+void k_sigma(const double* __restrict__ Binv, const double* __restrict__ s, int N, int ld,
+             double* __restrict__ out)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n >= N || m >= N) return;
+    const int hi = m > n ? m : n, lo = m > n ? n : m;
+    const double b = Binv[(size_t)hi * ld + lo];
+    out[(size_t)m * ld + n] = ((m == n ? 1.0 : 0.0) - b) / (s[m] * s[n]);
+}
+
+int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_sigma, dim3((c->N + 255) / 256, c->N), dim3(256), 0, c->stream, Binv, s,
+                       c->N, c->ld, out);
+    LAUNCH_END(c);
+}

@@ -1,0 +1,492 @@
+"""Mean-field variational inference for GP regression networks on MI355X.
+
+Drop-in for the reference's ``gpyrn.meanfield.inference`` on its hot path:
+``ELBO`` / ``ELBOcalc`` / ``ELBOaux`` / ``nELBO`` / ``optimize`` and the whole
+component / parameter API (meanfield.py:92-379, 556-710, 1095-1152), same
+names, argument meaning, return shapes and error types.  What differs is where
+the work happens: covariance assembly, every Cholesky / triangular inverse and
+all ELBO reductions run in libgprn_hip.so (include/gprn_hip.h) on the GPU,
+device-resident across sweeps; per sweep only the ELBO scalar returns to the
+host for the reference's stop rule (meanfield.py:640-646).
+
+There is no CPU fallback: without the built library and a GPU, anything that
+needs the ELBO raises ``_hip.BackendUnavailable``.  Host-side work that remains
+is O(#parameters) bookkeeping, O(pN) mean functions and the O(pqN)
+``_initMuVar`` start point.
+
+Reference behaviours kept because results must match: the
+first ``ELBOaux`` of ``ELBOcalc`` is evaluated and discarded (its ELBO is
+``elboArray[0]``); ``max_iter`` defaults to 10000; ``_mu``/``_var`` are cached only
+on the converged return; ``_initMuVar`` uses the first p weight amplitudes and
+emits the weight block node-major; ELBO = (LogL + LogP + Ent) / q.
+"""
+import time as time_module
+from itertools import chain
+
+import numpy as np
+
+from . import _hip, covfunc, meanfunc, sharding
+from ._utils import Array, _array_input  # noqa: F401
+
+__all__ = ['inference']
+
+_NUGGET = 1e-6          # meanfield.py:433
+_TWO_ARGUMENT = (covfunc.HarmonicPeriodic, covfunc.QuasiHarmonicPeriodic,
+                 covfunc.Polynomial)          # meanfield.py:426-428
+_NOT_SET = 'GPRN components not set, use set_components'
+
+
+class inference:
+    """
+    Mean-field variational inference for GPRNs (Nguyen & Bonilla 2013).
+
+    Args:
+        q: int
+            Number of latent node functions f(x)
+        time: array
+            Time coordinates
+        *args: arrays
+            The observed data in the following order:
+                y1, y1error, y2, y2error, ...
+        device: int, keyword only
+            GPU ordinal (default: LOCAL_RANK when sharded, else 0)
+        comm: ``sharding.Comm``, keyword only
+            Shard the q + q*p latent GPs over the ranks of one node
+    """
+
+    def __init__(self, q: int, time: Array, *args, device=None, comm=None):
+        self.q = q
+        self.time = time
+        self.N = self.time.size
+
+        assert len(args) > 0 and len(args) % 2 == 0, \
+            'Number of observed data arrays should be even: y1, y1error, ...'
+        assert np.all(np.array([len(a) for a in args]) == self.N), \
+            'Output arrays should all have the same dimensions as time'
+
+        self.p = int(len(args) / 2)
+        self.qp = self.q * self.p
+        self.d = self.N * self.q * (self.p + 1)
+
+        self.tt = np.tile(time, self.p)                 # "extended" time
+        self.y = np.concatenate([args[::2]])            # (p, N)
+        self.yerr = np.concatenate([args[1::2]])
+        self.yerr2 = self.yerr**2
+
+        self._components_set = False
+        self._frozen_mask = np.array([])
+        self._mu, self._var = None, None
+        self._mu_var_iters = 0
+        self.update_muvar_after = 50
+        self.elbo_max_iter = 5000
+
+        self._device = device
+        self._comm = comm
+        self._ctx = None
+        self._prior_key = None
+        self.last_info = 0
+
+    # ------------------------------------------------------------ components
+    def set_components(self, nodes, weights, means, jitters):
+        """
+        Set the GPRN components: q node kernels, q*p weight kernels (flat
+        order node-major: weight of node j and output i at index j*p + i),
+        p mean functions and p jitters.  Bare objects are accepted for
+        single-element lists.
+        """
+        if isinstance(nodes, covfunc.covFunction):
+            nodes = [nodes]
+        if len(nodes) != self.q:
+            raise ValueError('Wrong number of nodes provided, '
+                             f'expected {self.q} got {len(nodes)}')
+        if isinstance(weights, covfunc.covFunction):
+            weights = [weights]
+        if len(weights) != self.qp:
+            raise ValueError('Wrong number of weights provided, '
+                             f'expected {self.qp} got {len(weights)}')
+        if isinstance(means, (int, float, meanfunc.meanFunction)):
+            means = [means]
+        if isinstance(jitters, (int, float)):
+            jitters = [jitters]
+
+        self.nodes = nodes
+        self.weights = weights
+        self.means = means
+        self.jitters = np.array(jitters, dtype=float)
+        self._components_set = True
+
+    def _component_chain(self):
+        return chain.from_iterable([self.nodes, self.weights, self.means])
+
+    def get_parameters(self, nodes=None, weights=None, means=None,
+                       jitters=None, include_frozen=False):
+        """ Values of all the GPRN parameters: nodes, weights, means, jitters """
+        given = (nodes, weights, means, jitters)
+        if not self._components_set and all(g is None for g in given):
+            raise ValueError('Cannot get parameters. '
+                             'Provide arguments or run set_components before.')
+        if self._components_set:
+            nodes, weights, means, jitters = (self.nodes, self.weights,
+                                              self.means, self.jitters)
+        pieces = []
+        for group in (nodes, weights, means):
+            if group is not None:
+                pieces += [c.get_parameters() for c in group]
+        if jitters is not None:
+            pieces += [np.array([j]) for j in jitters]
+        flat = np.concatenate(pieces).ravel()
+        return flat if include_frozen else flat[~self.frozen_mask]
+
+    @_array_input
+    def set_parameters(self, parameters: Array):
+        """ Set all parameters (full vector, or only the non-frozen ones) """
+        assert self._components_set, _NOT_SET
+        current = self.get_parameters(include_frozen=True)
+        n_all = self.n_parameters
+        n_free = n_all - self.frozen_mask.sum()
+
+        if parameters.size == n_all:
+            parameters[self.frozen_mask] = current[self.frozen_mask]
+        elif parameters.size == n_free:
+            for i, value in enumerate(current):
+                if self.frozen_mask[i]:
+                    parameters = np.insert(parameters, i, value)
+        else:
+            msg = f'Wrong number of parameters provided: got {parameters.size}, '
+            msg += f'expected {n_all}' if n_all == n_free else \
+                f'expected {n_all} (all) or {n_free} (not frozen)'
+            raise ValueError(msg)
+
+        for component in self._component_chain():
+            parameters = component.set_parameters(parameters)
+        self.jitters = parameters
+
+    @property
+    def n_parameters(self):
+        """ Total number of parameters """
+        assert self._components_set, _NOT_SET
+        return sum(c.pars.size for c in self._component_chain()) + self.jitters.size
+
+    @property
+    def parameters_dict(self):
+        """ Dictionary with parameters names and values """
+        assert self._components_set, _NOT_SET
+        out = {}
+        for label, group in (('node', self.nodes), ('weight', self.weights),
+                             ('mean', self.means)):
+            for i, comp in enumerate(group, start=1):
+                for name, value in zip(comp._param_names, comp.pars):
+                    out[f'{label}{i}.{name}'] = value
+        for i, jit in enumerate(self.jitters, start=1):
+            out[f'jitter{i}'] = jit
+        return out
+
+    def _set_frozen(self, value, index, name):
+        self.frozen_mask        # materialise the mask
+        if index is None and name is None:
+            raise ValueError('Provide either index or name')
+        if name is None:
+            self._frozen_mask[index] = value
+        elif index is None:
+            names = list(self.parameters_dict.keys())
+            if '*' in name:
+                stem = name.replace('*', '')
+                for i, known in enumerate(names):
+                    if stem in known:
+                        self._frozen_mask[i] = value
+            else:
+                assert name in names, f'Name "{name}" not found in parameters_dict'
+                self._frozen_mask[names.index(name)] = value
+
+    def freeze_parameter(self, index=None, name=None):
+        """ Freeze (do not fit for) a parameter by index or name; a "*" in
+        `name` matches every parameter whose name contains the rest. """
+        self._set_frozen(True, index, name)
+
+    def thaw_parameter(self, index=None, name=None):
+        """ Thaw (free) a parameter by index or name ("*" as in freeze). """
+        self._set_frozen(False, index, name)
+
+    def freeze_all_parameters(self):
+        self._frozen_mask = np.ones(self._frozen_mask.size, dtype=bool)
+
+    def thaw_all_parameters(self):
+        self._frozen_mask = np.zeros(self._frozen_mask.size, dtype=bool)
+
+    fix_parameter = freeze_parameter
+    fix_all_parameters = freeze_all_parameters
+    free_parameter = thaw_parameter
+    free_all_parameters = thaw_all_parameters
+
+    @property
+    def frozen_mask(self):
+        """ Boolean mask for the frozen parameters """
+        assert self._components_set, _NOT_SET
+        if self._frozen_mask.size == 0:
+            self._frozen_mask = np.full(self.n_parameters, False, dtype=bool)
+        return self._frozen_mask
+
+    @frozen_mask.setter
+    def frozen_mask(self, mask):
+        raise NotImplementedError(
+            'Do not set frozen_mask, use thaw_parameter/freeze_parameter')
+
+    # ------------------------------------------------------------- host glue
+    def _mean(self, means, time=None):
+        """ Mean functions evaluated at `time` (default: the data), flat (p*N,) """
+        t = self.time if time is None else time
+        n = t.size
+        m = np.zeros(n * self.p)
+        for i, fun in enumerate(means):
+            if fun is not None:
+                m[i * n:(i + 1) * n] = fun(t)
+        return m
+
+    def _u_to_fhatW(self, u):
+        """ Split a flat variational vector: nodes (1,q,N), weights (p,q,N) """
+        f = u[:self.q * self.N].reshape((1, self.q, self.N))
+        w = u[self.q * self.N:].reshape((self.p, self.q, self.N))
+        return f, w
+
+    def _initMuVar(self, nodes, weights, jitter):
+        """ Data-driven start point of the coordinate ascent (meanfield.py:491-510) """
+        jitter = np.asarray(jitter, dtype=float)
+        w_amp = np.array([w.pars[0] for w in weights][:self.p])[:, None]
+        absy, sgn = np.abs(self.y), np.sign(self.y)
+        mu_f, mu_w, var_f, var_w = [], [], [], []
+        for node in nodes:
+            a = node.pars[0]
+            mu_f.append(np.mean(np.sqrt(absy * a / w_amp) * sgn, axis=0))
+            mu_w.append(np.sqrt(absy * w_amp / a))
+            var_f.append(np.full(self.N, np.mean(jitter)))
+            var_w.append(jitter[:, None] * np.ones((self.p, self.N)))
+        mu = np.concatenate((mu_f, mu_w), axis=None)
+        var = np.concatenate((var_f, var_w), axis=None)
+        return mu, var
+
+    def _randomMuVar(self):
+        return np.random.randn(self.d, 1), np.random.rand(self.d, 1)
+
+    def _get_components(self, nodes=None, weights=None, means=None,
+                        jitters=None):
+        if all(i is None for i in (nodes, weights, means, jitters)) \
+                and not self._components_set:
+            raise ValueError(_NOT_SET)
+        nodes = self.nodes if nodes is None else nodes
+        weights = self.weights if weights is None else weights
+        means = self.means if means is None else means
+        jitters = self.jitters if jitters is None else jitters
+        return nodes, weights, means, jitters
+
+    # ---------------------------------------------------------------- device
+    def _backend(self):
+        """The GPU context of this problem (created on first use, after fork)."""
+        if self._ctx is None:
+            comm = self._comm
+            device = self._device
+            if device is None:
+                device = comm.local_rank if comm is not None else 0
+            ctx = _hip.Context(device)
+            if comm is not None and comm.world > 1:
+                ctx.comm_init(comm.world, comm.rank, comm.unique_id())
+            ctx.set_data(np.asarray(self.time, dtype=float), self.y, self.yerr, self.q)
+            if comm is not None and comm.world > 1:
+                ctx.set_owners(sharding.owners(self.p, self.q, comm.world))
+            self._ctx = ctx
+        return self._ctx
+
+    def _host_K(self, kernel, time):
+        """Kernel matrix evaluated in Python: the path for user-defined kernels."""
+        if isinstance(kernel, _TWO_ARGUMENT):
+            return kernel(time[:, None], time[None, :])
+        r = time[:, None] - time[None, :]
+        return kernel(r) + _NUGGET * np.eye(time.size)
+
+    def _send_kernel(self, ctx, gp, kernel):
+        program = kernel._device_program() if isinstance(kernel, covfunc.covFunction) else None
+        if program is None:
+            K = np.asarray(self._host_K(kernel, np.asarray(self.time, dtype=float)))
+            ctx.upload_K(gp, K)
+            return ('host', K.tobytes())
+        ops, params = program
+        nugget = not isinstance(kernel, _TWO_ARGUMENT)
+        ctx.set_kernel(gp, ops, params, nugget)
+        return (tuple(ops), params.tobytes(), nugget)
+
+    def _KMatrix(self, kernel, time=None):
+        """
+        Covariance matrix of `kernel` at the data times, with the reference's
+        1e-6 nugget (meanfield.py:413-434).  Built by the fused HIP fill kernel
+        for built-in kernels when `time` is the data's own time vector.
+        """
+        time = self.time if time is None else time
+        if time is self.time or (np.shape(time) == np.shape(self.time)
+                                 and np.array_equal(time, self.time)):
+            ctx = self._backend()
+            if isinstance(kernel, covfunc.covFunction) and kernel._device_program() is not None:
+                scratch = _hip.Context(ctx_device(ctx))
+                try:
+                    scratch.set_data(np.asarray(self.time, dtype=float), self.y[:1], self.yerr[:1], 1)
+                    self._send_kernel(scratch, 0, kernel)
+                    self._send_kernel(scratch, 1, covfunc.Constant(1.0))
+                    scratch.factor_priors()
+                    return scratch.get_matrix(_hip.M_K, 0)
+                finally:
+                    scratch.close()
+        return self._host_K(kernel, np.asarray(time, dtype=float))
+
+    def _setup_device(self, nodes, weights, means, jitters):
+        """The setup block of ELBOcalc (meanfield.py:618-624) on the GPU."""
+        ctx = self._backend()
+        key = []
+        for gp, kernel in enumerate(chain(nodes, weights)):
+            key.append(self._send_kernel(ctx, gp, kernel))
+        key = tuple(key)
+        if key != self._prior_key:
+            self.last_info = ctx.factor_priors()
+            self._prior_key = key
+        y = np.concatenate(self.y) - self._mean(means)
+        ctx.set_y_resid(np.array(np.array_split(y, self.p)))
+        ctx.set_jitters(np.asarray(jitters, dtype=float))
+        return ctx
+
+    # ------------------------------------------------------------------ ELBO
+    @property
+    def ELBO(self):
+        """ The evidence lower bound for the GPRN """
+        return self.ELBOcalc()[0]
+
+    def ELBOcalc(self, nodes=None, weights=None, means=None, jitters=None,
+                 max_iter=None, mu=None, var=None):
+        """
+        Calculate the evidence lower bound by coordinate ascent on the
+        variational means/variances.
+
+        Args:
+            nodes, weights, means, jitters: optional overrides of the components
+            max_iter: int, default 10000
+            mu, var: arrays (flat d or (p+1,q,N)), or 'init', 'random', 'previous'
+
+        Returns:
+            ELBO (float), mu (p+1,q,N), var (p+1,q,N), iterNumber (int)
+        """
+        nodes, weights, means, jitters = self._get_components(
+            nodes, weights, means, jitters)
+
+        if mu is None or var is None:
+            mu = var = 'init'
+        mu_s = mu if isinstance(mu, str) else None
+        var_s = var if isinstance(var, str) else None
+        if mu_s == 'previous' or var_s == 'previous':
+            if self._mu is not None:
+                mu, var = self._mu, self._var
+            else:
+                mu, var = self._initMuVar(nodes, weights, jitters)
+        elif mu_s == 'random' and var_s == 'random':
+            mu, var = self._randomMuVar()
+        elif mu_s == 'init' and var_s == 'init':
+            mu, var = self._initMuVar(nodes, weights, jitters)
+
+        if max_iter is None:
+            max_iter = 10000
+
+        ctx = self._setup_device(nodes, weights, means, jitters)
+        ctx.set_muvar(np.asarray(mu, dtype=float), np.asarray(var, dtype=float))
+
+        # the first sweep's update is thrown away, only its ELBO is kept
+        first, _, info = ctx.sweep(1, commit=False)
+        self.last_info = self.last_info or info
+        history = [first[0]]
+        ELBO = np.float64(first[0])
+        iterNumber = 0
+        while iterNumber < max_iter:
+            e, _, info = ctx.sweep(1, commit=True)
+            self.last_info = self.last_info or info
+            ELBO = np.float64(e[0])
+            history.append(ELBO)
+            iterNumber += 1
+            if iterNumber > 3:
+                last3 = np.array(history[-3:])
+                criteria = np.abs(np.std(last3) / np.mean(last3))
+                if criteria < 1e-3 and criteria != 0:
+                    mu, var = ctx.get_muvar()
+                    self._mu, self._var = mu, var
+                    self._elbo_history = np.array(history)
+                    return ELBO, mu, var, iterNumber
+
+        print('\nMax iterations reached')
+        mu, var = ctx.get_muvar()
+        self._elbo_history = np.array(history)
+        return ELBO, mu, var, iterNumber
+
+    def ELBOaux(self, Kf, Kw, Lf, Lw, y, jitt2, mu, var):
+        """
+        One coordinate-ascent sweep + ELBO from explicit host matrices
+        (compatibility with meanfield.py:651-710; `Lf`/`Lw` are recomputed on the
+        device and ignored).  Returns ELBO, new_mu, new_var, sigmaF (q,N,N),
+        sigmaW (q,p,N,N).
+        """
+        ctx = self._backend()
+        Kf = np.asarray(Kf, dtype=float).reshape(self.q, self.N, self.N)
+        Kw = np.asarray(Kw, dtype=float).reshape(self.qp, self.N, self.N)
+        for gp, K in enumerate(chain(Kf, Kw)):
+            ctx.upload_K(gp, K)
+        self._prior_key = None
+        self.last_info = ctx.factor_priors()
+        ctx.set_y_resid(np.asarray(y, dtype=float).reshape(self.p, self.N))
+        ctx.set_jitters(np.sqrt(np.asarray(jitt2, dtype=float)))
+        ctx.set_muvar(np.asarray(mu, dtype=float), np.asarray(var, dtype=float))
+        ctx.keep_sigma(True)
+        try:
+            e, _, info = ctx.sweep(1, commit=True)
+            sigmaF = np.array([ctx.get_matrix(_hip.M_SIGMA, j) for j in range(self.q)])
+            sigmaW = np.array([ctx.get_matrix(_hip.M_SIGMA, self.q + k)
+                               for k in range(self.qp)]).reshape(self.q, self.p, self.N, self.N)
+        finally:
+            ctx.keep_sigma(False)
+        self.last_info = self.last_info or info
+        new_mu, new_var = ctx.get_muvar()
+        return np.float64(e[0]), new_mu, new_var, sigmaF, sigmaW
+
+    def nELBO(self, parameters, max_iter=None):
+        """ Negative ELBO at `parameters` (warm-started, meanfield.py:1095-1111) """
+        assert self._components_set, _NOT_SET
+        self.set_parameters(parameters)
+        start = time_module.time()
+        elbo, _, _, _ = self.ELBOcalc(self.nodes, self.weights, self.means,
+                                      self.jitters, max_iter=max_iter,
+                                      mu='previous', var='previous')
+        took = 1e3 * (time_module.time() - start)
+        print(f'ELBO={elbo:7.2f} (took {took:5.2f} ms)' + 20 * ' ', end='\r', flush=True)
+        return -elbo
+
+    def optimize(self, vars=None, **kwargs):
+        """
+        Maximise the ELBO over the free parameters with scipy.optimize.minimize
+        (Nelder-Mead unless `method` is given).  `vars`: 'name' optimises only
+        that parameter, '-name' all but it, a list optimises those named.
+        """
+        from scipy.optimize import minimize
+        if vars is not None:
+            if isinstance(vars, str):
+                if '-' in vars:
+                    self.thaw_parameter(name='*')
+                    self.freeze_parameter(name=vars.replace('-', ''))
+                else:
+                    self.freeze_parameter(name='*')
+                    self.thaw_parameter(name=vars)
+            elif isinstance(vars, list):
+                self.freeze_parameter(name='*')
+                for name in vars:
+                    self.thaw_parameter(name=name)
+            else:
+                raise ValueError(f'`vars` should be str or list, got {type(vars)}')
+        kwargs.setdefault('method', 'Nelder-Mead')
+        res = minimize(self.nELBO, self.get_parameters(), **kwargs)
+        self.set_parameters(res.x)
+        return res
+
+
+def ctx_device(ctx):
+    """GPU ordinal a context lives on (contexts do not expose it in the C ABI)."""
+    return getattr(ctx, 'device', 0)

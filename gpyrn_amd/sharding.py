@@ -1,0 +1,96 @@
+"""Sharding of the q + q*p latent GPs over the GPUs of one node.
+
+Not in the reference (it is single-process NumPy).  The latent GPs of one
+half-sweep are independent (meanfield.py:769-792 nodes, :846-865 weights), so
+each rank factors and updates only the GPs it owns; per sweep the owners then
+broadcast their O(N) rows of mu/var (one grouped RCCL call per half-sweep) and
+one all-reduce sums the per-GP ELBO scalars -- see DESIGN.md §5.  No N x N
+matrix ever crosses xGMI.
+
+One process per GPU (``python -m torch.distributed.run`` or any launcher that
+sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT); the ncclUniqueId travels
+through a file in /tmp keyed by the launcher's pid, so no torch import is
+needed here.
+"""
+import os
+import time
+
+_generation = 0
+
+
+def owners(p, q, world):
+    """Rank that owns each latent GP, in the library's index order: nodes
+    0..q-1, then weights q + j*p + i.  Nodes go round-robin from rank 0, weights
+    continue round-robin after them, which balances each half-sweep on its own
+    (the two half-sweeps are sequential)."""
+    out = [j % world for j in range(q)]
+    out += [(q + k) % world for k in range(q * p)]
+    return out
+
+
+def local_gps(p, q, world, rank):
+    own = owners(p, q, world)
+    nodes = [g for g in range(q) if own[g] == rank]
+    weights = [g for g in range(q, q + q * p) if own[g] == rank]
+    return nodes, weights
+
+
+def helper_inverses(p, q, world, rank):
+    """Nodes j whose explicit K_j^-1 this rank must hold for the reference's
+    cumulative-trace quirk (meanfield.py:1039-1041: node j's trace term sums the
+    Sigma of every node k <= j): all j > the smallest locally owned node."""
+    nodes, _ = local_gps(p, q, world, rank)
+    if q < 2 or not nodes:
+        return []
+    return list(range(nodes[0] + 1, q))
+
+
+class Comm:
+    """World description + ncclUniqueId rendezvous for one communicator."""
+
+    def __init__(self, world=None, rank=None, local_rank=None, tag=None):
+        env = os.environ
+        self.world = int(env.get('WORLD_SIZE', 1)) if world is None else int(world)
+        self.rank = int(env.get('RANK', 0)) if rank is None else int(rank)
+        self.local_rank = int(env.get('LOCAL_RANK', self.rank)) if local_rank is None \
+            else int(local_rank)
+        global _generation
+        _generation += 1
+        port = env.get('MASTER_PORT', '0')
+        self._path = '/tmp/gprn_uid_%s_%s_%s_%d' % (
+            tag if tag is not None else os.getppid(), port, self.world, _generation)
+        self._id = None
+
+    def unique_id(self, timeout=300.0):
+        """Rank 0 creates the id and publishes it atomically; the others wait."""
+        if self._id is not None or self.world == 1:
+            return self._id
+        if self.rank == 0:
+            from . import _hip
+            self._id = _hip.comm_unique_id()
+            tmp = self._path + '.tmp%d' % os.getpid()
+            with open(tmp, 'wb') as f:
+                f.write(self._id)
+            os.replace(tmp, self._path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(self._path, 'rb') as f:
+                        data = f.read()
+                    if len(data) == 128:
+                        self._id = data
+                        break
+                except FileNotFoundError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f'no ncclUniqueId at {self._path} after {timeout}s')
+                time.sleep(0.01)
+        return self._id
+
+    def cleanup(self):
+        if self.rank == 0:
+            try:
+                os.unlink(self._path)
+            except OSError:
+                pass

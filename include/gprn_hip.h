@@ -1,0 +1,157 @@
+/* gprn_hip.h -- C ABI of libgprn_hip.so, the MI355X (gfx950) backend of the
+ * gpyrn mean-field ELBO hot path.
+ *
+ * The reference (iastro-pt/gpyrn) is pure Python and has no FFI; the boundary
+ * this library sits behind is `gpyrn/meanfield.py`'s `inference.ELBOcalc` /
+ * `ELBOaux` (meanfield.py:561-710) and the kernel-matrix assembly
+ * `inference._KMatrix` (meanfield.py:413-434) over `gpyrn/covfunc.py`.  Each
+ * entry point below names the reference code it replaces.  The only caller is
+ * gpyrn_amd/_hip.py (ctypes); INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - every function returns int: 0 ok; >0 a LAPACK-style `info` (order of the
+ *    first non-positive pivot, see gprn_last_info_gp); <0 GPRN_E_* below, with
+ *    text in gprn_last_error().
+ *  - all arrays are C-contiguous IEEE fp64 host buffers owned by the caller and
+ *    only touched during the call; device memory is owned by the context.
+ *  - one context = one GPU = one host thread at a time.  Create contexts after
+ *    fork()/in spawned workers (HIP state does not survive fork).
+ *  - latent GP index `gp`: 0..q-1 are the nodes, q + (j*p + i) is the weight
+ *    of node j / output i  (the reference's flat Kw order, meanfield.py:620,749).
+ */
+#ifndef GPRN_HIP_H
+#define GPRN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gprn_ctx gprn_ctx;
+
+enum {
+    GPRN_OK = 0,
+    GPRN_E_ARG = -1,      /* bad argument / call order */
+    GPRN_E_HIP = -2,      /* HIP runtime error */
+    GPRN_E_NODEV = -3,    /* no usable GPU */
+    GPRN_E_COMM = -4,     /* RCCL error */
+    GPRN_E_NOMEM = -5
+};
+
+/* ---- kernel ids of the fused covariance fill (covfunc.py line numbers) ---- */
+enum {
+    GPRN_K_CONSTANT = 0,            /* :123-125 */
+    GPRN_K_WHITENOISE = 1,          /* :144-148, square-matrix branch */
+    GPRN_K_SE = 2,                  /* :169-170 */
+    GPRN_K_PERIODIC = 3,            /* :211-213 */
+    GPRN_K_QP = 4,                  /* :251-255 */
+    GPRN_K_RQ = 5,                  /* :286-288 */
+    GPRN_K_RQP = 6,                 /* :310-313 */
+    GPRN_K_COSINE = 7,              /* :330-331 */
+    GPRN_K_EXPONENTIAL = 8,         /* :351-352 */
+    GPRN_K_MATERN32 = 9,            /* :370-373 */
+    GPRN_K_MATERN52 = 10,           /* :391-396 */
+    GPRN_K_GAMMAEXP = 11,           /* :431-432 */
+    GPRN_K_PIECEWISE = 12,          /* :469-473 */
+    GPRN_K_PACIOREK = 13,           /* :493-496 */
+    GPRN_K_NEWPERIODIC = 14,        /* :517-519 */
+    GPRN_K_QUASINEWPERIODIC = 15,   /* :543-546 */
+    GPRN_K_COSPERIODIC = 16,        /* :664-665 */
+    GPRN_K_QUASICOSPERIODIC = 17,   /* :687-689 */
+    GPRN_K_POLYNOMIAL = 18,         /* :454-455, two-argument */
+    GPRN_K_HARMONICPERIODIC = 19,   /* :598-607, two-argument */
+    GPRN_K_QUASIHARMONICPERIODIC = 20, /* :631-642, two-argument */
+    GPRN_K_DSE = 21,                /* :182-185 */
+    GPRN_K_DPERIODIC = 22,          /* :215-221 */
+    GPRN_K_DQP = 23,                /* :257-266 */
+    GPRN_K_COUNT = 24
+};
+/* postfix opcodes of a kernel expression (covfunc.py:65-77 Sum/Multiplication) */
+enum { GPRN_OP_PUSH = 0, GPRN_OP_ADD = 1, GPRN_OP_MUL = 2 };
+#define GPRN_MAX_OPS 32
+#define GPRN_MAX_KPARAMS 64
+
+/* ---- context ---- */
+int gprn_device_count(void);
+/* Replaces nothing in the reference (it has no device); one per GPU. */
+int gprn_create(gprn_ctx** out, int device_id);
+void gprn_destroy(gprn_ctx* ctx);
+const char* gprn_last_error(const gprn_ctx* ctx);
+/* which latent GP the last positive `info` belongs to (-1 if none) */
+int gprn_last_info_gp(const gprn_ctx* ctx);
+
+/* ---- problem: inference.__init__ data layout, meanfield.py:106-134 ----
+ * y, yerr are (p, N) row-major: the reference's self.y / self.yerr. */
+int gprn_set_data(gprn_ctx* ctx, int N, int p, int q,
+                  const double* time, const double* y, const double* yerr);
+
+/* ---- multi-GPU sharding (new): one context per rank/GPU.
+ * comm_init before set_data; set_owners after set_data and before set_kernel:
+ * latent GP g is factored and updated by rank owner[g] (q + q*p entries). */
+int gprn_comm_unique_id(char* id128);
+int gprn_comm_init(gprn_ctx* ctx, int world, int rank, const char* id128);
+int gprn_set_owners(gprn_ctx* ctx, const int* owner);
+int gprn_comm_barrier_max(gprn_ctx* ctx, double* value); /* all-reduce(max) + sync */
+
+/* ---- per-ELBOcalc setup: meanfield.py:618-624 ----
+ * set_kernel: latent GP `gp` gets K = expr(t_i, t_j) (+ 1e-6 I when add_nugget,
+ * meanfield.py:432-433); ops = n_ops triples (opcode, kernel id, param offset).
+ * upload_K: K evaluated by the caller (user-defined covFunction subclasses). */
+int gprn_set_kernel(gprn_ctx* ctx, int gp, const int32_t* ops, int n_ops,
+                    const double* params, int n_params, int add_nugget);
+int gprn_upload_K(gprn_ctx* ctx, int gp, const double* K);
+int gprn_set_y_resid(gprn_ctx* ctx, const double* y_minus_mean);   /* (p,N), :623-624 */
+int gprn_set_jitters(gprn_ctx* ctx, const double* jitters);        /* (p), :618 */
+/* covariance fill + chol(K) (+ K^-1 pieces the sweep needs): replaces
+ * _KMatrix (:413-434) and _cholNugget (:71-89) of the setup block :619-622. */
+int gprn_factor_priors(gprn_ctx* ctx);
+
+/* ---- variational state: mu/var in the reference's flat layout (d = N q (p+1)),
+ * meanfield.py:473-489 ---- */
+int gprn_set_muvar(gprn_ctx* ctx, const double* mu, const double* var);
+int gprn_get_muvar(gprn_ctx* ctx, double* mu, double* var);
+
+/* ---- the hot loop: n_sweeps x ELBOaux (meanfield.py:651-710 = _updateSigMu
+ * :713-893 + _entropy :1069-1093 + _expectedLogPrior :992-1067 +
+ * _expectedLogLike :895-990).  elbo_out[n_sweeps]; parts_out[3*n_sweeps] =
+ * (LogL, LogP, Ent) per sweep, may be NULL.  commit=0 evaluates the sweep but
+ * leaves mu/var untouched (ELBOcalc's discarded first call, :627). */
+int gprn_sweep(gprn_ctx* ctx, int n_sweeps, int commit,
+               double* elbo_out, double* parts_out);
+
+/* ---- read-back for tests and the ELBOaux compatibility shim ---- */
+enum {
+    GPRN_M_K = 0,        /* prior covariance K_gp (N,N) */
+    GPRN_M_KLINV = 1,    /* chol(K_gp)^-1, lower */
+    GPRN_M_SIGMA = 2     /* variational covariance of the last sweep (N,N) */
+};
+int gprn_keep_sigma(gprn_ctx* ctx, int on);   /* form Sigma explicitly during sweeps (ELBOaux shim) */
+int gprn_get_matrix(gprn_ctx* ctx, int which, int gp, double* out);
+int gprn_get_logdet_K(gprn_ctx* ctx, double* out /* q+q*p */);
+
+/* ---- timing hooks used by bench.py (HIP events on the library's stream) ----
+ * milliseconds spent in, and launches of, each kernel family since the last
+ * reset; only collected while profiling is enabled (adds event records). */
+enum { GPRN_T_FILL = 0, GPRN_T_BUILD_B = 1, GPRN_T_DIAG = 2, GPRN_T_PANEL = 3,
+       GPRN_T_UPDATE = 4, GPRN_T_LAUUM = 5, GPRN_T_VEC = 6, GPRN_T_COUNT = 7 };
+int gprn_profile_enable(gprn_ctx* ctx, int family_mask);   /* bit f = time family GPRN_T_f; 0 = off */
+int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
+                      int64_t* launches /*GPRN_T_COUNT*/, int reset);
+
+/* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----
+ * C (+)= A.B on host matrices through the MFMA tile kernel; modes as in
+ * csrc/gemm_tile.hip (a_mode 0: A[m][k], 1: A[k][m]; b_mode 0: B[n][k], 1: B[k][n];
+ * c_mode 0: C=AB, 1: C-=AB, 2: C=-AB).  M, N multiples of 128; K multiple of 16. */
+int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
+                   int c_mode, const double* A, const double* B, double* C);
+/* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */
+int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
+                            double* L, double* Linv);
+/* out = lower(X^T X) for lower-triangular X */
+int gprn_test_lauum(gprn_ctx* ctx, int n, const double* X, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPRN_HIP_H */

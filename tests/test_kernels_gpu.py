@@ -1,0 +1,78 @@
+"""Each HIP kernel family on its own against NumPy (through the C ABI's
+diagnostic entry points).  Needs an MI355X: run with -m gpu."""
+import numpy as np
+import pytest
+
+from gpyrn_amd import _hip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize('a_mode,b_mode', [(0, 0), (0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize('c_mode', [0, 1, 2])
+def test_tile_gemm_layouts(ctx, a_mode, b_mode, c_mode):
+    # asymmetric integer data: any row/col or operand-order swap shows up exactly
+    rng = np.random.RandomState(5 + 4 * a_mode + 2 * b_mode + c_mode)
+    M, N, K = 256, 128, 48
+    A = rng.randint(-4, 5, size=(M, K)).astype(float)
+    B = rng.randint(-4, 5, size=(K, N)).astype(float)
+    C0 = rng.randint(-9, 10, size=(M, N)).astype(float)
+    out = ctx.test_gemm(A, B, C0, a_mode, b_mode, c_mode)
+    want = {0: A @ B, 1: C0 - A @ B, 2: -(A @ B)}[c_mode]
+    assert np.array_equal(out, want)
+
+
+def test_tile_gemm_random_fp64(ctx):
+    rng = np.random.RandomState(1)
+    A = rng.standard_normal((384, 512))
+    B = rng.standard_normal((512, 256))
+    C0 = rng.standard_normal((384, 256))
+    out = ctx.test_gemm(A, B, C0, 0, 0, 1)
+    np.testing.assert_allclose(out, C0 - A @ B, rtol=0, atol=5e-12)
+
+
+def _spd(n, rng, cond_shift=1.0):
+    t = np.sort(rng.uniform(0, 0.4 * n, n))
+    r = t[:, None] - t[None, :]
+    return np.exp(-0.5 * r**2 / 30.0**2) * np.outer(1 + rng.rand(n), 1 + rng.rand(n)) ** 0 \
+        + cond_shift * np.eye(n)
+
+
+@pytest.mark.parametrize('n,batch', [(128, 1), (256, 2), (640, 3)])
+def test_factor_invert(ctx, n, batch):
+    rng = np.random.RandomState(n)
+    A = np.array([_spd(n, rng, 1.0 + b) for b in range(batch)])
+    L, X, info = ctx.test_factor_invert(A)
+    assert info == 0
+    for b in range(batch):
+        Lref = np.linalg.cholesky(A[b])
+        np.testing.assert_allclose(L[b], Lref, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.tril(X[b]), np.linalg.inv(Lref), rtol=0, atol=1e-11)
+        # diagonal tiles of X carry explicit zeros above the diagonal
+        for k in range(n // 128):
+            blk = X[b][k * 128:(k + 1) * 128, k * 128:(k + 1) * 128]
+            assert np.array_equal(np.triu(blk, 1), np.zeros_like(blk))
+        np.testing.assert_allclose(np.tril(X[b]) @ Lref, np.eye(n), rtol=0, atol=1e-11)
+
+
+def test_factor_invert_not_positive_definite(ctx):
+    rng = np.random.RandomState(3)
+    A = _spd(256, rng)
+    A[200, 200] = -1.0
+    L, X, info = ctx.test_factor_invert(A)
+    assert info == 201                         # LAPACK-style order of the failing minor
+    assert np.isnan(L[0][255, 255])            # jax semantics: NaN, no exception
+
+
+def test_lauum(ctx):
+    rng = np.random.RandomState(9)
+    X = np.tril(rng.standard_normal((384, 384)))
+    out = ctx.test_lauum(X)
+    np.testing.assert_allclose(np.tril(out), np.tril(X.T @ X), rtol=0, atol=1e-11)
