@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ELBO sweeps per second at BASELINE config 3
+(N=4096 time stamps, p=3 outputs, q=2 nodes -> 8 latent GPs), fp64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--no-cpu]
+
+One "step" = one ELBOaux-equivalent sweep (meanfield.py:651-710) with the
+priors already factored, inputs resident in HBM.  With --gpus N > 1 (launched
+by torch.distributed.run, one rank per GPU) the same problem's latent GPs are
+sharded over the ranks (gpyrn_amd/sharding.py) -- strong scaling.  Rank 0
+prints one JSON line.  No torch import: the launcher only provides RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_*.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gpyrn_amd import _hip, covfunc, meanfunc, sharding, synth  # noqa: E402
+import gpyrn_amd as gpyrn  # noqa: E402
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet, fp64 matrix (= fp64 vector); see DESIGN.md §6
+TILE = 128
+
+
+def update_flops(T, G_nodes, G_weights):
+    """Algorithmic flops of the `update` launches of one sweep: trailing SYRK of
+    POTRF + right-hand-side updates of the inverse, per latent GP, tile by tile
+    (diagonal SYRK tiles count their lower triangle only)."""
+    full = 2.0 * TILE**3
+    diag = 2.0 * TILE * (TILE * (TILE + 1) / 2)
+    per_gp = 0.0
+    for k in range(T):
+        m = T - 1 - k
+        per_gp += (m * (m - 1) / 2) * full + m * diag      # SYRK tiles
+        per_gp += m * (k + 1) * full                       # inverse rows
+    return per_gp * (G_nodes + G_weights)
+
+
+def sweep_flops(N, p, q):
+    """minimal exact sweep, (2G/3 + (q-1)/3) N^3."""
+    G = q * (p + 1)
+    return (2 * G / 3 + (q - 1) / 3) * float(N)**3
+
+
+def cpu_baseline(N, p, q, kind):
+    """The reference's formulation (oracle/cpu_ref.sweep_ref, 7 N^3 per latent GP)
+    on the host cores, on a bounded sample: the same N with p=1, q=1 (2 of the
+    G latent GPs), scaled by G/2 -- every GP costs the same in that formulation."""
+    from oracle import cpu_ref
+    t, ys, es = synth.rv_series(N, 1)
+    spec = synth.component_spec(1, 1, kind)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    y = np.array(ys)
+    Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, y)
+    mu, var = cpu_ref.init_mu_var(y, [n.pars[0] for n in nodes], [w.pars[0] for w in weights], jit)
+    t0 = time.time()
+    cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu, var)
+    dt = time.time() - t0
+    G = q * (p + 1)
+    return {'value': 1.0 / (dt * G / 2), 'unit': 'sweeps/s', 'cores': os.cpu_count(),
+            'kind': 'port',
+            'sample': f'one reference-formulation sweep at N={N}, p=1, q=1 (2 of {G} latent GPs, '
+                      f'{dt:.1f} s, NumPy/SciPy LAPACK, all host cores), scaled by {G}/2'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', type=int, default=3)
+    ap.add_argument('--no-cpu', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    rank = int(os.environ.get('RANK', 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run '
+                     '(one rank per GPU)')
+        a.gpus = world
+    N, p, q, kind = synth.CONFIGS[a.config]
+    comm = sharding.Comm() if world > 1 else None
+
+    t, ys, es = synth.rv_series(N, p)
+    spec = synth.component_spec(p, q, kind)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    g = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair], comm=comm)
+    g.set_components(nodes, weights, means, jit)
+
+    t0 = time.time()
+    ctx = g._setup_device(nodes, weights, means, jit)     # fill + chol(K): once per ELBOcalc
+    ctx.barrier_max(0.0)
+    t_setup = time.time() - t0
+    mu0, var0 = g._initMuVar(nodes, weights, jit)
+    ctx.set_muvar(mu0, var0)
+
+    if a.warmup > 0:
+        ctx.sweep(a.warmup, commit=True)
+    ctx.profile_enable(['update'])
+    ctx.barrier_max(0.0)                                   # barrier + device sync
+    t0 = time.perf_counter()
+    elbo, parts, info = ctx.sweep(a.steps, commit=True)    # K sweeps, one host sync at the end
+    dt_local = time.perf_counter() - t0
+    dt = ctx.barrier_max(dt_local)                         # MAX over ranks
+    prof = ctx.profile_read()
+    ctx.profile_enable([])
+
+    if rank == 0:
+        nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
+        ms_upd, n_upd = prof['update']
+        T = (N + TILE - 1) // TILE
+        fl = update_flops(T, len(nodes_l), len(weights_l)) * a.steps
+        achieved = fl / (ms_upd * 1e-3) / 1e12 if ms_upd > 0 else None
+        out = {
+            'metric': 'ELBO iterations/sec (N=%d, P=%d, Q=%d)' % (N, p, q),
+            'value': a.steps / dt,
+            'unit': 'sweeps/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * dt / a.steps,
+            'higher_is_better': True,
+            'scaling': 'strong',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': 'BASELINE config %d: N=%d, p=%d outputs, q=%d nodes, %s nodes / SE '
+                                   'weights, synthetic RV series (seed 0)' % (a.config, N, p, q, kind),
+                       'latent_gps': q * (p + 1), 'sharding': 'latent GPs over %d rank(s)' % world},
+            'sweep_tflops': sweep_flops(N, p, q) * a.steps / dt / 1e12,
+            'setup_s': t_setup,
+            'elbo_last': float(elbo[-1]), 'info': int(info),
+            'roofline': {
+                'kernel': 'k_tile_gemm (update launches: trailing SYRK + inverse rows, v_mfma_f64_16x16x4_f64)',
+                'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                'unit': 'TFLOP/s',
+                'frac': (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,
+                'traffic': None,
+                'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
+                'flops_per_launch': (fl / n_upd) if n_upd else None,
+            },
+        }
+        if world == 1 and not a.no_cpu:
+            out['cpu_baseline'] = cpu_baseline(N, p, q, kind)
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        ctx.barrier_max(0.0)
+        comm.cleanup()
+
+
+if __name__ == '__main__':
+    main()

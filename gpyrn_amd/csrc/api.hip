@@ -227,6 +227,10 @@ extern "C" int gprn_set_kernel(gprn_ctx* c, int gp, const int32_t* ops, int n_op
     }
     if (depth != 1) return bad(c, "set_kernel: malformed expression");
     KernelSpec& ks = c->kspec[gp];
+    if (ks.set && !ks.uploaded && ks.n_ops == n_ops && ks.n_params == n_params &&
+        ks.nugget == (add_nugget ? 1 : 0) && !memcmp(ks.ops, ops, 3 * n_ops * sizeof(int32_t)) &&
+        (!n_params || !memcmp(ks.params, params, n_params * sizeof(double))))
+        return GPRN_OK;                      // unchanged: a finished factorisation stays valid
     ks.set = true; ks.uploaded = false;
     ks.n_ops = n_ops; ks.n_params = n_params; ks.nugget = add_nugget ? 1 : 0;
     memcpy(ks.ops, ops, 3 * n_ops * sizeof(int32_t));

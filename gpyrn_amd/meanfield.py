@@ -302,16 +302,29 @@ class inference:
         r = time[:, None] - time[None, :]
         return kernel(r) + _NUGGET * np.eye(time.size)
 
-    def _send_kernel(self, ctx, gp, kernel):
+    def _kernel_spec(self, kernel):
+        """How a kernel reaches the device: a postfix program for the fused fill
+        (built-ins and their sums/products), or a host-evaluated matrix."""
         program = kernel._device_program() if isinstance(kernel, covfunc.covFunction) else None
         if program is None:
-            K = np.asarray(self._host_K(kernel, np.asarray(self.time, dtype=float)))
-            ctx.upload_K(gp, K)
-            return ('host', K.tobytes())
+            K = np.asarray(self._host_K(kernel, np.asarray(self.time, dtype=float)), dtype=float)
+            return ('host', K)
         ops, params = program
-        nugget = not isinstance(kernel, _TWO_ARGUMENT)
-        ctx.set_kernel(gp, ops, params, nugget)
-        return (tuple(ops), params.tobytes(), nugget)
+        return ('device', tuple(ops), np.asarray(params, dtype=float),
+                not isinstance(kernel, _TWO_ARGUMENT))
+
+    @staticmethod
+    def _spec_key(spec):
+        if spec[0] == 'host':
+            return ('host', spec[1].tobytes())
+        return ('device', spec[1], spec[2].tobytes(), spec[3])
+
+    @staticmethod
+    def _send_spec(ctx, gp, spec):
+        if spec[0] == 'host':
+            ctx.upload_K(gp, spec[1])
+        else:
+            ctx.set_kernel(gp, spec[1], spec[2], spec[3])
 
     def _KMatrix(self, kernel, time=None):
         """
@@ -327,8 +340,8 @@ class inference:
                 scratch = _hip.Context(ctx_device(ctx))
                 try:
                     scratch.set_data(np.asarray(self.time, dtype=float), self.y[:1], self.yerr[:1], 1)
-                    self._send_kernel(scratch, 0, kernel)
-                    self._send_kernel(scratch, 1, covfunc.Constant(1.0))
+                    self._send_spec(scratch, 0, self._kernel_spec(kernel))
+                    self._send_spec(scratch, 1, self._kernel_spec(covfunc.Constant(1.0)))
                     scratch.factor_priors()
                     return scratch.get_matrix(_hip.M_K, 0)
                 finally:
@@ -338,11 +351,11 @@ class inference:
     def _setup_device(self, nodes, weights, means, jitters):
         """The setup block of ELBOcalc (meanfield.py:618-624) on the GPU."""
         ctx = self._backend()
-        key = []
-        for gp, kernel in enumerate(chain(nodes, weights)):
-            key.append(self._send_kernel(ctx, gp, kernel))
-        key = tuple(key)
-        if key != self._prior_key:
+        specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
+        key = tuple(self._spec_key(s) for s in specs)
+        if key != self._prior_key:             # unchanged hyper-parameters keep their factors
+            for gp, spec in enumerate(specs):
+                self._send_spec(ctx, gp, spec)
             self.last_info = ctx.factor_priors()
             self._prior_key = key
         y = np.concatenate(self.y) - self._mean(means)
