@@ -20,78 +20,176 @@
 
 #include <math.h>
 
-#define DPITCH 129
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+#define DP 130            // LDS pitch of the 128x128 image (doubles): conflict-free MFMA operand fetch
+#define XP 18             // pitch of the 16x16 inverted diagonal sub-block
+#define NSB 8             // 16x16 sub-blocks per tile edge
 
 // ------------------------------------------------------------------ diag
-// Unblocked potf2 + inverse of one 128x128 diagonal tile, in LDS.  The strict
-// upper triangle of the LDS image holds the transposed running right-hand
-// side: S[c][i] = R[i][c] (c < i).  Step k: v = column k of S scaled by
-// 1/l_kk (rows i>k: L_ik; rows c<k: X_kc); then S[a][b] -= v'[a] v[b] for
-// b > k, a in [0,k] U [b,127], with v'[k] = 1/l_kk.
+// potrf + inverse of one 128x128 diagonal tile: one workgroup, whole tile in LDS,
+// blocked by 16 so that all O(n^3) work runs on v_mfma_f64_16x16x4_f64.
+//
+// LDS image S: the lower triangle holds B then L; the strict upper triangle holds
+// the transposed running right-hand side of L X = I:  S[c][i] = R[i][c] (c < i).
+// With that storage every step of the blocked algorithm is the same formula on
+// 16x16 sub-tiles S(P,Q):
+//   base   (wave 0)   : S(kb,kb) -> L_kb (in place), X_kb = L_kb^-1 -> XD (register/shuffle potf2)
+//   panel  (all waves): S(P,kb) <- S(P,kb) X_kb^T            for every P != kb
+//   update (waves 1-3): S(P,Q) -= S(P,kb) S(Q,kb)^T          Q > kb, P < kb or P >= Q
+//                       S(kb,Q)  = -X_kb^T S(Q,kb)^T          (first touch of R's row kb)
+// and wave 0 updates S(kb+1,kb+1) first and then runs base(kb+1) while the other
+// waves finish update(kb) -- the 16-pivot dependency chain overlaps the MFMA work.
+
+// potf2 + trtri2 of a 16x16 block held in registers: lane (r = l&15, g = l>>4) owns
+// columns 4g..4g+3 of row r; strict upper = transposed right-hand side, as in S.
+__device__ __forceinline__ void base16(double* __restrict__ St, double* __restrict__ xd,
+                                       double* __restrict__ Xg, int ld, int* info, int slot,
+                                       int pivot0)
+{
+    const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * g + j;
+        a[j] = (b <= r) ? St[r * DP + b] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int gk = k >> 2, jk = k & 3;
+        const double piv = __shfl(a[jk], k + 16 * gk, 64);
+        if (!(piv > 0.0) && l == 0 && info[slot] == 0) info[slot] = pivot0 + k + 1;
+        const double lkk = sqrt(piv);          // NaN from here on for a non-PD input,
+        const double inv = 1.0 / lkk;          // like jnp.linalg.cholesky
+        double cv = a[jk] * inv;               // column k scaled (meaningful in group gk)
+        if (r == k) cv = inv;                  // v'[k] = 1/l_kk feeds row k of the inverse
+        if (g == gk) a[jk] = (r == k) ? lkk : cv;
+        const double vrow = __shfl(cv, r + 16 * gk, 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = 4 * g + j;
+            const double vc = __shfl(cv, b + 16 * gk, 64);
+            if (b > k && (r <= k || r >= b)) a[j] -= vrow * vc;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = 4 * g + j;
+        if (b <= r) St[r * DP + b] = a[j];
+        if (b > r) {
+            xd[b * XP + r] = a[j];  xd[r * XP + b] = 0.0;
+            Xg[(size_t)b * ld + r] = a[j];  Xg[(size_t)r * ld + b] = 0.0;
+        } else if (b == r) {
+            const double x = 1.0 / a[j];
+            xd[r * XP + r] = x;
+            Xg[(size_t)r * ld + r] = x;
+        }
+    }
+}
+
+// C(16x16 at Ct) = Cin - A B^T with A rows at At (element (m,k) = At[m*as_r + k*as_k]),
+// B rows at Bt (element (k,n) = Bt[n*DP + k]); K = 16.  `set`: C = -A B^T (no read).
+__device__ __forceinline__ void tile16(double* __restrict__ Ct, const double* __restrict__ At,
+                                       int as_r, int as_k, const double* __restrict__ Bt, bool set)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+    v4d acc;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = set ? 0.0 : Ct[(fk + 4 * t) * DP + fr];
+    double af[4], bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        af[s] = -At[fr * as_r + (4 * s + fk) * as_k];
+        bf[s] = Bt[fr * DP + 4 * s + fk];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Ct[(fk + 4 * t) * DP + fr] = acc[t];
+}
+
+// S(P,kb) <- S(P,kb) X_kb^T   (B operand from xd, element (k,n) = X_kb[n][k] = xd[n*XP + k])
+__device__ __forceinline__ void panel16(double* __restrict__ Ct, const double* __restrict__ xd)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    double af[4], bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        af[s] = Ct[fr * DP + 4 * s + fk];
+        bf[s] = xd[fr * XP + 4 * s + fk];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) Ct[(fk + 4 * t) * DP + fr] = acc[t];
+}
+
 __global__ __launch_bounds__(256)
 void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info)
 {
-    extern __shared__ double S[];           // 128 x DPITCH, then dg[128]
-    double* dg = S + 128 * DPITCH;
+    extern __shared__ __attribute__((aligned(16))) double S[];   // 128 x DP, then 2 x 16 x XP
+    double* XD = S + 128 * DP;
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     double* Bt = ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off;
     double* Xt = ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6;
 
     for (int e = tid; e < 128 * 128; e += 256) {
         const int r = e >> 7, c = e & 127;
-        S[r * DPITCH + c] = (c <= r) ? Bt[(size_t)r * ld + c] : 0.0;
+        S[r * DP + c] = (c <= r) ? Bt[(size_t)r * ld + c] : 0.0;
     }
     __syncthreads();
+    if (wave == 0) base16(S, XD, Xt, ld, info, slot, kblk * GPRN_TILE);
+    __syncthreads();
 
-    const int b_lane = tid & 127, half = tid >> 7;
-    for (int k = 0; k < 128; ++k) {
-        __syncthreads();                      // step k-1's rank-1 update is complete
-        const double piv = S[k * DPITCH + k];
-        if (tid == 0 && !(piv > 0.0)) {
-            if (info[slot] == 0) info[slot] = kblk * GPRN_TILE + k + 1;
-        }
-        const double lkk = sqrt(piv);         // NaN from here on for a non-PD input,
-        const double inv = 1.0 / lkk;         // like jnp.linalg.cholesky
-        if (tid < 128) {                      // nobody writes S[k][k] in this step
-            if (tid != k) S[tid * DPITCH + k] *= inv;
-            else dg[k] = lkk;
-        }
+    for (int kb = 0; kb < NSB; ++kb) {
+        const double* xd = XD + (kb & 1) * 16 * XP;
+        // ---- panel: every sub-tile of column kb except the diagonal one
+        for (int P = wave; P < NSB; P += 4)
+            if (P != kb) panel16(S + (16 * P) * DP + 16 * kb, xd);
         __syncthreads();
-        const int b = k + 1 + b_lane;
-        if (b < 128) {
-            const double vb = S[b * DPITCH + k];
-            if (half == 0) {
-                for (int a = 0; a < k; ++a)
-                    S[a * DPITCH + b] -= S[a * DPITCH + k] * vb;
-                S[k * DPITCH + b] -= inv * vb;
-            } else {
-                for (int a = b; a < 128; ++a)
-                    S[a * DPITCH + b] -= S[a * DPITCH + k] * vb;
+        if (kb == NSB - 1) break;
+        // ---- update, overlapped with the next base factorisation
+        if (wave == 0) {
+            const int n = kb + 1;
+            tile16(S + (16 * n) * DP + 16 * n, S + (16 * n) * DP + 16 * kb, DP, 1,
+                   S + (16 * n) * DP + 16 * kb, false);
+            base16(S + (16 * n) * DP + 16 * n, XD + (n & 1) * 16 * XP,
+                   Xt + (size_t)(16 * n) * ld + 16 * n, ld, info, slot,
+                   kblk * GPRN_TILE + 16 * n);
+        } else {
+            int idx = 0;
+            for (int Q = kb + 1; Q < NSB; ++Q) {
+                const double* Bq = S + (16 * Q) * DP + 16 * kb;
+                for (int P = 0; P < NSB; ++P) {
+                    if (P > kb && P < Q) continue;
+                    if (P == kb + 1 && Q == kb + 1) continue;          // wave 0 has it
+                    if ((idx++ % 3) != wave - 1) continue;
+                    double* Ct = S + (16 * P) * DP + 16 * Q;
+                    if (P == kb) tile16(Ct, xd, 1, XP, Bq, true);      // A = X_kb^T
+                    else tile16(Ct, S + (16 * P) * DP + 16 * kb, DP, 1, Bq, false);
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
 
+    // L -> B tile (lower), X -> X tile; X's diagonal 16x16 blocks were written by base16
     for (int e = tid; e < 128 * 128; e += 256) {
         const int r = e >> 7, c = e & 127;
-        if (c < r) {
-            Bt[(size_t)r * ld + c] = S[r * DPITCH + c];
-            Xt[(size_t)r * ld + c] = S[c * DPITCH + r];
-        } else if (c == r) {
-            Bt[(size_t)r * ld + c] = dg[r];
-            Xt[(size_t)r * ld + c] = 1.0 / dg[r];
-        } else {
-            Xt[(size_t)r * ld + c] = 0.0;
-        }
+        if (c <= r) Bt[(size_t)r * ld + c] = S[r * DP + c];
+        if ((r >> 4) != (c >> 4)) Xt[(size_t)r * ld + c] = (c < r) ? S[c * DP + r] : 0.0;
     }
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info)
 {
     static bool attr_set = false;
-    const size_t shmem = (128 * DPITCH + 128) * sizeof(double);
+    const size_t shmem = (128 * DP + 2 * 16 * XP) * sizeof(double);
     if (!attr_set) {
         HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_block),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
