@@ -22,25 +22,28 @@ static hipEvent_t prof_event(gprn_ctx* c)
     return e;
 }
 
-void prof_begin(gprn_ctx* c, int fam)
+void prof_begin(gprn_ctx* c, int fam, hipStream_t stream)
 {
     if (!c->prof.on || !((c->prof_mask >> fam) & 1)) { c->prof_open = false; return; }
+    if (!stream) stream = c->stream;
     Profiler::Rec r{fam, prof_event(c), prof_event(c)};
-    hipEventRecord(r.a, c->stream);
+    hipEventRecord(r.a, stream);
     c->prof.pending.push_back(r);
     c->prof_open = true;
+    c->prof_stream = stream;
 }
 
 void prof_end(gprn_ctx* c)
 {
     if (!c->prof_open) return;
-    hipEventRecord(c->prof.pending.back().b, c->stream);
+    hipEventRecord(c->prof.pending.back().b, c->prof_stream);
     c->prof_open = false;
 }
 
 static void prof_collect(gprn_ctx* c)
 {
     hipStreamSynchronize(c->stream);
+    hipStreamSynchronize(c->stream2);
     for (auto& r : c->prof.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -136,7 +139,14 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
     gprn_ctx* c = new gprn_ctx();
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    // the chain stream outranks the bulk stream so that the small, latency-critical kernels of
+    // the factorisation are dispatched ahead of queued trailing-update workgroups
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return GPRN_E_HIP;
     }
@@ -157,6 +167,10 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     free_problem(c);
     dev_free(c->d_tasks);
     dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
+    hipStreamSynchronize(c->stream2);
+    hipEventDestroy(c->ev_panel);
+    hipEventDestroy(c->ev_rest);
+    hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
 }

@@ -20,6 +20,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 #define DP 130            // LDS pitch of the 128x128 image (doubles): conflict-free MFMA operand fetch
@@ -59,8 +61,8 @@ __device__ __forceinline__ void base16(double* __restrict__ St, double* __restri
         const int gk = k >> 2, jk = k & 3;
         const double piv = __shfl(a[jk], k + 16 * gk, 64);
         if (!(piv > 0.0) && l == 0 && info[slot] == 0) info[slot] = pivot0 + k + 1;
-        const double lkk = sqrt(piv);          // NaN from here on for a non-PD input,
-        const double inv = 1.0 / lkk;          // like jnp.linalg.cholesky
+        const double inv = rsqrt(piv);         // NaN from here on for a non-PD input,
+        const double lkk = piv * inv;          // like jnp.linalg.cholesky
         double cv = a[jk] * inv;               // column k scaled (meaningful in group gk)
         if (r == k) cv = inv;                  // v'[k] = 1/l_kk feeds row k of the inverse
         if (g == gk) a[jk] = (r == k) ? lkk : cv;
@@ -208,6 +210,20 @@ static inline int64_t toff(int ti, int tj, int ld) {
     return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE;
 }
 
+// Two-level blocking.  Tile steps are grouped into outer panels of GPRN_OUTER tiles.
+// Inside a panel (tile step k in [k0,k1)) only what the panel itself needs is
+// updated right away, with K = 128:
+//     B_ij -= L_ik L_jk^T   j in (k, k1),  i >= j           (all rows, panel columns)
+//     R_ic -= L_ik X_kc     i in (k, k1),  c <= k           (panel rows, all columns)
+// and everything outside is updated once per panel with K = (k1-k0)*128 -- each
+// trailing tile is then read and written once per 512 columns of L instead of
+// once per 128 (16 -> 64 flop per HBM byte: MFMA-bound instead of HBM-bound):
+//     B_ij -= L[i,k0:k1] L[j,k0:k1]^T          i >= j >= k1
+//     R_ic -= L[i,k0:k1] X[k0:k1,c]            i >= k1, c < k0
+//     R_ic  = -L[i,c:k1] X[c:k1,c]             i >= k1, k0 <= c < k1   (first touch)
+// The outer update is split into the part the next panel needs ("next": its
+// columns of B, its rows of R) and the rest, so the next panel's latency chain
+// can run while the rest streams on a second HIP stream.
 int ensure_tasks(gprn_ctx* c)
 {
     const int T = c->T, ld = c->ld;
@@ -215,44 +231,64 @@ int ensure_tasks(gprn_ctx* c)
     std::vector<TileTask>& v = c->h_tasks;
     v.clear();
     c->steps.assign(T, gprn_ctx::StepRange{0, 0, 0, 0});
-    for (int k = 0; k < T; ++k) {
-        gprn_ctx::StepRange& s = c->steps[k];
-        s.panel0 = v.size();
-        for (int i = k + 1; i < T; ++i) {          // L_ik = B_ik X_kk^T   (in place)
-            TileTask t{toff(i, k, ld), toff(i, k, ld), toff(k, k, ld), GPRN_TILE,
-                       BUF_B, BUF_B, BUF_X, tile_modes(CM_SET, 0, 0)};
-            v.push_back(t);
+    c->outers.clear();
+    for (int k0 = 0; k0 < T; k0 += GPRN_OUTER) {
+        const int k1 = std::min(T, k0 + GPRN_OUTER);
+        for (int k = k0; k < k1; ++k) {
+            gprn_ctx::StepRange& s = c->steps[k];
+            s.panel0 = v.size();
+            for (int i = k + 1; i < T; ++i)            // L_ik = B_ik X_kk^T   (in place)
+                v.push_back(TileTask{toff(i, k, ld), toff(i, k, ld), toff(k, k, ld), GPRN_TILE,
+                                     BUF_B, BUF_B, BUF_X, tile_modes(CM_SET, 0, 0)});
+            for (int cc = 0; cc < k; ++cc)             // X_kc = X_kk R_kc     (in place)
+                v.push_back(TileTask{toff(k, cc, ld), toff(k, k, ld), toff(k, cc, ld), GPRN_TILE,
+                                     BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)});
+            s.npanel = v.size() - s.panel0;
+            s.upd0 = v.size();
+            for (int j = k + 1; j < k1; ++j)
+                for (int i = j; i < T; ++i)
+                    v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
+            for (int i = k + 1; i < k1; ++i)
+                for (int cc = 0; cc <= k; ++cc)
+                    v.push_back(TileTask{toff(i, cc, ld), toff(i, k, ld), toff(k, cc, ld), GPRN_TILE,
+                                         BUF_X, BUF_B, BUF_X,
+                                         tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
+            s.nupd = v.size() - s.upd0;
         }
-        for (int cc = 0; cc < k; ++cc) {           // X_kc = X_kk R_kc     (in place)
-            TileTask t{toff(k, cc, ld), toff(k, k, ld), toff(k, cc, ld), GPRN_TILE,
-                       BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)};
-            v.push_back(t);
-        }
-        s.npanel = v.size() - s.panel0;
-        s.upd0 = v.size();
-        for (int i = k + 1; i < T; ++i) {
-            for (int j = k + 1; j <= i; ++j) {     // B_ij -= L_ik L_jk^T
-                TileTask t{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
-                           BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)};
-                v.push_back(t);
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0};
+        const int kw = (k1 - k0) * GPRN_TILE;
+        const int n1 = std::min(T, k1 + GPRN_OUTER);   // the next panel is tiles [k1, n1)
+        for (int pass = 0; pass < 2; ++pass) {         // 0: what the next panel needs, 1: the rest
+            const size_t begin = v.size();
+            for (int i = k1; i < T; ++i) {
+                for (int j = k1; j <= i; ++j) {
+                    const bool next = j < n1;
+                    if (next != (pass == 0)) continue;
+                    v.push_back(TileTask{toff(i, j, ld), toff(i, k0, ld), toff(j, k0, ld), kw,
+                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
+                }
+                const bool next = i < n1;
+                if (next != (pass == 0)) continue;
+                for (int cc = 0; cc < k0; ++cc)
+                    v.push_back(TileTask{toff(i, cc, ld), toff(i, k0, ld), toff(k0, cc, ld), kw,
+                                         BUF_X, BUF_B, BUF_X, tile_modes(CM_SUB, 0, 1)});
+                for (int cc = k0; cc < k1; ++cc)
+                    v.push_back(TileTask{toff(i, cc, ld), toff(i, cc, ld), toff(cc, cc, ld),
+                                         (k1 - cc) * GPRN_TILE, BUF_X, BUF_B, BUF_X,
+                                         tile_modes(CM_SETNEG, 0, 1)});
             }
-            for (int cc = 0; cc <= k; ++cc) {      // R_ic -= L_ik X_kc ; first touch at c == k
-                TileTask t{toff(i, cc, ld), toff(i, k, ld), toff(k, cc, ld), GPRN_TILE,
-                           BUF_X, BUF_B, BUF_X,
-                           tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)};
-                v.push_back(t);
-            }
+            if (pass == 0) { o.next0 = begin; o.nnext = v.size() - begin; }
+            else { o.rest0 = begin; o.nrest = v.size() - begin; }
         }
-        s.nupd = v.size() - s.upd0;
+        c->outers.push_back(o);
     }
     // lower(X^T X) -> BUF_B: tile (a,b), a >= b, sums over rows a*128 .. ld of X
     c->lauum0 = v.size();
     for (int a = 0; a < T; ++a)
-        for (int b = 0; b <= a; ++b) {
-            TileTask t{toff(a, b, ld), toff(a, a, ld), toff(a, b, ld), ld - a * GPRN_TILE,
-                       BUF_B, BUF_X, BUF_X, tile_modes(CM_SET, 1, 1)};
-            v.push_back(t);
-        }
+        for (int b = 0; b <= a; ++b)
+            v.push_back(TileTask{toff(a, b, ld), toff(a, a, ld), toff(a, b, ld), ld - a * GPRN_TILE,
+                                 BUF_B, BUF_X, BUF_X, tile_modes(CM_SET, 1, 1)});
     c->nlauum = v.size() - c->lauum0;
 
     if (v.size() > c->tasks_cap) {
@@ -261,6 +297,7 @@ int ensure_tasks(gprn_ctx* c)
         HIP_TRY(c, hipMalloc(&c->d_tasks, v.size() * sizeof(TileTask)));
         c->tasks_cap = v.size();
     }
+    HIP_TRY(c, hipStreamSynchronize(c->stream2));
     HIP_TRY(c, hipMemcpyAsync(c->d_tasks, v.data(), v.size() * sizeof(TileTask),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -272,14 +309,32 @@ int factor_invert(gprn_ctx* c, int nbatch)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
-    for (int k = 0; k < c->T; ++k) {
-        const gprn_ctx::StepRange& s = c->steps[k];
-        if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
-        if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_PANEL))) return rc;
-        if ((rc = launch_tiles(c, c->d_tasks + s.upd0, s.nupd, c->d_ptrs, nbatch, c->ld,
+    bool rest_pending = false;
+    for (size_t J = 0; J < c->outers.size(); ++J) {
+        const gprn_ctx::OuterRange& o = c->outers[J];
+        for (int k = o.k0; k < o.k1; ++k) {            // the latency chain of this panel
+            const gprn_ctx::StepRange& s = c->steps[k];
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
+            if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
+                                   GPRN_T_PANEL))) return rc;
+            if ((rc = launch_tiles(c, c->d_tasks + s.upd0, s.nupd, c->d_ptrs, nbatch, c->ld,
+                                   GPRN_T_PANEL))) return rc;
+        }
+        if (o.nnext + o.nrest == 0) continue;
+        HIP_TRY(c, hipEventRecord(c->ev_panel, c->stream));
+        if (rest_pending)                              // same tiles as the previous panel's rest
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
+        if ((rc = launch_tiles(c, c->d_tasks + o.next0, o.nnext, c->d_ptrs, nbatch, c->ld,
                                GPRN_T_UPDATE))) return rc;
+        if (o.nrest) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
+            if ((rc = launch_tiles(c, c->d_tasks + o.rest0, o.nrest, c->d_ptrs, nbatch, c->ld,
+                                   GPRN_T_UPDATE, c->stream2))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_rest, c->stream2));
+            rest_pending = true;
+        }
     }
+    if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
     return GPRN_OK;
 }
 

@@ -133,12 +133,13 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam)
+                 int nbatch, int ld, int fam, hipStream_t stream)
 {
     if (ntasks == 0 || nbatch == 0) return GPRN_OK;
-    prof_begin(c, fam);
+    if (!stream) stream = c->stream;
+    prof_begin(c, fam, stream);
     dim3 grid((unsigned)ntasks, (unsigned)nbatch);
-    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), 0, c->stream, d_tasks,
+    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), 0, stream, d_tasks,
                        (double* const*)d_ptrs, ld);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -11,6 +11,7 @@
 #define GPRN_TILE 128          // tile edge of the blocked factorisation (nb)
 #define GPRN_KC 16             // K chunk staged through LDS per pipeline stage
 #define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
+#define GPRN_OUTER 4           // tiles per outer panel: bulk updates contract over 4*128 = 512
 
 // buffer slots of a tile task (index into the per-GP pointer table)
 enum { BUF_B = 0, BUF_X = 1, BUF_K = 2, BUF_KLINV = 3 };
@@ -60,7 +61,10 @@ struct KernelSpec {            // how latent GP g gets its K
 
 struct gprn_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
+    hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
+    hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+    hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;
     Profiler prof;
@@ -116,19 +120,21 @@ struct gprn_ctx {
     TileTask* d_tasks = nullptr;
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
-    struct StepRange { size_t panel0, npanel, upd0, nupd; };
+    struct StepRange { size_t panel0, npanel, upd0, nupd; };   // per tile step: panel, in-panel update
     std::vector<StepRange> steps;    // T entries
+    struct OuterRange { int k0, k1; size_t next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
+    std::vector<OuterRange> outers;
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
 };
 
 // ---- launchers (each enqueues on ctx->stream; no sync) ----
-void prof_begin(gprn_ctx* c, int fam);
+void prof_begin(gprn_ctx* c, int fam, hipStream_t stream = nullptr);   // nullptr = ctx->stream
 void prof_end(gprn_ctx* c);
 
 int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K);
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam);
+                 int nbatch, int ld, int fam, hipStream_t stream = nullptr);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info);
 // factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
 int factor_invert(gprn_ctx* c, int nbatch);
