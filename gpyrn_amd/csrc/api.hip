@@ -146,7 +146,9 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return GPRN_E_HIP;
     }
@@ -170,6 +172,8 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     hipStreamSynchronize(c->stream2);
     hipEventDestroy(c->ev_panel);
     hipEventDestroy(c->ev_rest);
+    hipEventDestroy(c->ev_nodes);
+    hipEventDestroy(c->ev_q1);
     hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
@@ -482,7 +486,7 @@ static int build_tables(gprn_ctx* c)
     c->loc_nodes.clear(); c->loc_weights.clear();
     for (int g = 0; g < c->q; ++g) if (c->owner[g] == c->rank) c->loc_nodes.push_back(g);
     for (int g = c->q; g < c->G; ++g) if (c->owner[g] == c->rank) c->loc_weights.push_back(g);
-    const int want = std::max<size_t>(1, std::max(c->loc_nodes.size(), c->loc_weights.size()));
+    const int want = std::max<size_t>(1, c->loc_nodes.size() + c->loc_weights.size());
     const size_t nn = (size_t)c->ld * c->ld;
     if (want != c->nslot) {
         for (auto& p : c->wsB) dev_free(p);
@@ -511,18 +515,20 @@ static int build_tables(gprn_ctx* c)
     for (int g : c->loc_nodes) TRY(ensure_gp_storage(c, g));
     for (int g : c->loc_weights) TRY(ensure_gp_storage(c, g));
     std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
-    auto fill_rows = [&](const std::vector<int>& gps) {
+    // nodes keep slots [0, #nodes), weights the slots after them: both phases' factors stay
+    // resident, so the node phase's X^T X (quirk Q1) can run behind the weight phase
+    auto fill_rows = [&](const std::vector<int>& gps, size_t first) {
         std::fill(rows.begin(), rows.end(), nullptr);
         for (size_t s = 0; s < gps.size(); ++s) {
-            rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
-            rows[s * GPRN_NBUF + BUF_X] = c->wsX[s];
+            rows[s * GPRN_NBUF + BUF_B] = c->wsB[first + s];
+            rows[s * GPRN_NBUF + BUF_X] = c->wsX[first + s];
             rows[s * GPRN_NBUF + BUF_K] = c->K[gps[s]];
             rows[s * GPRN_NBUF + BUF_KLINV] = c->KLinv[gps[s]];
         }
     };
-    fill_rows(c->loc_nodes);
+    fill_rows(c->loc_nodes, 0);
     TRY(upload_table(c, c->tab_node, rows));
-    fill_rows(c->loc_weights);
+    fill_rows(c->loc_weights, c->loc_nodes.size());
     TRY(upload_table(c, c->tab_weight, rows));
     if (!c->loc_nodes.empty())
         HIP_TRY(c, hipMemcpy(c->d_slotgp_node, c->loc_nodes.data(), c->loc_nodes.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -640,34 +646,42 @@ static int run_phase(gprn_ctx* c, bool weights)
     const int ns = (int)gps.size();
     const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
     c->d_ptrs = weights ? c->tab_weight : c->tab_node;
+    c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
     c->d_info_cur = c->d_info + (weights ? 2 : 1) * (size_t)c->nslot;
+    const size_t o = (size_t)c->slot0 * c->ld;
     if (ns) {
         TRY(vec_prep(c, weights, slotgp, ns));
         TRY(vec_matvec_z(c, ns));
         TRY(vec_build_B(c, ns));
         TRY(factor_invert(c, ns));
         TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
-        TRY(vec_lower_matvec(c, BUF_X, c->d_z, c->ld, 0, slotgp, ns, c->d_u));
+        TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o));
         TRY(vec_colops(c, ns));
         TRY(vec_finalize(c, slotgp, ns));
-        int n_inv = 0;                       // slots whose explicit B^-1 is needed
-        if (c->keep_sigma) n_inv = ns;
-        else if (!weights && c->q > 1) n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
-        if (n_inv) TRY(lauum_lower(c, n_inv));
+        if (c->keep_sigma) {
+            const size_t nn = (size_t)c->ld * c->ld;
+            TRY(lauum_lower(c, ns));
+            for (int s = 0; s < ns; ++s) {
+                if (!c->Sig[gps[s]]) TRY(dev_alloc(c, &c->Sig[gps[s]], nn));
+                TRY(vec_sigma(c, c->wsB[c->slot0 + s], c->d_s + o + (size_t)s * c->ld, c->Sig[gps[s]]));
+            }
+        }
         if (!weights && c->q > 1) {
+            // quirk Q1: <K_j^-1, Sigma_k> for k < j needs the explicit B_k^-1 = X^T X of every node
+            // but the last.  Nothing in the weight phase reads it, so it runs behind that phase on
+            // the second stream and is joined before the ELBO assembly.
+            const int n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
+            HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
+            if (n_inv && !c->keep_sigma) TRY(lauum_lower(c, n_inv, c->stream2));
             for (int s = 0; s < ns; ++s) {
                 const int k = gps[s];
                 for (int j = k + 1; j < c->q; ++j)
-                    TRY(vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld,
-                               c->d_q1 + (size_t)j * c->q + k));
+                    TRY(vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld, c->d_u,
+                               c->d_q1 + (size_t)j * c->q + k, c->stream2));
             }
-        }
-        if (c->keep_sigma) {
-            const size_t nn = (size_t)c->ld * c->ld;
-            for (int s = 0; s < ns; ++s) {
-                if (!c->Sig[gps[s]]) TRY(dev_alloc(c, &c->Sig[gps[s]], nn));
-                TRY(vec_sigma(c, c->wsB[s], c->d_s + (size_t)s * c->ld, c->Sig[gps[s]]));
-            }
+            HIP_TRY(c, hipEventRecord(c->ev_q1, c->stream2));
+            c->q1_pending = true;
         }
     }
     return exchange_rows(c, weights);
@@ -681,8 +695,10 @@ static int mu_k_mu(gprn_ctx* c, bool weights)
     const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
     c->d_ptrs = weights ? c->tab_weight : c->tab_node;
     // a = L_K^-1 m_g with m_g = state row g (nodes: mu_f[g]; weights: the raw-reshape row, quirk Q2)
-    TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, c->d_u));
-    return vec_dot_self(c, slotgp, ns, c->d_u, c->d_muKmu);
+    c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
+    double* a = c->d_u + (size_t)c->slot0 * c->ld;
+    TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, a));
+    return vec_dot_self(c, slotgp, ns, a, c->d_muKmu);
 }
 
 extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
@@ -706,6 +722,10 @@ extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_ou
         HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), c->stream));
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));
+        if (c->q1_pending) {                    // the Q1 traces computed behind the weight phase
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_q1, 0));
+            c->q1_pending = false;
+        }
         TRY(mu_k_mu(c, false));
         TRY(mu_k_mu(c, true));
         TRY(reduce_scalars(c));

@@ -339,10 +339,10 @@ int factor_invert(gprn_ctx* c, int nbatch)
 }
 
 // BUF_B of every slot = lower(X^T X), X in BUF_X (L in BUF_B is overwritten)
-int lauum_lower(gprn_ctx* c, int nbatch)
+int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
     return launch_tiles(c, c->d_tasks + c->lauum0, c->nlauum, c->d_ptrs, nbatch, c->ld,
-                        GPRN_T_LAUUM);
+                        GPRN_T_LAUUM, stream);
 }

@@ -63,7 +63,7 @@ struct gprn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
-    hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
     hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;
@@ -93,9 +93,11 @@ struct gprn_ctx {
     std::vector<double*> Kinv;       // q   K_j^-1 lower, only for nodes j>=1 that feed quirk Q1
     std::vector<double*> Sig;        // G   explicit Sigma of the last sweep (keep_sigma only)
     bool keep_sigma = false;
+    bool q1_pending = false;
     double* d_logdetK = nullptr;     // G
     // ---- workspaces: nslot pairs (B, X), nslot = max local GPs of a phase
-    int nslot = 0;
+    int nslot = 0;                   // local nodes + local weights: every local GP has its own (B, X)
+    int slot0 = 0;                   // first slot of the running phase (0 nodes, #local nodes weights)
     std::vector<double*> wsB, wsX;
     double** d_ptrs = nullptr;       // the table the launchers use right now (one of the three below)
     double **tab_node = nullptr, **tab_weight = nullptr, **tab_setup = nullptr;  // [nslot][GPRN_NBUF]
@@ -138,5 +140,5 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info);
 // factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
 int factor_invert(gprn_ctx* c, int nbatch);
-int lauum_lower(gprn_ctx* c, int nbatch);   // BUF_B = lower(X^T X), X in BUF_X
+int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
 int ensure_tasks(gprn_ctx* c);

@@ -11,7 +11,7 @@ int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, in
 int vec_colops(gprn_ctx* c, int nslots);
 int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots);
 int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
-           double* out_scalar);
+           double* scratch, double* out_scalar, hipStream_t stream);
 int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out);
 int vec_elbo(gprn_ctx* c, double* out4);
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);

@@ -360,15 +360,16 @@ int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots)
 {
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
+    const size_t o = (size_t)c->slot0 * c->ld;
     dim3 grid((c->ld + 255) / 256, nslots);
     if (weights)
         hipLaunchKernelGGL(k_prep_weights, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d, c->d_s, c->d_pred);
+                           c->d_d + o, c->d_s + o, c->d_pred + o);
     else
         hipLaunchKernelGGL(k_prep_nodes, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d, c->d_s, c->d_pred);
+                           c->d_d + o, c->d_s + o, c->d_pred + o);
     LAUNCH_END(c);
 }
 
@@ -377,7 +378,8 @@ int vec_matvec_z(gprn_ctx* c, int nslots)
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
     hipLaunchKernelGGL(k_matvec_z, dim3(c->ld / 4, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s, c->d_pred, c->d_z);
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld,
+                       c->d_pred + (size_t)c->slot0 * c->ld, c->d_z + (size_t)c->slot0 * c->ld);
     LAUNCH_END(c);
 }
 
@@ -386,7 +388,7 @@ int vec_build_B(gprn_ctx* c, int nslots)
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_BUILD_B);
     hipLaunchKernelGGL(k_build_B, dim3(c->T, c->T, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s);
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld);
     LAUNCH_END(c);
 }
 
@@ -414,10 +416,11 @@ int vec_colops(gprn_ctx* c, int nslots)
 {
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
+    const size_t o = (size_t)c->slot0 * c->ld, po = (size_t)c->slot0 * c->T * 2 * c->ld;
     hipLaunchKernelGGL(k_colops_partial, dim3(c->ld / 64, c->T, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->ld, c->T, c->d_u, c->d_part);
+                       (double* const*)c->d_ptrs, c->ld, c->T, c->d_u + o, c->d_part + po);
     hipLaunchKernelGGL(k_colops_reduce, dim3((c->ld + 255) / 256, nslots), dim3(256), 0,
-                       c->stream, c->ld, c->T, c->d_part, c->d_cs, c->d_ct);
+                       c->stream, c->ld, c->T, c->d_part + po, c->d_cs + o, c->d_ct + o);
     LAUNCH_END(c);
 }
 
@@ -425,19 +428,20 @@ int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots)
 {
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
+    const size_t o = (size_t)c->slot0 * c->ld;
     hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
-                       c->p, c->q, c->d_d, c->d_s, c->d_cs, c->d_ct, c->d_mu, c->d_var,
+                       c->p, c->q, c->d_d + o, c->d_s + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
                        c->d_trBinv);
     LAUNCH_END(c);
 }
 
 int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
-           double* out_scalar)
+           double* scratch, double* out_scalar, hipStream_t stream)
 {
-    prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_q1_rows, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, Kinv_j, Binv_k,
-                       c->N, c->ld, s_k, c->d_u /* scratch: slot 0 of u is free here */);
-    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, c->stream, c->d_u, c->N, out_scalar);
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_q1_rows, dim3((c->N + 3) / 4), dim3(256), 0, stream, Kinv_j, Binv_k,
+                       c->N, c->ld, s_k, scratch);
+    hipLaunchKernelGGL(k_sum_to, dim3(1), dim3(256), 0, stream, scratch, c->N, out_scalar);
     LAUNCH_END(c);
 }
 
