@@ -1,0 +1,215 @@
+"""Host-side surface: the reference's own tests (tests/test_*.py of gpyrn)
+restated against gpyrn_amd, the parameter plumbing against vectors recorded
+from the reference (tests/golden/api.json), and the host evaluation of every
+kernel against the reference's matrices (tests/golden/kernels.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gpyrn_amd as gpyrn
+from gpyrn_amd import covfunc, meanfunc
+from gpyrn_amd.meanfield import inference
+from tests import _cases
+
+
+# ---------------------------------------------------------- reference: imports
+def test_imports():
+    from gpyrn_amd import covfunc, meanfunc, meanfield  # noqa: F401
+    assert gpyrn.__version__ == '1.0'
+    for name in ('Constant', 'Linear', 'SquaredExponential', 'QuasiPeriodic', 'inference'):
+        assert hasattr(gpyrn, name)
+
+
+# ---------------------------------------------------- reference: cov functions
+def test_QP_equals_prod():
+    k1 = covfunc.SquaredExponential(1, 10) * covfunc.Periodic(1, 20, 0.5)
+    k2 = covfunc.QuasiPeriodic(1, 10, 20, 0.5)
+    t = np.sort(np.random.uniform(0, 100, size=50))
+    T = t[:, None] - t[None, :]
+    assert np.allclose(k1(T), k2(T))
+
+
+# --------------------------------------------------- reference: mean functions
+def test_Constant():
+    m = meanfunc.Constant(0.0)
+    assert m.pars[0] == 0.0 and np.all(m(np.random.rand(10)) == 0.0)
+    m = meanfunc.Constant(10.0)
+    assert np.all(m(np.random.rand(3)) == 10.0)
+    with pytest.raises(TypeError):
+        meanfunc.Constant()
+    assert np.all((meanfunc.Constant(5.0) + meanfunc.Constant(10.0))(np.random.rand(3)) == 15.0)
+    assert np.all((meanfunc.Constant(2) * meanfunc.Constant(10.0))(np.random.rand(3)) == 20.0)
+
+
+def test_Linear():
+    m = meanfunc.Linear(0.0, 1.0)
+    assert np.all(m(np.random.rand(10)) == 1.0)
+    m = meanfunc.Linear(1.0, 2.0)
+    t = np.array([0.0, 1.0, 2.0, 3.0])
+    assert np.all(m(t) == np.polyval(m.pars, t - t.mean()))
+
+
+def test_mean_parameter_chaining_and_names():
+    s = meanfunc.Constant(1.0) + meanfunc.Constant(2.0)
+    assert s._param_names == ('c1', 'c2') and s._parsize == 2
+    rest = s.set_parameters(np.array([3.0, 4.0, 9.0]))
+    assert np.array_equal(rest, [9.0])
+    assert s.m1.pars[0] == 3.0 and s.m2.pars[0] == 4.0
+    mc = meanfunc.MultiConstant([1.0, 5.0], np.array([1, 1, 2, 2]), np.arange(4.0))
+    assert np.array_equal(mc(np.arange(4.0)), [6.0, 6.0, 5.0, 5.0])
+
+
+# -------------------------------------------------------- reference: inference
+def test_create_inference():
+    t, y, yerr = np.random.rand(3, 10)
+    g = inference(1, t, y, yerr)
+    assert g.time is t and g.N == t.size and g.q == 1 and g.p == 1
+    t, y1, e1, y2, e2 = np.random.rand(5, 10)
+    g = inference(1, t, y1, e1, y2, e2)
+    assert np.allclose(g.y, np.c_[y1, y2].T)
+    assert g.q == 1 and g.p == 2 and g.qp == 2 and g.d == 10 * 1 * 3
+    assert g.yerr.shape == (2, 10) and g.tt.shape == (20,)
+
+
+def test_create_inference_exception():
+    with pytest.raises(TypeError):
+        inference(1)
+    with pytest.raises(AssertionError):
+        inference(1, np.random.rand(10))
+    t, y1, e1 = np.random.rand(3, 10)
+    y2, e2 = np.random.rand(2, 20)
+    with pytest.raises(AssertionError):
+        inference(1, t, y1, e1, y2, e2)
+
+
+def test_set_components_forms_and_errors():
+    t, y, yerr = np.random.rand(3, 10)
+    g = inference(1, t, y, yerr)
+    with pytest.raises(ValueError):
+        g.get_parameters()
+    with pytest.raises(ValueError):
+        g._get_components()
+    node, weight = covfunc.SquaredExponential(1, 1), covfunc.SquaredExponential(1, 1)
+    g.set_components(node, weight, meanfunc.Constant(0), 0.0)
+    assert g.nodes[0] is node and g.jitters.dtype == np.float64
+    g.set_components([node], [weight], [meanfunc.Constant(0)], [0.0])
+    with pytest.raises(ValueError):
+        g.set_components([node, node], [weight], meanfunc.Constant(0), 0.0)
+    with pytest.raises(ValueError):
+        g.set_components(node, [weight, weight], meanfunc.Constant(0), 0.0)
+
+
+# -------------------------------------------- parameter plumbing vs reference
+def test_parameter_api_matches_reference_vectors():
+    with open(os.path.join(_cases.GOLDEN, 'api.json')) as f:
+        ref = json.load(f)
+    from gpyrn_amd import synth
+    t, ys, es = synth.rv_series(16, 2)
+    g = inference(2, t, ys[0], es[0], ys[1], es[1])
+    nodes, weights, means, jit = synth.component_spec(2, 2, 'QP')
+    means = [('Constant', [0.7]), ('Linear', [0.01, -0.4])]
+    jit = [0.3, 0.55]
+    g.set_components(*synth.build_components(covfunc, meanfunc, (nodes, weights, means, jit)))
+    assert list(g.parameters_dict.keys()) == ref['names']
+    assert np.allclose(list(g.parameters_dict.values()), ref['values'])
+    assert np.allclose(g.get_parameters(include_frozen=True), ref['get_all'])
+    assert g.n_parameters == ref['n_parameters']
+    g.freeze_parameter(name='node1*')
+    g.freeze_parameter(index=9)
+    assert g.frozen_mask.tolist() == ref['mask_after_freeze']
+    assert np.allclose(g.get_parameters(), ref['get_free'])
+    g.thaw_parameter(name='node1.P')
+    assert g.frozen_mask.tolist() == ref['mask_after_thaw']
+    g.set_parameters(np.arange(1, g.n_parameters + 1, dtype=float) / 10)
+    assert np.allclose(g.get_parameters(include_frozen=True), ref['after_set_all'])
+    g.set_parameters(g.get_parameters() * 2)
+    assert np.allclose(g.get_parameters(include_frozen=True), ref['after_set_free'])
+    assert np.allclose(g.jitters, ref['jitters_after'])
+    with pytest.raises(ValueError):
+        g.set_parameters(np.ones(3))
+    with pytest.raises(NotImplementedError):
+        g.frozen_mask = np.zeros(3)
+    with pytest.raises(ValueError):
+        g.freeze_parameter()
+    assert inference.fix_parameter is inference.freeze_parameter
+    g.freeze_all_parameters()
+    assert g.frozen_mask.all()
+    g.thaw_all_parameters()
+    assert not g.frozen_mask.any()
+
+
+# ----------------------------------------- host kernels vs reference matrices
+def test_host_kernels_match_reference_matrices():
+    with open(os.path.join(_cases.GOLDEN, 'kernels.json')) as f:
+        meta = json.load(f)
+    d = np.load(os.path.join(_cases.GOLDEN, 'kernels.npz'))
+    t = d['time']
+    g = inference(1, t, np.zeros(t.size), np.ones(t.size))
+    for name, pars in meta['simple']:
+        K = g._host_K(getattr(covfunc, name)(*pars), t)
+        np.testing.assert_allclose(K, d['K_' + name], rtol=1e-14, atol=1e-15, err_msg=name)
+    for tag, expr in meta['composite']:
+        K = g._host_K(eval(expr, {'c': covfunc}), t)
+        np.testing.assert_allclose(K, d['K_' + tag], rtol=1e-14, atol=1e-15, err_msg=tag)
+    r = d['rect_r']
+    assert np.array_equal(covfunc.WhiteNoise(0.7)(r), d['rect_WhiteNoise'])
+    np.testing.assert_allclose(covfunc.QuasiPeriodic(1.1, 30.0, 12.5, 0.6)(r),
+                               d['rect_QuasiPeriodic'], rtol=1e-15)
+
+
+def test_kernel_protocol_quirks():
+    k = covfunc.SquaredExponential(1.0, 2.0)
+    rest = k.set_parameters([3.0, 4.0, 5.0])
+    assert np.array_equal(rest, [5.0]) and np.array_equal(k.pars, [3.0, 4.0])
+    assert k.set_parameters([1.0, 2.0]) is None
+    with pytest.raises(AssertionError):
+        k.set_parameters([1.0])
+    with pytest.raises(NotImplementedError):
+        covfunc.covFunction(1.0)(np.zeros((2, 2)))
+    s = covfunc.SquaredExponential(1, 2) + covfunc.Matern32(3, 4)
+    s.set_parameters([9, 9, 9, 9])                 # composite does not reach its children
+    assert np.array_equal(s.k1.pars, [1, 2]) and np.array_equal(s.pars, [9, 9, 9, 9])
+    assert not hasattr(s, '_param_names')
+    c = covfunc.CosPeriodic(2.0, 11.0, 0.9)
+    assert c.pars.size == 2                        # amplitude never enters pars
+    with pytest.raises(ValueError):
+        covfunc.Derivative(covfunc.Matern32(1, 1))
+    with pytest.raises(AttributeError):
+        covfunc.NewRQP(1, 1, 1, 1, 1, 1)(np.zeros((2, 2)))
+    assert repr(covfunc.SquaredExponential(1, 2)) == 'SquaredExponential(theta=1.0, ell=2.0)'
+
+
+def test_device_programs():
+    se = covfunc.SquaredExponential(1.5, 3.0)
+    ops, par = se._device_program()
+    assert ops == [(covfunc.OP_PUSH, covfunc.KID['SE'], 0)] and np.array_equal(par, [1.5, 3.0])
+    k = covfunc.SquaredExponential(1, 2) * covfunc.Periodic(3, 4, 5) + covfunc.Exponential(6, 7)
+    ops, par = k._device_program()
+    assert ops == [(0, covfunc.KID['SE'], 0), (0, covfunc.KID['PERIODIC'], 2), (2, 0, 0),
+                   (0, covfunc.KID['EXPONENTIAL'], 5), (1, 0, 0)]
+    assert np.array_equal(par, [1, 2, 3, 4, 5, 6, 7])
+    assert covfunc.CosPeriodic(2.0, 11.0, 0.9)._device_pars() == [2.0, 11.0, 0.9]
+    assert covfunc.Derivative(covfunc.Periodic(1, 2, 3))._device_program()[0][0][1] == covfunc.KID['DPERIODIC']
+
+    class Mine(covfunc.SquaredExponential):        # subclass may override __call__: host path
+        pass
+    assert Mine(1, 2)._device_program() is None
+    assert (covfunc.SquaredExponential(1, 2) + Mine(1, 2))._device_program() is None
+    assert covfunc.Linear(1.0)._device_program() is None
+    assert (covfunc.Polynomial(1, 1, 1, 2) + se)._device_program() is None
+
+
+def test_init_mu_var_matches_reference():
+    for tag in ['step_p1q1', 'step_p3q2', 'step_p2q3']:
+        meta, d = _cases.load(tag)
+        nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+        g = inference(meta['q'], np.array(d['time']), *_cases.data_args(d))
+        g.set_components(nodes, weights, means, jit)
+        mu, var = g._initMuVar(nodes, weights, jit)
+        assert np.array_equal(mu, d['mu_init']) and np.array_equal(var, d['var_init'])
+        f, w = g._u_to_fhatW(mu)
+        assert np.array_equal(f, d['mu_init_f']) and np.array_equal(w, d['mu_init_w'])
+        y = np.concatenate(g.y) - g._mean(means)
+        np.testing.assert_allclose(np.array(np.array_split(y, g.p)), d['y_resid'], atol=1e-14)

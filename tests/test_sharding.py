@@ -1,0 +1,163 @@
+"""Multi-rank path on CPU (gloo, world_size 2): the sharding schedule of
+csrc/api.hip -- who owns which latent GP, what is broadcast after each
+half-sweep, which scalars are all-reduced -- executed with the oracle's per-GP
+arithmetic in place of the HIP kernels, and compared with the unsharded sweep."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from gpyrn_amd import covfunc, meanfunc, sharding
+from oracle import cpu_ref
+from tests import _cases
+
+
+def test_owner_map_covers_and_balances():
+    for p, q, world in [(3, 2, 1), (3, 2, 2), (3, 4, 4), (4, 3, 8), (1, 1, 4), (3, 2, 8)]:
+        own = sharding.owners(p, q, world)
+        assert len(own) == q * (p + 1) and all(0 <= o < world for o in own)
+        seen = []
+        for r in range(world):
+            n, w = sharding.local_gps(p, q, world, r)
+            seen += n + w
+            assert len(n) <= -(-q // world) and len(w) <= -(-q * p // world)
+        assert sorted(seen) == list(range(q * (p + 1)))
+    # BASELINE config 4: one node and three weights per GPU
+    assert [len(sharding.local_gps(3, 4, 4, r)[0]) for r in range(4)] == [1, 1, 1, 1]
+    assert [len(sharding.local_gps(3, 4, 4, r)[1]) for r in range(4)] == [3, 3, 3, 3]
+
+
+def test_helper_inverses():
+    assert sharding.helper_inverses(3, 1, 2, 0) == []
+    assert sharding.helper_inverses(3, 2, 1, 0) == [1]
+    assert sharding.helper_inverses(3, 4, 4, 0) == [1, 2, 3]
+    assert sharding.helper_inverses(3, 4, 4, 3) == []
+    assert sharding.helper_inverses(3, 4, 8, 5) == []          # owns no node
+
+
+def _row(g, p, q):
+    if g < q:
+        return g
+    j, i = divmod(g - q, p)
+    return (1 + i) * q + j
+
+
+def sharded_sweep(rank, world, dist, torch, Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var):
+    """One sweep with the latent GPs sharded over `world` ranks (schedule of
+    gprn_sweep in csrc/api.hip; arithmetic of oracle/cpu_ref.sweep_B)."""
+    q, N = Kf.shape[0], Kf.shape[-1]
+    p = Kw.shape[0] // q
+    G = q * (p + 1)
+    own = sharding.owners(p, q, world)
+    nodes_l, weights_l = sharding.local_gps(p, q, world, rank)
+    Kinv = {j: cpu_ref.cho_solve((Lf[j], True), np.eye(N))
+            for j in sharding.helper_inverses(p, q, world, rank)}
+    variance = jitt2[:, None] + yerr2
+    muF, muW = cpu_ref.split_u(mu, p, q, N)
+    varF, varW = cpu_ref.split_u(var, p, q, N)
+    state_mu = np.concatenate((muF[None], muW)).reshape((p + 1) * q, N).copy()
+    state_var = np.concatenate((varF[None], varW)).reshape((p + 1) * q, N).copy()
+    scal = np.zeros(3 * G + q * q)                   # logdetB, trBinv, muKmu, q1
+    logdetK = np.array([2 * np.sum(np.log(np.diag(L))) for L in list(Lf) + list(Lw)])
+
+    def exchange(gps):
+        for g in gps:
+            for st in (state_mu, state_var):
+                t = torch.from_numpy(st[_row(g, p, q)])
+                dist.broadcast(t, src=own[g])
+
+    # ---- node half-sweep (Jacobi: every local node sees the old state)
+    new_rows = {}
+    for j in nodes_l:
+        d, pred = cpu_ref._node_d_and_pred(y, variance, muF, muW, varW, j)
+        ds, m, ldB, trB, Binv, s = cpu_ref._gp_update_B(Kf[j], d, pred, need_inverse=(j < q - 1))
+        new_rows[j] = (m, ds)
+        scal[j], scal[G + j] = ldB, trB
+        for jj in range(j + 1, q):                   # quirk Q1 on the owner of the earlier node
+            Sk = (np.eye(N) - Binv) / (s[:, None] * s[None, :])
+            scal[3 * G + jj * q + j] = np.sum(Kinv[jj] * Sk)
+    for j, (m, ds) in new_rows.items():
+        state_mu[j], state_var[j] = m, ds
+    exchange(range(q))
+    mu_f, dsf = state_mu[:q].copy(), state_var[:q].copy()
+
+    # ---- weight half-sweep (new nodes, old weights)
+    new_rows = {}
+    for g in weights_l:
+        j, i = divmod(g - q, p)
+        d, pred = cpu_ref._weight_d_and_pred(y, variance, mu_f, dsf, muW, j, i)
+        ds, m, ldB, trB, _, _ = cpu_ref._gp_update_B(Kw[g - q], d, pred)
+        new_rows[g] = (m, ds)
+        scal[g], scal[G + g] = ldB, trB
+    for g, (m, ds) in new_rows.items():
+        state_mu[_row(g, p, q)], state_var[_row(g, p, q)] = m, ds
+    exchange(range(q, G))
+
+    # ---- mu^T K^-1 mu with the state row g (quirk Q2 for the weights), then one all-reduce
+    for g in nodes_l + weights_l:
+        L = Lf[g] if g < q else Lw[g - q]
+        a = cpu_ref.solve_triangular(L, state_mu[g], lower=True)
+        scal[2 * G + g] = a @ a
+    t = torch.from_numpy(scal)
+    dist.all_reduce(t)
+
+    new_mu = state_mu.reshape(p + 1, q, N)
+    new_var = state_var.reshape(p + 1, q, N)
+    dsw = np.transpose(new_var[1:], (1, 0, 2))
+    logl = cpu_ref.expected_loglike(y_raw, variance, new_mu[0], new_mu[1:], new_var[0], dsw)
+    ent = 0.5 * np.sum(logdetK - scal[:G]) + 0.5 * q * (p + 1) * N * (1 + cpu_ref.LOG2PI)
+    logp = -0.5 * N * q * (p + 1) * cpu_ref.LOG2PI
+    for g in range(G):
+        tr = scal[G + g]
+        if g < q:
+            tr += sum(scal[3 * G + g * q + k] for k in range(g))
+        logp += -0.5 * logdetK[g] - 0.5 * (scal[2 * G + g] + tr)
+    return (logl + logp + ent) / q, new_mu, new_var
+
+
+def _worker(rank, world, port, tag, out_dir):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank,
+                            world_size=world)
+    try:
+        meta, d = _cases.load(tag)
+        nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+        Kf, Kw, Lf, Lw, y, j2 = cpu_ref.setup(d['time'], nodes, weights, means, jit, d['y'])
+        mu, var = d['mu_init'], d['var_init']
+        elbos = []
+        for _ in range(2):
+            E, mu, var = sharded_sweep(rank, world, dist, torch, Kf, Kw, Lf, Lw, y, d['y'],
+                                       d['yerr']**2, j2, mu, var)
+            elbos.append(E)
+        np.savez(os.path.join(out_dir, f'rank{rank}.npz'), elbo=np.array(elbos), mu=mu, var=var)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('tag', ['step_p3q2', 'step_p2q3'])
+def test_two_ranks_gloo_match_unsharded(tag, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), tag, str(tmp_path)), nprocs=world, join=True)
+    meta, d = _cases.load(tag)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    r1 = np.load(tmp_path / 'rank1.npz')
+    assert np.array_equal(r0['elbo'], r1['elbo']) and np.array_equal(r0['mu'], r1['mu'])
+    # against the reference's golden sweeps and the unsharded oracle
+    np.testing.assert_allclose(r0['elbo'], d['elbo_sweeps'][:2], rtol=1e-9)
+    nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+    args = cpu_ref.setup(d['time'], nodes, weights, means, jit, d['y'])
+    mu, var = d['mu_init'], d['var_init']
+    for s in range(2):
+        E, mu, var, _ = cpu_ref.sweep_B(*args[:5], d['y'], d['yerr']**2, args[5], mu, var)
+        np.testing.assert_allclose(r0['elbo'][s], E, rtol=1e-12)
+    np.testing.assert_allclose(r0['mu'], mu, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(r0['var'], var, rtol=1e-10, atol=1e-14)
