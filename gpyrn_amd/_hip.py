@@ -11,7 +11,7 @@ from ctypes import POINTER, byref, c_char, c_char_p, c_double, c_int, c_int32, c
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgprn_hip.so')
+LIB_PATH = os.environ.get('GPRN_HIP_LIB') or os.path.join(_HERE, 'libgprn_hip.so')
 
 GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM = -1, -2, -3, -4, -5
 M_K, M_KLINV, M_SIGMA = 0, 1, 2

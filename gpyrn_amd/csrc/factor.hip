@@ -24,181 +24,267 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-#define DP 130            // LDS pitch of the 128x128 image (doubles): conflict-free MFMA operand fetch
-#define XP 18             // pitch of the 16x16 inverted diagonal sub-block
+#define PP 18             // LDS pitch (doubles) of a 16-wide column panel: conflict-free operand fetch
 #define NSB 8             // 16x16 sub-blocks per tile edge
 
 // ------------------------------------------------------------------ diag
-// potrf + inverse of one 128x128 diagonal tile: one workgroup, whole tile in LDS,
-// blocked by 16 so that all O(n^3) work runs on v_mfma_f64_16x16x4_f64.
+// potrf + inverse of one 128x128 diagonal tile by one workgroup, blocked by 16 so that
+// all O(n^3) work runs on v_mfma_f64_16x16x4_f64 -- and with the whole tile resident in
+// the MFMA accumulators: 3 compute waves own the 8 sub-tile rows ({0,7}, {1,6,3},
+// {2,5,4}: equal update counts; up to 24 sub-tiles of 16x16 = 192 VGPRs per lane), the
+// 4th wave runs the scalar pivot chains (one wave per SIMD: 512 VGPRs each).  Only the
+// current 16-wide column panel passes through LDS (2 x 18 KiB), so the kernel fits on
+// a CU next to the bulk-update workgroups of the look-ahead stream.
 //
-// LDS image S: the lower triangle holds B then L; the strict upper triangle holds
-// the transposed running right-hand side of L X = I:  S[c][i] = R[i][c] (c < i).
-// With that storage every step of the blocked algorithm is the same formula on
-// 16x16 sub-tiles S(P,Q):
-//   base   (wave 0)   : S(kb,kb) -> L_kb (in place), X_kb = L_kb^-1 -> XD (register/shuffle potf2)
-//   panel  (all waves): S(P,kb) <- S(P,kb) X_kb^T            for every P != kb
-//   update (waves 1-3): S(P,Q) -= S(P,kb) S(Q,kb)^T          Q > kb, P < kb or P >= Q
-//                       S(kb,Q)  = -X_kb^T S(Q,kb)^T          (first touch of R's row kb)
-// and wave 0 updates S(kb+1,kb+1) first and then runs base(kb+1) while the other
-// waves finish update(kb) -- the 16-pivot dependency chain overlaps the MFMA work.
+// Storage convention (as for the big tiles): sub-tile (P,Q), P >= Q holds B then L;
+// P < Q holds the transposed running right-hand side of L X = I, S(P,Q) = R(Q,P)^T.
+// With it every step kb is the same formula on sub-tiles:
+//   base   (wave 3)   : S(kb,kb) -> L_kb,  X_kb = L_kb^-1 -> XD     (register/shuffle potf2)
+//   panel             : S(P,kb) <- S(P,kb) X_kb^T                    every P != kb
+//   update            : S(P,Q) -= S(P,kb) S(Q,kb)^T                  Q > kb, P < kb or P >= Q
+//                       S(kb,Q)  = -X_kb^T S(Q,kb)^T                 first touch of R's row kb
+// The update of column kb+1 goes first (U1) and is published to LDS, so that the base
+// wave factors S(kb+1,kb+1) while the compute waves finish the rest of the update (U2).
 
-// potf2 + trtri2 of a 16x16 block held in registers: lane (r = l&15, g = l>>4) owns
-// columns 4g..4g+3 of row r; strict upper = transposed right-hand side, as in S.
-__device__ __forceinline__ void base16(double* __restrict__ St, double* __restrict__ xd,
-                                       double* __restrict__ Xg, int ld, int* info, int slot,
-                                       int pivot0)
+// 1/sqrt(x) and sqrt(x) to fp64 round-off from the hardware seed (v_rsq_f64, ~2^-26) plus
+// Newton steps: a fraction of the latency of the IEEE sqrt + divide sequences, and this
+// sits on the serial pivot chain.  NaN for x < 0 (jnp.linalg.cholesky semantics).
+__device__ __forceinline__ void rsqrt_sqrt(double x, double& inv, double& root)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    y = y * fma(-0.5 * x * y, y, 1.5);
+    double sq = x * y;
+    sq = fma(0.5 * y, fma(-sq, sq, x), sq);
+    inv = y;
+    root = sq;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-uniform */)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// potf2 + trtri2 of a 16x16 block in registers: lane (r = l&15, g = l>>4) owns columns
+// 4g..4g+3 of row r; strict upper = transposed right-hand side, as in S.  Per pivot: the
+// pivot itself by v_readlane, the scaled column broadcast through a 16-double LDS line
+// (one write, three reads) -- one LDS round trip per pivot on the critical path.
+__device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
+                                       double* __restrict__ xd, gptr_t Xg, int ld,
+                                       int* info, int slot, int pivot0,
+                                       double* __restrict__ line /* 2 x 16 doubles of LDS */)
 {
     const int l = threadIdx.x & 63, r = l & 15, g = l >> 4;
     double a[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = 4 * g + j;
-        a[j] = (b <= r) ? St[r * DP + b] : 0.0;
+        a[j] = (b <= r) ? St[r * PP + b] : 0.0;
     }
+#ifndef PROBE_SKIP_BASE
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int gk = k >> 2, jk = k & 3;
-        const double piv = __shfl(a[jk], k + 16 * gk, 64);
+        const double piv = readlane_f64(a[jk], k + 16 * gk);
         if (!(piv > 0.0) && l == 0 && info[slot] == 0) info[slot] = pivot0 + k + 1;
-        const double inv = rsqrt(piv);         // NaN from here on for a non-PD input,
-        const double lkk = piv * inv;          // like jnp.linalg.cholesky
-        double cv = a[jk] * inv;               // column k scaled (meaningful in group gk)
-        if (r == k) cv = inv;                  // v'[k] = 1/l_kk feeds row k of the inverse
-        if (g == gk) a[jk] = (r == k) ? lkk : cv;
-        const double vrow = __shfl(cv, r + 16 * gk, 64);
+        double inv, lkk;
+        rsqrt_sqrt(piv, inv, lkk);
+        double* ln = line + 16 * (k & 1);
+        if (g == gk) {
+            const double cv = (r == k) ? inv : a[jk] * inv;   // v'[k] = 1/l_kk feeds the inverse's row k
+            a[jk] = (r == k) ? lkk : cv;
+            ln[r] = cv;
+        }
+        __builtin_amdgcn_wave_barrier();        // same wave, in-order LDS: the reads below see the line
+        const double vrow = ln[r];
+        double vc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vc[j] = ln[4 * g + j];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int b = 4 * g + j;
-            const double vc = __shfl(cv, b + 16 * gk, 64);
-            if (b > k && (r <= k || r >= b)) a[j] -= vrow * vc;
+            if (b > k && (r <= k || r >= b)) a[j] -= vrow * vc[j];
         }
     }
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = 4 * g + j;
-        if (b <= r) St[r * DP + b] = a[j];
+        if (b <= r) St[r * PP + b] = a[j];
         if (b > r) {
-            xd[b * XP + r] = a[j];  xd[r * XP + b] = 0.0;
+            xd[b * PP + r] = a[j];  xd[r * PP + b] = 0.0;
             Xg[(size_t)b * ld + r] = a[j];  Xg[(size_t)r * ld + b] = 0.0;
         } else if (b == r) {
             const double x = 1.0 / a[j];
-            xd[r * XP + r] = x;
+            xd[r * PP + r] = x;
             Xg[(size_t)r * ld + r] = x;
         }
     }
 }
 
-// C(16x16 at Ct) = Cin - A B^T with A rows at At (element (m,k) = At[m*as_r + k*as_k]),
-// B rows at Bt (element (k,n) = Bt[n*DP + k]); K = 16.  `set`: C = -A B^T (no read).
-__device__ __forceinline__ void tile16(double* __restrict__ Ct, const double* __restrict__ At,
-                                       int as_r, int as_k, const double* __restrict__ Bt, bool set)
+// acc -= A B^T over K = 16: A rows at At (element (m,k) = At[m*as_r + k*as_k]), B rows at Bt (pitch PP)
+__device__ __forceinline__ void sub_abt(v4d& acc, const double* __restrict__ At, int as_r, int as_k,
+                                        const double* __restrict__ Bt)
 {
     const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
-    v4d acc;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = set ? 0.0 : Ct[(fk + 4 * t) * DP + fr];
     double af[4], bf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         af[s] = -At[fr * as_r + (4 * s + fk) * as_k];
-        bf[s] = Bt[fr * DP + 4 * s + fk];
+        bf[s] = Bt[fr * PP + 4 * s + fk];
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Ct[(fk + 4 * t) * DP + fr] = acc[t];
-}
-
-// S(P,kb) <- S(P,kb) X_kb^T   (B operand from xd, element (k,n) = X_kb[n][k] = xd[n*XP + k])
-__device__ __forceinline__ void panel16(double* __restrict__ Ct, const double* __restrict__ xd)
-{
-    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    double af[4], bf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        af[s] = Ct[fr * DP + 4 * s + fk];
-        bf[s] = xd[fr * XP + 4 * s + fk];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) Ct[(fk + 4 * t) * DP + fr] = acc[t];
 }
 
 __global__ __launch_bounds__(256)
 void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info)
 {
-    extern __shared__ __attribute__((aligned(16))) double S[];   // 128 x DP, then 2 x 16 x XP
-    double* XD = S + 128 * DP;
+    __shared__ __attribute__((aligned(16))) double PA[128 * PP];   // column panel before scaling
+    __shared__ __attribute__((aligned(16))) double PB[128 * PP];   // ... after scaling by X_kb^T
+    __shared__ __attribute__((aligned(16))) double XD[2 * 16 * PP];
+    __shared__ __attribute__((aligned(16))) double LINE[32];
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-    double* Bt = ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off;
-    double* Xt = ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off;
-    const int tid = threadIdx.x, wave = tid >> 6;
+    gptr_t Bt = (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off);
+    gptr_t Xt = (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int fr = lane & 15, fk = lane >> 4;
+    const bool compute = wave < 3;
+    // this wave's sub-tile rows (-1 = none)
+    const int rows[3] = {wave == 0 ? 0 : (wave == 1 ? 1 : 2), wave == 0 ? 7 : (wave == 1 ? 6 : 5),
+                         wave == 0 ? -1 : (wave == 1 ? 3 : 4)};
 
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        S[r * DP + c] = (c <= r) ? Bt[(size_t)r * ld + c] : 0.0;
+    v4d acc[3][NSB];
+    if (compute) {
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int Q = 0; Q < NSB; ++Q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int row = 16 * rows[pp] + fk + 4 * t, col = 16 * Q + fr;
+                    acc[pp][Q][t] = (rows[pp] >= 0 && col <= row) ? Bt[(size_t)row * ld + col] : 0.0;
+                }
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (rows[pp] >= 0) PA[(16 * rows[pp] + fk + 4 * t) * PP + fr] = acc[pp][0][t];
     }
     __syncthreads();
-    if (wave == 0) base16(S, XD, Xt, ld, info, slot, kblk * GPRN_TILE);
+    if (!compute) base16(PA, XD, Xt, ld, info, slot, kblk * GPRN_TILE, LINE);
     __syncthreads();
 
     for (int kb = 0; kb < NSB; ++kb) {
-        const double* xd = XD + (kb & 1) * 16 * XP;
-        // ---- panel: every sub-tile of column kb except the diagonal one
-        for (int P = wave; P < NSB; P += 4)
-            if (P != kb) panel16(S + (16 * P) * DP + 16 * kb, xd);
-        __syncthreads();
-        if (kb == NSB - 1) break;
-        // ---- update, overlapped with the next base factorisation
-        if (wave == 0) {
-            const int n = kb + 1;
-            tile16(S + (16 * n) * DP + 16 * n, S + (16 * n) * DP + 16 * kb, DP, 1,
-                   S + (16 * n) * DP + 16 * kb, false);
-            base16(S + (16 * n) * DP + 16 * n, XD + (n & 1) * 16 * XP,
-                   Xt + (size_t)(16 * n) * ld + 16 * n, ld, info, slot,
-                   kblk * GPRN_TILE + 16 * n);
-        } else {
-            int idx = 0;
-            for (int Q = kb + 1; Q < NSB; ++Q) {
-                const double* Bq = S + (16 * Q) * DP + 16 * kb;
-                for (int P = 0; P < NSB; ++P) {
-                    if (P > kb && P < Q) continue;
-                    if (P == kb + 1 && Q == kb + 1) continue;          // wave 0 has it
-                    if ((idx++ % 3) != wave - 1) continue;
-                    double* Ct = S + (16 * P) * DP + 16 * Q;
-                    if (P == kb) tile16(Ct, xd, 1, XP, Bq, true);      // A = X_kb^T
-                    else tile16(Ct, S + (16 * P) * DP + 16 * kb, DP, 1, Bq, false);
+        const double* xd = XD + (kb & 1) * 16 * PP;
+        // ---- panel: S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back from the base wave
+        if (compute) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const int P = rows[pp];
+                if (P < 0) continue;
+#pragma unroll
+                for (int Q = 0; Q < NSB; ++Q) {
+                    if (Q != kb) continue;
+                    if (P == kb) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[pp][Q][t] = PA[(16 * P + fk + 4 * t) * PP + fr];
+                    } else {
+                        v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
+                        double af[4], bf[4];
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            af[s] = PA[(16 * P + fr) * PP + 4 * s + fk];
+                            bf[s] = xd[fr * PP + 4 * s + fk];
+                        }
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            r = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], r, 0, 0, 0);
+                        acc[pp][Q] = r;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) PB[(16 * P + fk + 4 * t) * PP + fr] = r[t];
+                    }
                 }
             }
         }
         __syncthreads();
+        if (kb == NSB - 1) break;
+        // ---- U1: column kb+1 first, published as the next panel
+        if (compute) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const int P = rows[pp];
+                if (P < 0) continue;
+#pragma unroll
+                for (int Q = 0; Q < NSB; ++Q) {
+                    if (Q != kb + 1) continue;
+                    if (P == kb) sub_abt(acc[pp][Q], xd, 1, PP, PB + (16 * Q) * PP);
+                    else sub_abt(acc[pp][Q], PB + (16 * P) * PP, PP, 1, PB + (16 * Q) * PP);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        PA[(16 * P + fk + 4 * t) * PP + fr] = acc[pp][Q][t];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- U2 (compute waves) overlapped with the next pivot chain (base wave)
+        if (compute) {
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const int P = rows[pp];
+                if (P < 0) continue;
+#pragma unroll
+                for (int Q = 0; Q < NSB; ++Q) {
+                    if (Q <= kb + 1) continue;
+#ifdef PROBE_SKIP_U2
+                    continue;
+#endif
+                    if (P == kb) sub_abt(acc[pp][Q], xd, 1, PP, PB + (16 * Q) * PP);
+                    else if (P < kb || P >= Q) sub_abt(acc[pp][Q], PB + (16 * P) * PP, PP, 1, PB + (16 * Q) * PP);
+                }
+            }
+        } else {
+            const int n = kb + 1;
+            base16(PA + (16 * n) * PP, XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n,
+                   ld, info, slot, kblk * GPRN_TILE + 16 * n, LINE);
+        }
+        __syncthreads();
     }
 
-    // L -> B tile (lower), X -> X tile; X's diagonal 16x16 blocks were written by base16
-    for (int e = tid; e < 128 * 128; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        if (c <= r) Bt[(size_t)r * ld + c] = S[r * DP + c];
-        if ((r >> 4) != (c >> 4)) Xt[(size_t)r * ld + c] = (c < r) ? S[c * DP + r] : 0.0;
+    // L -> B tile (lower); X -> X tile: sub-tile (P,Q), P < Q is X(Q,P)^T; zeros above the diagonal.
+    // X's diagonal 16x16 blocks were written by base16.
+    if (compute) {
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            const int P = rows[pp];
+            if (P < 0) continue;
+#pragma unroll
+            for (int Q = 0; Q < NSB; ++Q)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int r = fk + 4 * t;
+                    if (Q <= P) {
+                        const int row = 16 * P + r, col = 16 * Q + fr;
+                        if (col <= row) Bt[(size_t)row * ld + col] = acc[pp][Q][t];
+                    } else {
+#ifndef PROBE_SKIP_XSTORE
+                        Xt[(size_t)(16 * Q + fr) * ld + 16 * P + r] = acc[pp][Q][t];
+#endif
+                        Xt[(size_t)(16 * P + r) * ld + 16 * Q + fr] = 0.0;
+                    }
+                }
+        }
     }
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info)
 {
-    static bool attr_set = false;
-    const size_t shmem = (128 * DP + 2 * 16 * XP) * sizeof(double);
-    if (!attr_set) {
-        HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_diag_block),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        attr_set = true;
-    }
     prof_begin(c, GPRN_T_DIAG);
-    hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), shmem, c->stream,
+    hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, c->stream,
                        (double* const*)d_ptrs, ld, kblk, d_info);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -22,6 +22,7 @@
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef const GPRN_GLOBAL v2d* gv2d_t;
 
 #define OPER_DOUBLES 2304
 
@@ -32,9 +33,9 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 
     const TileTask t = tasks[blockIdx.x];
     double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
-    const double* __restrict__ A = gp[t.a_buf] + t.a_off;
-    const double* __restrict__ B = gp[t.b_buf] + t.b_off;
-    double* __restrict__ C = gp[t.c_buf] + t.c_off;
+    gcptr_t A = (gcptr_t)(gp[t.a_buf] + t.a_off);
+    gcptr_t B = (gcptr_t)(gp[t.b_buf] + t.b_off);
+    gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off);
     const int c_mode = t.modes & 3;
     const int a_mode = (t.modes >> 2) & 1;
     const int b_mode = (t.modes >> 3) & 1;
@@ -78,8 +79,8 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     v2d ra[4], rb[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        ra[it] = *reinterpret_cast<const v2d*>(A + a_g[it]);
-        rb[it] = *reinterpret_cast<const v2d*>(B + b_g[it]);
+        ra[it] = *(gv2d_t)(A + a_g[it]);
+        rb[it] = *(gv2d_t)(B + b_g[it]);
     }
 
     for (int c = 0; c < nchunks; ++c) {
@@ -96,8 +97,8 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
             B += b_step;
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                ra[it] = *reinterpret_cast<const v2d*>(A + a_g[it]);
-                rb[it] = *reinterpret_cast<const v2d*>(B + b_g[it]);
+                ra[it] = *(gv2d_t)(A + a_g[it]);
+                rb[it] = *(gv2d_t)(B + b_g[it]);
             }
         }
 #pragma unroll
@@ -117,14 +118,14 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     }
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
-    double* Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
+    gptr_t Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                double* pc = Cw + (size_t)(i * 16 + 4 * r) * ld + j * 16;
+                gptr_t pc = Cw + (size_t)(i * 16 + 4 * r) * ld + j * 16;
                 const double v = acc[i][j][r];
                 if (c_mode == CM_SET) *pc = v;
                 else if (c_mode == CM_SUB) *pc = *pc - v;

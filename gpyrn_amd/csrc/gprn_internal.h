@@ -13,6 +13,14 @@
 #define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
 #define GPRN_OUTER 4           // tiles per outer panel: bulk updates contract over 4*128 = 512
 
+// Pointers fetched from a device pointer table are generic to the compiler, which then emits
+// FLAT loads; those also tick the LDS counter (lgkmcnt), so the wait before the first MFMA of
+// a K-chunk would drain the global prefetch of the next chunk.  Casting to the global
+// address space yields global_load/global_store (vmcnt only) and keeps the prefetch in flight.
+#define GPRN_GLOBAL __attribute__((address_space(1)))
+typedef GPRN_GLOBAL double* gptr_t;
+typedef const GPRN_GLOBAL double* gcptr_t;
+
 // buffer slots of a tile task (index into the per-GP pointer table)
 enum { BUF_B = 0, BUF_X = 1, BUF_K = 2, BUF_KLINV = 3 };
 // c_mode of a tile task
