@@ -69,11 +69,19 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const int a_frag = (wr * 64 + fr) * a_rs + fk * a_ks;
     const int b_frag = (wc * 64 + fr) * b_rs + fk * b_ks;
 
+    // C -= A.B runs as D = (-A).B + C with the accumulators preloaded from C: the tile is read
+    // once, up front and all loads back to back (a read-modify-write epilogue serialises into 64
+    // dependent load->store round trips), and the epilogue is stores only.
+    const double a_sign = (c_mode == CM_SET) ? 1.0 : -1.0;
+    gptr_t Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
     v4d acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[i][j][r] = (c_mode == CM_SUB) ? Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] : 0.0;
 
     const int nchunks = t.klen / GPRN_KC;
     v2d ra[4], rb[4];
@@ -88,7 +96,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
         double* sB = sA + OPER_DOUBLES;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it];
+            *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it] * a_sign;
             *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
         }
         __syncthreads();
@@ -118,19 +126,13 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     }
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
-    gptr_t Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gptr_t pc = Cw + (size_t)(i * 16 + 4 * r) * ld + j * 16;
-                const double v = acc[i][j][r];
-                if (c_mode == CM_SET) *pc = v;
-                else if (c_mode == CM_SUB) *pc = *pc - v;
-                else *pc = -v;
-            }
+            for (int r = 0; r < 4; ++r)
+                Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = acc[i][j][r];
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
