@@ -46,18 +46,16 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // The update of column kb+1 goes first (U1) and is published to LDS, so that the base
 // wave factors S(kb+1,kb+1) while the compute waves finish the rest of the update (U2).
 
-// 1/sqrt(x) and sqrt(x) to fp64 round-off from the hardware seed (v_rsq_f64, ~2^-26) plus
-// Newton steps: a fraction of the latency of the IEEE sqrt + divide sequences, and this
-// sits on the serial pivot chain.  NaN for x < 0 (jnp.linalg.cholesky semantics).
-__device__ __forceinline__ void rsqrt_sqrt(double x, double& inv, double& root)
+// 1/sqrt(x) to fp64 round-off from the hardware seed (v_rsq_f64) plus two Newton steps: a
+// fraction of the latency of the IEEE sqrt + divide sequences, and this sits on the serial
+// pivot chain.  NaN for x < 0 (jnp.linalg.cholesky semantics).
+__device__ __forceinline__ double rsqrt_nr(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    y = y * fma(-0.5 * x * y, y, 1.5);
-    double sq = x * y;
-    sq = fma(0.5 * y, fma(-sq, sq, x), sq);
-    inv = y;
-    root = sq;
+    const double hx = -0.5 * x;
+    y = y * fma(hx * y, y, 1.5);
+    y = y * fma(hx * y, y, 1.5);
+    return y;
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-uniform */)
@@ -69,8 +67,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
 
 // potf2 + trtri2 of a 16x16 block in registers: lane (r = l&15, g = l>>4) owns columns
 // 4g..4g+3 of row r; strict upper = transposed right-hand side, as in S.  Per pivot: the
-// pivot itself by v_readlane, the scaled column broadcast through a 16-double LDS line
-// (one write, three reads) -- one LDS round trip per pivot on the critical path.
+// pivot itself by v_readlane; the *unscaled* column is broadcast through a 16-double LDS
+// line while every lane computes 1/sqrt(pivot) -- the LDS round trip hides under the
+// Newton iteration instead of following it.
 __device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
                                        double* __restrict__ xd, gptr_t Xg, int ld,
                                        int* info, int slot, int pivot0,
@@ -83,32 +82,29 @@ __device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
         const int b = 4 * g + j;
         a[j] = (b <= r) ? St[r * PP + b] : 0.0;
     }
-#ifndef PROBE_SKIP_BASE
+    int bad_at = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int gk = k >> 2, jk = k & 3;
         const double piv = readlane_f64(a[jk], k + 16 * gk);
-        if (!(piv > 0.0) && l == 0 && info[slot] == 0) info[slot] = pivot0 + k + 1;
-        double inv, lkk;
-        rsqrt_sqrt(piv, inv, lkk);
         double* ln = line + 16 * (k & 1);
-        if (g == gk) {
-            const double cv = (r == k) ? inv : a[jk] * inv;   // v'[k] = 1/l_kk feeds the inverse's row k
-            a[jk] = (r == k) ? lkk : cv;
-            ln[r] = cv;
-        }
+        if (g == gk) ln[r] = a[jk];
         __builtin_amdgcn_wave_barrier();        // same wave, in-order LDS: the reads below see the line
-        const double vrow = ln[r];
-        double vc[4];
+        const double raw_row = ln[r];
+        double raw_c[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vc[j] = ln[4 * g + j];
+        for (int j = 0; j < 4; ++j) raw_c[j] = ln[4 * g + j];
+        bad_at = (bad_at == 0 && !(piv > 0.0)) ? k + 1 : bad_at;
+        const double inv = rsqrt_nr(piv);
+        const double vrow = (r == k) ? inv : raw_row * inv;   // v'[k] = 1/l_kk feeds the inverse's row k
+        if (g == gk) a[jk] = (r == k) ? piv * inv : vrow;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int b = 4 * g + j;
-            if (b > k && (r <= k || r >= b)) a[j] -= vrow * vc[j];
+            if (b > k && (r <= k || r >= b)) a[j] -= vrow * (raw_c[j] * inv);
         }
     }
-#endif
+    if (bad_at && l == 0 && info[slot] == 0) info[slot] = pivot0 + bad_at;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int b = 4 * g + j;
@@ -140,12 +136,55 @@ __device__ __forceinline__ void sub_abt(v4d& acc, const double* __restrict__ At,
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
 }
 
+// r = A B^T over K = 16 (A rows at At pitch PP, B rows at Bt pitch PP)
+__device__ __forceinline__ v4d mul_abt(const double* __restrict__ At, const double* __restrict__ Bt)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+    v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
+    double af[4], bf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        af[s] = At[fr * PP + 4 * s + fk];
+        bf[s] = Bt[fr * PP + 4 * s + fk];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        r = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], r, 0, 0, 0);
+    return r;
+}
+
+// 16x16 tile in MFMA C/D layout <-> LDS image [row][col], pitch PP
+__device__ __forceinline__ void put16(double* __restrict__ T, const v4d& v)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) T[(fk + 4 * t) * PP + fr] = v[t];
+}
+__device__ __forceinline__ v4d get16(const double* __restrict__ T)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+    v4d v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = T[(fk + 4 * t) * PP + fr];
+    return v;
+}
+
+// Schedule.  Phase kb = 0..7, one workgroup barrier in the middle (M) and one at the end (E):
+//   compute waves:  panel(kb) with X_kb            | M |  update(kb); publish column kb+1 (pre-
+//                   (diag sub-tile kb <- L_kb)     |   |  scaling) and diagonal sub-tile kb+2
+//   pivot wave   :  L' = S(kb+1,kb) X_kb^T,        | M |  base(kb+1): L_{kb+1}, X_{kb+1}
+//                   T = S(kb+1,kb+1) - L' L'^T     |   |
+// The pivot wave runs one step ahead of the compute waves: it needs only the column panel and
+// the diagonal sub-tile as they stood after update(kb-1), both published to LDS in phase kb-1,
+// so the 16-pivot chains (the serial part) never wait for the bulk of the update.
 __global__ __launch_bounds__(256)
 void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info)
 {
-    __shared__ __attribute__((aligned(16))) double PA[128 * PP];   // column panel before scaling
-    __shared__ __attribute__((aligned(16))) double PB[128 * PP];   // ... after scaling by X_kb^T
-    __shared__ __attribute__((aligned(16))) double XD[2 * 16 * PP];
+    __shared__ __attribute__((aligned(16))) double PA[2 * 128 * PP];   // published column panels (by parity)
+    __shared__ __attribute__((aligned(16))) double PB[128 * PP];       // current column after scaling by X_kb^T
+    __shared__ __attribute__((aligned(16))) double DG[2 * 16 * PP];    // diagonal sub-tiles for / from the pivot wave
+    __shared__ __attribute__((aligned(16))) double XD[2 * 16 * PP];    // X_kb by parity
+    __shared__ __attribute__((aligned(16))) double SC[16 * PP];        // pivot wave scratch
     __shared__ __attribute__((aligned(16))) double LINE[32];
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
@@ -169,20 +208,27 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
                     const int row = 16 * rows[pp] + fk + 4 * t, col = 16 * Q + fr;
                     acc[pp][Q][t] = (rows[pp] >= 0 && col <= row) ? Bt[(size_t)row * ld + col] : 0.0;
                 }
+        // publish column 0 and the diagonal sub-tiles 0 and 1 as they are
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp)
+        for (int pp = 0; pp < 3; ++pp) {
+            const int P = rows[pp];
+            if (P < 0) continue;
+            put16(PA + (16 * P) * PP, acc[pp][0]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (rows[pp] >= 0) PA[(16 * rows[pp] + fk + 4 * t) * PP + fr] = acc[pp][0][t];
+            for (int Q = 0; Q < 2; ++Q)
+                if (P == Q) put16(DG + Q * 16 * PP, acc[pp][Q]);
+        }
     }
     __syncthreads();
-    if (!compute) base16(PA, XD, Xt, ld, info, slot, kblk * GPRN_TILE, LINE);
+    if (!compute) base16(DG, XD, Xt, ld, info, slot, kblk * GPRN_TILE, LINE);
     __syncthreads();
 
     for (int kb = 0; kb < NSB; ++kb) {
         const double* xd = XD + (kb & 1) * 16 * PP;
-        // ---- panel: S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back from the base wave
+        const double* pa = PA + (kb & 1) * 128 * PP;
+        double* pa_next = PA + ((kb + 1) & 1) * 128 * PP;
         if (compute) {
+            // ---- panel(kb): S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back as L_kb
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
                 const int P = rows[pp];
@@ -190,93 +236,87 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
 #pragma unroll
                 for (int Q = 0; Q < NSB; ++Q) {
                     if (Q != kb) continue;
-                    if (P == kb) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) acc[pp][Q][t] = PA[(16 * P + fk + 4 * t) * PP + fr];
-                    } else {
-                        v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
-                        double af[4], bf[4];
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            af[s] = PA[(16 * P + fr) * PP + 4 * s + fk];
-                            bf[s] = xd[fr * PP + 4 * s + fk];
-                        }
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            r = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], r, 0, 0, 0);
-                        acc[pp][Q] = r;
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) PB[(16 * P + fk + 4 * t) * PP + fr] = r[t];
+                    if (P == kb) acc[pp][Q] = get16(DG + (kb & 1) * 16 * PP);
+                    else {
+                        acc[pp][Q] = mul_abt(pa + (16 * P) * PP, xd);
+                        put16(PB + (16 * P) * PP, acc[pp][Q]);
                     }
                 }
             }
-        }
-        __syncthreads();
-        if (kb == NSB - 1) break;
-        // ---- U1: column kb+1 first, published as the next panel
-        if (compute) {
+            __syncthreads();                                   // M
+            if (kb < NSB - 1) {
+                // ---- update(kb): column kb+1 first (published as the next panel), then the rest
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                const int P = rows[pp];
-                if (P < 0) continue;
+                for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-                for (int Q = 0; Q < NSB; ++Q) {
-                    if (Q != kb + 1) continue;
-                    if (P == kb) sub_abt(acc[pp][Q], xd, 1, PP, PB + (16 * Q) * PP);
-                    else sub_abt(acc[pp][Q], PB + (16 * P) * PP, PP, 1, PB + (16 * Q) * PP);
+                    for (int pp = 0; pp < 3; ++pp) {
+                        const int P = rows[pp];
+                        if (P < 0) continue;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        PA[(16 * P + fk + 4 * t) * PP + fr] = acc[pp][Q][t];
-                }
-            }
-        }
-        __syncthreads();
-        // ---- U2 (compute waves) overlapped with the next pivot chain (base wave)
-        if (compute) {
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                const int P = rows[pp];
-                if (P < 0) continue;
-#pragma unroll
-                for (int Q = 0; Q < NSB; ++Q) {
-                    if (Q <= kb + 1) continue;
-#ifdef PROBE_SKIP_U2
-                    continue;
-#endif
-                    if (P == kb) sub_abt(acc[pp][Q], xd, 1, PP, PB + (16 * Q) * PP);
-                    else if (P < kb || P >= Q) sub_abt(acc[pp][Q], PB + (16 * P) * PP, PP, 1, PB + (16 * Q) * PP);
-                }
+                        for (int Q = 0; Q < NSB; ++Q) {
+                            if (Q <= kb || (Q == kb + 1) != (pass == 0)) continue;
+                            if (P == kb + 1 && Q == kb + 1) continue;          // the pivot wave's tile
+                            if (P == kb) sub_abt(acc[pp][Q], xd, 1, PP, PB + (16 * Q) * PP);
+                            else if (P < kb || P >= Q)
+                                sub_abt(acc[pp][Q], PB + (16 * P) * PP, PP, 1, PB + (16 * Q) * PP);
+                            else continue;
+                            if (Q == kb + 1) put16(pa_next + (16 * P) * PP, acc[pp][Q]);
+                            if (Q == kb + 2 && P == Q) put16(DG + (kb & 1) * 16 * PP, acc[pp][Q]);
+                        }
+                    }
             }
         } else {
-            const int n = kb + 1;
-            base16(PA + (16 * n) * PP, XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n,
-                   ld, info, slot, kblk * GPRN_TILE + 16 * n, LINE);
+            if (kb < NSB - 1) {
+                // ---- one step ahead: bring S(kb+1,kb+1) up to date through step kb, then factor it
+                const int n = kb + 1;
+                double* dg = DG + (n & 1) * 16 * PP;
+                v4d lp = mul_abt(pa + (16 * n) * PP, xd);
+                put16(SC, lp);
+                v4d tt = get16(dg);
+                sub_abt(tt, SC, PP, 1, SC);
+                put16(dg, tt);
+            }
+            __syncthreads();                                   // M
+            if (kb < NSB - 1) {
+                const int n = kb + 1;
+                base16(DG + (n & 1) * 16 * PP, XD + (n & 1) * 16 * PP,
+                       Xt + (size_t)(16 * n) * ld + 16 * n, ld, info, slot,
+                       kblk * GPRN_TILE + 16 * n, LINE);
+            }
         }
-        __syncthreads();
+        __syncthreads();                                       // E
     }
 
-    // L -> B tile (lower); X -> X tile: sub-tile (P,Q), P < Q is X(Q,P)^T; zeros above the diagonal.
-    // X's diagonal 16x16 blocks were written by base16.
+    // L -> B tile (lower).  X -> X tile: sub-tile (P,Q), P < Q holds X(Q,P)^T -- transposed through a
+    // per-wave LDS patch so the global stores run along rows; zeros above the diagonal.  X's
+    // diagonal 16x16 blocks were written by base16.
     if (compute) {
+        double* patch = PB + wave * 16 * PP;
 #pragma unroll
         for (int pp = 0; pp < 3; ++pp) {
             const int P = rows[pp];
             if (P < 0) continue;
 #pragma unroll
-            for (int Q = 0; Q < NSB; ++Q)
+            for (int Q = 0; Q < NSB; ++Q) {
+                if (Q <= P) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int r = fk + 4 * t;
-                    if (Q <= P) {
-                        const int row = 16 * P + r, col = 16 * Q + fr;
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = 16 * P + fk + 4 * t, col = 16 * Q + fr;
                         if (col <= row) Bt[(size_t)row * ld + col] = acc[pp][Q][t];
-                    } else {
-#ifndef PROBE_SKIP_XSTORE
-                        Xt[(size_t)(16 * Q + fr) * ld + 16 * P + r] = acc[pp][Q][t];
-#endif
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) patch[fr * PP + fk + 4 * t] = acc[pp][Q][t];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int r = fk + 4 * t;
+                        Xt[(size_t)(16 * Q + r) * ld + 16 * P + fr] = patch[r * PP + fr];
                         Xt[(size_t)(16 * P + r) * ld + 16 * Q + fr] = 0.0;
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
+            }
         }
     }
 }
