@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <math.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -139,8 +140,8 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
     gprn_ctx* c = new gprn_ctx();
     c->device = device_id;
-    // the chain stream outranks the bulk stream so that the small, latency-critical kernels of
-    // the factorisation are dispatched ahead of queued trailing-update workgroups
+    // Two streams: `stream` carries everything incl. the latency chain of the factorisation,
+    // `stream2` the bulk trailing updates running behind it (look-ahead).
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
@@ -404,7 +405,8 @@ extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id12
     HIP_TRY(c, hipSetDevice(c->device));
     comm_teardown(c);
     c->world = world; c->rank = rank;
-    if (world == 1) return GPRN_OK;
+    // a one-rank communicator is legal RCCL and lets a single GPU exercise every collective call
+    if (world == 1 && !getenv("GPRN_FORCE_RCCL")) return GPRN_OK;
     if (!id128) return bad(c, "comm_init: id required");
     TRY(rccl_load(&c->err));
     ncclUniqueId id;
@@ -430,7 +432,7 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 {
     if (!c || !value) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->world > 1 && c->comm) {
+    if (c->comm) {
         double* d = nullptr;
         TRY(dev_alloc(c, &d, 1));
         HIP_TRY(c, hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -447,7 +449,7 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 // rows of the (p+1, q, N) state owned by other ranks arrive from their owners
 static int exchange_rows(gprn_ctx* c, bool weights)
 {
-    if (c->world == 1) return GPRN_OK;
+    if (!c->comm) return GPRN_OK;
     const int g0 = weights ? c->q : 0, g1 = weights ? c->G : c->q;
     NCCL_TRY(c, g_rccl.GroupStart());
     for (int g = g0; g < g1; ++g) {
@@ -465,7 +467,7 @@ static int exchange_rows(gprn_ctx* c, bool weights)
 
 static int reduce_scalars(gprn_ctx* c)
 {
-    if (c->world == 1) return GPRN_OK;
+    if (!c->comm) return GPRN_OK;
     const size_t n = 3 * (size_t)c->G + (size_t)c->q * c->q;
     NCCL_TRY(c, g_rccl.AllReduce(c->d_scal, c->d_scal, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
     return GPRN_OK;
@@ -630,7 +632,7 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
         HIP_TRY(c, hipMemcpy(h.data(), c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
         for (int g = 0; g < c->G; ++g) if (c->owner[g] != c->rank) h[g] = 0.0;
         HIP_TRY(c, hipMemcpy(c->d_logdetK, h.data(), c->G * sizeof(double), hipMemcpyHostToDevice));
-        if (c->world > 1)
+        if (c->comm)
             NCCL_TRY(c, g_rccl.AllReduce(c->d_logdetK, c->d_logdetK, c->G, ncclDouble, ncclSum,
                                          (ncclComm_t)c->comm, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -405,7 +405,15 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
             if (pass == 0) { o.next0 = begin; o.nnext = v.size() - begin; }
-            else { o.rest0 = begin; o.nrest = v.size() - begin; }
+            else {
+                // Workgroups are dispatched in task order and are not preempted: with the short
+                // first-touch tasks (K = 128..384) in front, the first slots free up after a
+                // quarter of a full task instead of all at once, so the next panel's small,
+                // higher-priority kernels get onto the CUs early.
+                std::stable_sort(v.begin() + begin, v.end(),
+                                 [](const TileTask& a, const TileTask& b) { return a.klen < b.klen; });
+                o.rest0 = begin; o.nrest = v.size() - begin;
+            }
         }
         c->outers.push_back(o);
     }

@@ -20,6 +20,8 @@
 // two workgroups per CU.
 #include "gprn_internal.h"
 
+#include <stdlib.h>
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const GPRN_GLOBAL v2d* gv2d_t;
@@ -142,7 +144,15 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     if (!stream) stream = c->stream;
     prof_begin(c, fam, stream);
     dim3 grid((unsigned)ntasks, (unsigned)nbatch);
-    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), 0, stream, d_tasks,
+    // Bulk launches on the look-ahead stream ask for 16 KiB of unused dynamic LDS on top of the
+    // 72 KiB image: one workgroup per CU instead of two.  Workgroups are never preempted and stream
+    // priorities do not reorder dispatch, so this is what keeps half of every CU's LDS and wave
+    // slots open for the latency chain's kernels (measured +4 % sweeps/s at config 3; a CU mask
+    // for the bulk stream measured worse).  GPRN_BULK_PAD_KB overrides.
+    static int pad_kb = -1;
+    if (pad_kb < 0) { const char* e = getenv("GPRN_BULK_PAD_KB"); pad_kb = e ? atoi(e) : 16; }
+    const size_t dyn = (stream == c->stream2) ? (size_t)pad_kb * 1024 : 0;
+    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), dyn, stream, d_tasks,
                        (double* const*)d_ptrs, ld);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

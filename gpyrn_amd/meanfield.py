@@ -20,6 +20,7 @@ first ``ELBOaux`` of ``ELBOcalc`` is evaluated and discarded (its ELBO is
 on the converged return; ``_initMuVar`` uses the first p weight amplitudes and
 emits the weight block node-major; ELBO = (LogL + LogP + Ent) / q.
 """
+import os
 import time as time_module
 from itertools import chain
 
@@ -285,9 +286,11 @@ class inference:
             comm = self._comm
             device = self._device
             if device is None:
-                device = comm.local_rank if comm is not None else 0
+                # one rank per GPU; with fewer GPUs than ranks (rehearsals) ranks share devices
+                device = comm.local_rank % max(1, _hip.device_count()) if comm is not None else 0
             ctx = _hip.Context(device)
-            if comm is not None and comm.world > 1:
+            forced = bool(os.environ.get('GPRN_FORCE_RCCL'))      # one-rank communicator, for tests
+            if comm is not None and (comm.world > 1 or forced):
                 ctx.comm_init(comm.world, comm.rank, comm.unique_id())
             ctx.set_data(np.asarray(self.time, dtype=float), self.y, self.yerr, self.q)
             if comm is not None and comm.world > 1:

@@ -184,3 +184,23 @@ def test_cfg3_properties_full_size():
     if _cases.available('cfg3_N4096'):
         dd = _cases.load('cfg3_N4096')[1]
         np.testing.assert_allclose(e_a[:2], dd['elbo_sweeps'], rtol=RTOL)
+
+
+def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
+    """Every collective of the sharded sweep (grouped row broadcasts, scalar all-reduce,
+    barrier) executed for real on RCCL with world = 1: results must not change."""
+    from gpyrn_amd import sharding
+    monkeypatch.setenv('GPRN_FORCE_RCCL', '1')
+    meta, d, g_plain = _model('step_p3q2')
+    ref = g_plain.ELBOcalc()
+    meta, d, g = _model('step_p3q2')
+
+    class OneRank(sharding.Comm):
+        def unique_id(self, timeout=0):
+            return _hip.comm_unique_id()
+    g._comm = OneRank(world=1, rank=0, local_rank=0)
+    ctx = g._backend()
+    assert ctx.barrier_max(3.5) == 3.5
+    out = g.ELBOcalc()
+    assert out[3] == ref[3] and out[0] == ref[0]
+    assert np.array_equal(out[1], ref[1])
