@@ -836,7 +836,7 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
             t.b_off = b_mode == 0 ? (int64_t)tj * GPRN_TILE * ld : (int64_t)tj * GPRN_TILE;
             t.klen = K;
             t.c_buf = 2; t.a_buf = 0; t.b_buf = 1;
-            t.modes = tile_modes(c_mode, a_mode, b_mode);
+            t.modes = tile_modes(c_mode & 3, a_mode, b_mode);
             tasks.push_back(t);
         }
     TileTask* d_t = nullptr;
@@ -846,7 +846,7 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
     double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], c->d_test[2], nullptr};
     HIP_TRY(c, hipMemcpy(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice));
-    int rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE);
+    int rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, (c_mode >> 4) & 3);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess)
         e = hipMemcpy(hc.data(), c->d_test[2], nn * sizeof(double), hipMemcpyDeviceToHost);

@@ -19,6 +19,7 @@
 #include "gprn_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -96,12 +97,14 @@ __device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
         for (int j = 0; j < 4; ++j) raw_c[j] = ln[4 * g + j];
         bad_at = (bad_at == 0 && !(piv > 0.0)) ? k + 1 : bad_at;
         const double inv = rsqrt_nr(piv);
-        const double vrow = (r == k) ? inv : raw_row * inv;   // v'[k] = 1/l_kk feeds the inverse's row k
-        if (g == gk) a[jk] = (r == k) ? piv * inv : vrow;
+        // scaled column entry of this lane's row; v'[k] = 1/l_kk feeds the inverse's row k
+        if (g == gk) a[jk] = (r == k) ? piv * inv : raw_row * inv;
+        // rank-1 update a[j] -= v'[r] v[b] with both 1/l_kk folded into one factor
+        const double vrow2 = ((r == k) ? 1.0 : raw_row) * (inv * inv);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int b = 4 * g + j;
-            if (b > k && (r <= k || r >= b)) a[j] -= vrow * (raw_c[j] * inv);
+            if (b > k && (r <= k || r >= b)) a[j] = fma(-vrow2, raw_c[j], a[j]);
         }
     }
     if (bad_at && l == 0 && info[slot] == 0) info[slot] = pivot0 + bad_at;
@@ -356,16 +359,19 @@ int ensure_tasks(gprn_ctx* c)
     if (c->tasks_T == T && c->d_tasks) return GPRN_OK;
     std::vector<TileTask>& v = c->h_tasks;
     v.clear();
-    c->steps.assign(T, gprn_ctx::StepRange{0, 0, 0, 0});
+    c->steps.assign(T, gprn_ctx::StepRange{0, 0, 0, 0, 0});
     c->outers.clear();
-    for (int k0 = 0; k0 < T; k0 += GPRN_OUTER) {
-        const int k1 = std::min(T, k0 + GPRN_OUTER);
+    static int outer = 0;                          // GPRN_OUTER_TILES overrides (experiments)
+    if (!outer) { const char* e = getenv("GPRN_OUTER_TILES"); outer = e && atoi(e) > 0 ? atoi(e) : GPRN_OUTER; }
+    for (int k0 = 0; k0 < T; k0 += outer) {
+        const int k1 = std::min(T, k0 + outer);
         for (int k = k0; k < k1; ++k) {
             gprn_ctx::StepRange& s = c->steps[k];
             s.panel0 = v.size();
             for (int i = k + 1; i < T; ++i)            // L_ik = B_ik X_kk^T   (in place)
                 v.push_back(TileTask{toff(i, k, ld), toff(i, k, ld), toff(k, k, ld), GPRN_TILE,
                                      BUF_B, BUF_B, BUF_X, tile_modes(CM_SET, 0, 0)});
+            s.npanel_l = v.size() - s.panel0;
             for (int cc = 0; cc < k; ++cc)             // X_kc = X_kk R_kc     (in place)
                 v.push_back(TileTask{toff(k, cc, ld), toff(k, k, ld), toff(k, cc, ld), GPRN_TILE,
                                      BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)});
@@ -384,7 +390,7 @@ int ensure_tasks(gprn_ctx* c)
         }
         gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
-        const int n1 = std::min(T, k1 + GPRN_OUTER);   // the next panel is tiles [k1, n1)
+        const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
         for (int pass = 0; pass < 2; ++pass) {         // 0: what the next panel needs, 1: the rest
             const size_t begin = v.size();
             for (int i = k1; i < T; ++i) {
@@ -444,22 +450,31 @@ int factor_invert(gprn_ctx* c, int nbatch)
     int rc = ensure_tasks(c);
     if (rc) return rc;
     bool rest_pending = false;
+    // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
+    // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.
+    // In-place panel tasks may only be cut along the dimension they do not read across.
+    auto few = [&](size_t ntasks) { return ntasks * (size_t)nbatch <= 320; };
     for (size_t J = 0; J < c->outers.size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[J];
         for (int k = o.k0; k < o.k1; ++k) {            // the latency chain of this panel
             const gprn_ctx::StepRange& s = c->steps[k];
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
-            if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
-                                   GPRN_T_PANEL))) return rc;
+            if (few(s.npanel)) {
+                if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel_l, c->d_ptrs, nbatch, c->ld,
+                                       GPRN_T_PANEL, nullptr, TS_64x128))) return rc;
+                if ((rc = launch_tiles(c, c->d_tasks + s.panel0 + s.npanel_l, s.npanel - s.npanel_l,
+                                       c->d_ptrs, nbatch, c->ld, GPRN_T_PANEL, nullptr, TS_128x64))) return rc;
+            } else if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
+                                          GPRN_T_PANEL))) return rc;
             if ((rc = launch_tiles(c, c->d_tasks + s.upd0, s.nupd, c->d_ptrs, nbatch, c->ld,
-                                   GPRN_T_PANEL))) return rc;
+                                   GPRN_T_PANEL, nullptr, few(s.nupd) ? TS_64x64 : TS_128x128))) return rc;
         }
         if (o.nnext + o.nrest == 0) continue;
         HIP_TRY(c, hipEventRecord(c->ev_panel, c->stream));
         if (rest_pending)                              // same tiles as the previous panel's rest
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
         if ((rc = launch_tiles(c, c->d_tasks + o.next0, o.nnext, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_UPDATE))) return rc;
+                               GPRN_T_UPDATE, nullptr, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
         if (o.nrest) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
             if ((rc = launch_tiles(c, c->d_tasks + o.rest0, o.nrest, c->d_ptrs, nbatch, c->ld,

@@ -26,21 +26,32 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const GPRN_GLOBAL v2d* gv2d_t;
 
-#define OPER_DOUBLES 2304
-
+// Output tile of one workgroup: BM x BN in {64,128}^2.  A 128x128 task is cut into
+// (128/BM) x (128/BN) workgroups (sub-tile index = blockIdx.x % that).  128x128 is the
+// throughput shape (bulk updates); the smaller shapes put a latency-bound launch -- a few
+// dozen tasks with K = 128 on the factorisation's critical path -- on 2-4x as many CUs:
+//   64x128 (rows split)  is safe for in-place panel tasks whose C tile is their A operand,
+//   128x64 (cols split)  for in-place tasks whose C tile is their B operand,
+//   64x64                for everything that is not in place.
+template <int BM, int BN>
 __global__ __launch_bounds__(256, 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld)
 {
-    __shared__ __attribute__((aligned(16))) double lds[4 * OPER_DOUBLES];
+    constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
+    constexpr int MI = BM / 32, NI = BN / 32;                   // 16x16 MFMA tiles per wave (2x2 waves)
+    constexpr int A_DOUBLES = 16 * BM + 256, B_DOUBLES = 16 * BN + 256;   // >= BM*18 and 16*(BM+16)
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;               // 16-byte loads per thread per chunk
+    __shared__ __attribute__((aligned(16))) double lds[2 * (A_DOUBLES + B_DOUBLES)];
 
-    const TileTask t = tasks[blockIdx.x];
+    const TileTask t = tasks[blockIdx.x / (SM * SN)];
+    const int sub = blockIdx.x % (SM * SN), sr = sub / SN, sc = sub % SN;
     double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
-    gcptr_t A = (gcptr_t)(gp[t.a_buf] + t.a_off);
-    gcptr_t B = (gcptr_t)(gp[t.b_buf] + t.b_off);
-    gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off);
     const int c_mode = t.modes & 3;
     const int a_mode = (t.modes >> 2) & 1;
     const int b_mode = (t.modes >> 3) & 1;
+    gcptr_t A = (gcptr_t)(gp[t.a_buf] + t.a_off) + (a_mode ? (size_t)sr * BM : (size_t)sr * BM * ld);
+    gcptr_t B = (gcptr_t)(gp[t.b_buf] + t.b_off) + (b_mode ? (size_t)sc * BN : (size_t)sc * BN * ld);
+    gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off) + (size_t)sr * BM * ld + sc * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -48,102 +59,102 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const int wr = wave >> 1, wc = wave & 1;
 
     // ---- global -> LDS staging geometry (pairs of doubles along the contiguous dim)
-    const int a_shift = a_mode ? 6 : 3, b_shift = b_mode ? 6 : 3;
-    const int a_pitch = a_mode ? 144 : 18, b_pitch = b_mode ? 144 : 18;
+    // k-contiguous operand: image [row][k], pitch 18;  row-contiguous: image [k][row], pitch rows+16
+    const int a_shift = a_mode ? (BM == 128 ? 6 : 5) : 3, b_shift = b_mode ? (BN == 128 ? 6 : 5) : 3;
+    const int a_pitch = a_mode ? BM + 16 : 18, b_pitch = b_mode ? BN + 16 : 18;
     const size_t a_step = a_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
     const size_t b_step = b_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
-    size_t a_g[4], b_g[4];
-    int a_l[4], b_l[4];
+    size_t a_g[A_IT], b_g[B_IT];
+    int a_l[A_IT], b_l[B_IT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < A_IT; ++it) {
         const int pi = tid + 256 * it;
         const int as = pi >> a_shift, af = pi & ((1 << a_shift) - 1);
-        const int bs = pi >> b_shift, bf = pi & ((1 << b_shift) - 1);
         a_g[it] = (size_t)as * ld + 2 * af;
         a_l[it] = as * a_pitch + 2 * af;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int pi = tid + 256 * it;
+        const int bs = pi >> b_shift, bf = pi & ((1 << b_shift) - 1);
         b_g[it] = (size_t)bs * ld + 2 * bf;
         b_l[it] = bs * b_pitch + 2 * bf;
     }
     // ---- MFMA operand fetch geometry: lane holds A[row = l&15][k = l>>4], B[k = l>>4][col = l&15]
     const int fr = lane & 15, fk = lane >> 4;
-    const int a_rs = a_mode ? 1 : 18, a_ks = a_mode ? 144 : 1;
-    const int b_rs = b_mode ? 1 : 18, b_ks = b_mode ? 144 : 1;
-    const int a_frag = (wr * 64 + fr) * a_rs + fk * a_ks;
-    const int b_frag = (wc * 64 + fr) * b_rs + fk * b_ks;
+    const int a_rs = a_mode ? 1 : 18, a_ks = a_mode ? BM + 16 : 1;
+    const int b_rs = b_mode ? 1 : 18, b_ks = b_mode ? BN + 16 : 1;
+    const int a_frag = (wr * (BM / 2) + fr) * a_rs + fk * a_ks;
+    const int b_frag = (wc * (BN / 2) + fr) * b_rs + fk * b_ks;
 
     // C -= A.B runs as D = (-A).B + C with the accumulators preloaded from C: the tile is read
-    // once, up front and all loads back to back (a read-modify-write epilogue serialises into 64
+    // once, up front and all loads back to back (a read-modify-write epilogue serialises into
     // dependent load->store round trips), and the epilogue is stores only.
     const double a_sign = (c_mode == CM_SET) ? 1.0 : -1.0;
-    gptr_t Cw = C + (size_t)(wr * 64 + fk) * ld + wc * 64 + fr;
-    v4d acc[4][4];
+    gptr_t Cw = C + (size_t)(wr * (BM / 2) + fk) * ld + wc * (BN / 2) + fr;
+    v4d acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc[i][j][r] = (c_mode == CM_SUB) ? Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] : 0.0;
 
     const int nchunks = t.klen / GPRN_KC;
-    v2d ra[4], rb[4];
+    v2d ra[A_IT], rb[B_IT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        ra[it] = *(gv2d_t)(A + a_g[it]);
-        rb[it] = *(gv2d_t)(B + b_g[it]);
-    }
+    for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
 
     for (int c = 0; c < nchunks; ++c) {
-        double* sA = lds + (c & 1) * 2 * OPER_DOUBLES;
-        double* sB = sA + OPER_DOUBLES;
+        double* sA = lds + (c & 1) * (A_DOUBLES + B_DOUBLES);
+        double* sB = sA + A_DOUBLES;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it] * a_sign;
-            *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
-        }
+        for (int it = 0; it < A_IT; ++it) *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it] * a_sign;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
         __syncthreads();
         if (c + 1 < nchunks) {
             A += a_step;
             B += b_step;
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                ra[it] = *(gv2d_t)(A + a_g[it]);
-                rb[it] = *(gv2d_t)(B + b_g[it]);
-            }
+            for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
         }
 #pragma unroll
         for (int ks = 0; ks < GPRN_KC / 4; ++ks) {
-            double af[4], bf[4];
+            double af[MI], bf[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = sA[a_frag + i * 16 * a_rs + ks * 4 * a_ks];
-                bf[i] = sB[b_frag + i * 16 * b_rs + ks * 4 * b_ks];
-            }
+            for (int i = 0; i < MI; ++i) af[i] = sA[a_frag + i * 16 * a_rs + ks * 4 * a_ks];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < NI; ++j) bf[j] = sB[b_frag + j * 16 * b_rs + ks * 4 * b_ks];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = acc[i][j][r];
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream)
+                 int nbatch, int ld, int fam, hipStream_t stream, int shape)
 {
     if (ntasks == 0 || nbatch == 0) return GPRN_OK;
     if (!stream) stream = c->stream;
     prof_begin(c, fam, stream);
-    dim3 grid((unsigned)ntasks, (unsigned)nbatch);
     // Bulk launches on the look-ahead stream ask for 16 KiB of unused dynamic LDS on top of the
     // 72 KiB image: one workgroup per CU instead of two.  Workgroups are never preempted and stream
     // priorities do not reorder dispatch, so this is what keeps half of every CU's LDS and wave
@@ -152,8 +163,24 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     static int pad_kb = -1;
     if (pad_kb < 0) { const char* e = getenv("GPRN_BULK_PAD_KB"); pad_kb = e ? atoi(e) : 16; }
     const size_t dyn = (stream == c->stream2) ? (size_t)pad_kb * 1024 : 0;
-    hipLaunchKernelGGL(k_tile_gemm, grid, dim3(256), dyn, stream, d_tasks,
-                       (double* const*)d_ptrs, ld);
+    double* const* tab = (double* const*)d_ptrs;
+    switch (shape) {
+    case TS_64x64:
+        hipLaunchKernelGGL((k_tile_gemm<64, 64>), dim3((unsigned)ntasks * 4, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld);
+        break;
+    case TS_64x128:
+        hipLaunchKernelGGL((k_tile_gemm<64, 128>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld);
+        break;
+    case TS_128x64:
+        hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld);
+        break;
+    default:
+        hipLaunchKernelGGL((k_tile_gemm<128, 128>), dim3((unsigned)ntasks, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld);
+    }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

@@ -130,7 +130,7 @@ struct gprn_ctx {
     TileTask* d_tasks = nullptr;
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
-    struct StepRange { size_t panel0, npanel, upd0, nupd; };   // per tile step: panel, in-panel update
+    struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
     std::vector<StepRange> steps;    // T entries
     struct OuterRange { int k0, k1; size_t next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
     std::vector<OuterRange> outers;
@@ -143,8 +143,10 @@ void prof_begin(gprn_ctx* c, int fam, hipStream_t stream = nullptr);   // nullpt
 void prof_end(gprn_ctx* c);
 
 int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K);
+// workgroup output shape of a tile launch (csrc/gemm_tile.hip)
+enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream = nullptr);
+                 int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info);
 // factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
 int factor_invert(gprn_ctx* c, int nbatch);

@@ -142,7 +142,8 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
 /* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----
  * C (+)= A.B on host matrices through the MFMA tile kernel; modes as in
  * csrc/gemm_tile.hip (a_mode 0: A[m][k], 1: A[k][m]; b_mode 0: B[n][k], 1: B[k][n];
- * c_mode 0: C=AB, 1: C-=AB, 2: C=-AB).  M, N multiples of 128; K multiple of 16. */
+ * c_mode 0: C=AB, 1: C-=AB, 2: C=-AB; bits 4-5 of c_mode pick the workgroup shape 128x128, 64x64,
+ * 64x128, 128x64).  M, N multiples of 128; K multiple of 16. */
 int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
                    int c_mode, const double* A, const double* B, double* C);
 /* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */

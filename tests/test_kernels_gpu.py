@@ -29,6 +29,19 @@ def test_tile_gemm_layouts(ctx, a_mode, b_mode, c_mode):
     assert np.array_equal(out, want)
 
 
+@pytest.mark.parametrize('shape', [1, 2, 3])
+@pytest.mark.parametrize('a_mode,b_mode', [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_tile_gemm_small_workgroup_shapes(ctx, shape, a_mode, b_mode):
+    # the 64x64 / 64x128 / 128x64 cuts of a 128x128 task (latency-bound launches)
+    rng = np.random.RandomState(50 + 16 * shape + 4 * a_mode + 2 * b_mode)
+    M, N, K = 256, 384, 80
+    A = rng.randint(-4, 5, size=(M, K)).astype(float)
+    B = rng.randint(-4, 5, size=(K, N)).astype(float)
+    C0 = rng.randint(-9, 10, size=(M, N)).astype(float)
+    out = ctx.test_gemm(A, B, C0, a_mode, b_mode, 1 | (shape << 4))
+    assert np.array_equal(out, C0 - A @ B)
+
+
 def test_tile_gemm_random_fp64(ctx):
     rng = np.random.RandomState(1)
     A = rng.standard_normal((384, 512))
