@@ -58,6 +58,7 @@ SIGNATURES = {
     'gprn_test_gemm': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
+    'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
 }
 
 _lib = None
@@ -263,6 +264,13 @@ class Context:
         info = self._check(self._lib.gprn_test_factor_invert(self._h, n, batch, _ptr(A), _ptr(L), _ptr(X)),
                            'test_factor_invert')
         return L, X, info
+
+    def mfma_peak(self, wg_per_cu=1, iters=2000):
+        """Measured fp64 MFMA issue ceiling (TFLOP/s) of this device."""
+        v = c_double(0.0)
+        self._check(self._lib.gprn_test_mfma_peak(self._h, int(wg_per_cu), int(iters), byref(v)),
+                    'test_mfma_peak')
+        return v.value
 
     def test_lauum(self, X):
         X = _f64(X)

@@ -453,7 +453,9 @@ int factor_invert(gprn_ctx* c, int nbatch)
     // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
     // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.
     // In-place panel tasks may only be cut along the dimension they do not read across.
-    auto few = [&](size_t ntasks) { return ntasks * (size_t)nbatch <= 320; };
+    static size_t few_max = 0;                     // GPRN_FEW_TASKS overrides (experiments)
+    if (!few_max) { const char* e = getenv("GPRN_FEW_TASKS"); few_max = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
+    auto few = [&](size_t ntasks) { return ntasks * (size_t)nbatch <= few_max; };
     for (size_t J = 0; J < c->outers.size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[J];
         for (int k = o.k0; k < o.k1; ++k) {            // the latency chain of this panel

@@ -108,6 +108,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
 
+    // (a two-chunk-deep register prefetch measured no gain: the loads are not the limiter)
     for (int c = 0; c < nchunks; ++c) {
         double* sA = lds + (c & 1) * (A_DOUBLES + B_DOUBLES);
         double* sB = sA + A_DOUBLES;
@@ -183,5 +184,51 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// ---- diagnostic: the fp64 MFMA issue ceiling of this device ------------------------------
+// Every wave issues `iters` x 16 independent v_mfma_f64_16x16x4_f64 back to back from
+// registers (no memory traffic); 4 waves per workgroup, `wg_per_cu` workgroups per CU.
+__global__ __launch_bounds__(256, 2)
+void k_mfma_peak(double* __restrict__ out, int iters)
+{
+    v4d acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        a += 1e-12;
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+extern "C" int gprn_test_mfma_peak(gprn_ctx* c, int wg_per_cu, int iters, double* tflops)
+{
+    if (!c || wg_per_cu < 1 || iters < 1 || !tflops) return GPRN_E_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    const int nwg = prop.multiProcessorCount * wg_per_cu;
+    double* d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)nwg * 256 * sizeof(double)));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(nwg), dim3(256), 0, c->stream, d, iters);   // warm-up
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_mfma_peak, dim3(nwg), dim3(256), 0, c->stream, d, iters);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
+    *tflops = (double)nwg * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
     return GPRN_OK;
 }

@@ -149,6 +149,9 @@ int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
 /* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */
 int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
                             double* L, double* Linv);
+/* back-to-back v_mfma_f64_16x16x4_f64 from registers on every CU: the measured fp64 MFMA
+ * ceiling of this device in TFLOP/s (what roofline fractions can be judged against) */
+int gprn_test_mfma_peak(gprn_ctx* ctx, int wg_per_cu, int iters, double* tflops);
 /* out = lower(X^T X) for lower-triangular X */
 int gprn_test_lauum(gprn_ctx* ctx, int n, const double* X, double* out);
 
