@@ -30,21 +30,34 @@ TILE = 128
 
 
 def update_flops(T, n_gp, outer=4):
-    """Algorithmic flops of the `update` launches (the K = 512 bulk updates of the
-    two-level factorisation, csrc/factor.hip: trailing SYRK + right-hand-side rows
-    of the inverse outside the current panel), per sweep, for n_gp latent GPs.
-    Diagonal SYRK tiles count their lower triangle only."""
+    """Algorithmic flops of the bulk-update launches of one sweep for n_gp latent GPs: the
+    K = 512 `k_tile_gemm<128,128>` launches on the look-ahead stream (csrc/factor.hip, the
+    "rest" half of each outer update: trailing SYRK tiles and inverse rows beyond the next
+    panel).  Diagonal SYRK tiles count their lower triangle only."""
     per_gp = 0.0
     for k0 in range(0, T, outer):
         k1 = min(T, k0 + outer)
+        n1 = min(T, k1 + outer)
         kw = (k1 - k0) * TILE
-        for i in range(k1, T):
-            per_gp += (i - k1) * 2.0 * TILE * TILE * kw            # B_ij, j < i
+        for i in range(n1, T):
+            per_gp += (i - n1) * 2.0 * TILE * TILE * kw            # B_ij, n1 <= j < i
             per_gp += 2.0 * (TILE * (TILE + 1) / 2) * kw           # B_ii
             per_gp += k0 * 2.0 * TILE * TILE * kw                  # R_ic, c < k0
             for c in range(k0, k1):
                 per_gp += 2.0 * TILE * TILE * (k1 - c) * TILE      # R_ic, first touch
     return per_gp * n_gp
+
+
+def pmc_traffic():
+    """HBM bytes per bulk-update launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    coalesced reads on gfx950).  Produced by profiles/summarize_pmc.py; None if absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_bulk_update.json')
+    try:
+        with open(path) as f:
+            return json.load(f)['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def sweep_flops(N, p, q):
@@ -141,11 +154,12 @@ def main():
             'setup_s': t_setup,
             'elbo_last': float(elbo[-1]), 'info': int(info),
             'roofline': {
-                'kernel': 'k_tile_gemm (bulk update launches, K=512: trailing SYRK + inverse rows, v_mfma_f64_16x16x4_f64)',
+                'kernel': 'k_tile_gemm<128,128> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,
-                'traffic': None,
+                'traffic': pmc_traffic() if world == 1 and a.config == 3 else None,
+                'measured_mfma_ceiling': ctx.mfma_peak(2, 4000),
                 'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
                 'flops_per_launch': (fl / n_upd) if n_upd else None,
             },

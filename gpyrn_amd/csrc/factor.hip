@@ -476,7 +476,7 @@ int factor_invert(gprn_ctx* c, int nbatch)
         if (rest_pending)                              // same tiles as the previous panel's rest
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
         if ((rc = launch_tiles(c, c->d_tasks + o.next0, o.nnext, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_UPDATE, nullptr, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
+                               GPRN_T_PANEL, nullptr, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
         if (o.nrest) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
             if ((rc = launch_tiles(c, c->d_tasks + o.rest0, o.nrest, c->d_ptrs, nbatch, c->ld,
