@@ -282,6 +282,8 @@ if __name__ == '__main__':
         cases += [
             ('cfg2_N2048', 2048, 1, 1, 'QP', False, 3, False, False),
             ('cfg3_N4096', 4096, 3, 2, 'QP', False, 2, False, False),
+            # BASELINE config 4 (16 latent GPs, four nodes: the cumulative-trace quirk at full size)
+            ('cfg4_N4096_q4', 4096, 3, 4, 'QP', False, 1, False, False),
         ]
     for c in cases:
         if want(c[0]):

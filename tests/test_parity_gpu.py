@@ -65,7 +65,7 @@ SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3']
 MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1']
 
 
-@pytest.mark.parametrize('tag', SMALL + MID + ['cfg2_N2048', 'cfg3_N4096'])
+@pytest.mark.parametrize('tag', SMALL + MID + ['cfg2_N2048', 'cfg3_N4096', 'cfg4_N4096_q4'])
 def test_forced_sweeps_match_reference(tag):
     if not _cases.available(tag):
         pytest.skip('fixture not generated')
