@@ -148,6 +148,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
         delete c;
@@ -173,6 +174,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     hipStreamSynchronize(c->stream2);
     hipEventDestroy(c->ev_panel);
     hipEventDestroy(c->ev_rest);
+    hipEventDestroy(c->ev_next);
     hipEventDestroy(c->ev_nodes);
     hipEventDestroy(c->ev_q1);
     hipStreamDestroy(c->stream2);

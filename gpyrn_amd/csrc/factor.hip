@@ -460,20 +460,21 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
             s.nupd = v.size() - s.upd0;
         }
-        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0};
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
-        for (int pass = 0; pass < 2; ++pass) {         // 0: what the next panel needs, 1: the rest
+        // pass 0: the next panel's first column of B / first row of R (what its first tile step
+        // needs); pass 1: the rest of the next panel's columns / rows; pass 2: everything else
+        for (int pass = 0; pass < 3; ++pass) {
             const size_t begin = v.size();
+            auto cls = [&](int t) { return t == k1 ? 0 : (t < n1 ? 1 : 2); };
             for (int i = k1; i < T; ++i) {
                 for (int j = k1; j <= i; ++j) {
-                    const bool next = j < n1;
-                    if (next != (pass == 0)) continue;
+                    if (cls(j) != pass) continue;
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k0, ld), toff(j, k0, ld), kw,
                                          BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
                 }
-                const bool next = i < n1;
-                if (next != (pass == 0)) continue;
+                if (cls(i) != pass) continue;
                 for (int cc = 0; cc < k0; ++cc)
                     v.push_back(TileTask{toff(i, cc, ld), toff(i, k0, ld), toff(k0, cc, ld), kw,
                                          BUF_X, BUF_B, BUF_X, tile_modes(CM_SUB, 0, 1)});
@@ -482,12 +483,12 @@ int ensure_tasks(gprn_ctx* c)
                                          (k1 - cc) * GPRN_TILE, BUF_X, BUF_B, BUF_X,
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
-            if (pass == 0) { o.next0 = begin; o.nnext = v.size() - begin; }
+            if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
+            else if (pass == 1) { o.next0 = begin; o.nnext = v.size() - begin; }
             else {
                 // Workgroups are dispatched in task order and are not preempted: with the short
                 // first-touch tasks (K = 128..384) in front, the first slots free up after a
-                // quarter of a full task instead of all at once, so the next panel's small,
-                // higher-priority kernels get onto the CUs early.
+                // quarter of a full task instead of all at once.
                 std::stable_sort(v.begin() + begin, v.end(),
                                  [](const TileTask& a, const TileTask& b) { return a.klen < b.klen; });
                 o.rest0 = begin; o.nrest = v.size() - begin;
@@ -521,7 +522,7 @@ int factor_invert(gprn_ctx* c, int nbatch)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
-    bool rest_pending = false;
+    bool rest_pending = false, next_pending = false;
     // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
     // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.
     // In-place panel tasks may only be cut along the dimension they do not read across.
@@ -540,23 +541,36 @@ int factor_invert(gprn_ctx* c, int nbatch)
                                        c->d_ptrs, nbatch, c->ld, GPRN_T_PANEL, nullptr, TS_128x64))) return rc;
             } else if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
                                           GPRN_T_PANEL))) return rc;
+            if (next_pending) {                        // the other columns / rows of this panel
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_next, 0));
+                next_pending = false;
+            }
             if ((rc = launch_tiles(c, c->d_tasks + s.upd0, s.nupd, c->d_ptrs, nbatch, c->ld,
                                    GPRN_T_PANEL, nullptr, few(s.nupd) ? TS_64x64 : TS_128x128))) return rc;
         }
-        if (o.nnext + o.nrest == 0) continue;
+        if (o.nfirst + o.nnext + o.nrest == 0) continue;
+        // Outer update of panel J.  On the chain stream only what the next panel's first tile step
+        // needs (its first column of B, first row of R); the rest of the next panel and everything
+        // beyond go to the second stream, which the chain joins before its first in-panel update
+        // (the first kernel that touches those tiles again).
         HIP_TRY(c, hipEventRecord(c->ev_panel, c->stream));
         if (rest_pending)                              // same tiles as the previous panel's rest
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
+        if ((rc = launch_tiles(c, c->d_tasks + o.first0, o.nfirst, c->d_ptrs, nbatch, c->ld,
+                               GPRN_T_PANEL, nullptr, few(o.nfirst) ? TS_64x64 : TS_128x128))) return rc;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
         if ((rc = launch_tiles(c, c->d_tasks + o.next0, o.nnext, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_PANEL, nullptr, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
+                               GPRN_T_PANEL, c->stream2, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_next, c->stream2));
+        next_pending = o.nnext > 0;
         if (o.nrest) {
-            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
             if ((rc = launch_tiles(c, c->d_tasks + o.rest0, o.nrest, c->d_ptrs, nbatch, c->ld,
                                    GPRN_T_UPDATE, c->stream2))) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_rest, c->stream2));
             rest_pending = true;
         }
     }
+    if (next_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_next, 0));
     if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
     return GPRN_OK;
 }

@@ -71,7 +71,7 @@ struct gprn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
-    hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
     hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;
@@ -132,7 +132,7 @@ struct gprn_ctx {
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
     std::vector<StepRange> steps;    // T entries
-    struct OuterRange { int k0, k1; size_t next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
+    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
     std::vector<OuterRange> outers;
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
