@@ -104,29 +104,40 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const int nchunks = t.klen / GPRN_KC;
     // (de-phasing co-resident workgroups by half a chunk measured no gain; PMC: MFMA pipe busy 78 %
     // of the cycles at an effective 2.13 GHz, no LDS bank conflicts -- DESIGN.md section 8)
+    // Software pipeline over K-chunks, one barrier per chunk:
+    //   registers hold chunk c+1 (requested during chunk c-1 ... c), LDS stage c&1 holds chunk c.
+    //   While chunk c is multiplied, chunk c+1 is written to the other LDS stage after the second
+    //   of the four k4-steps (its global loads have had >2000 cycles), and chunk c+2 is requested.
+    //   The barrier at the end of the chunk publishes stage (c+1)&1 and retires the reads of c&1.
+    // The LDS staging therefore overlaps the MFMA stream instead of sitting between two chunks.
     v2d ra[A_IT], rb[B_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
-
-    // (a two-chunk-deep register prefetch measured no gain: the loads are not the limiter)
-    for (int c = 0; c < nchunks; ++c) {
-        double* sA = lds + (c & 1) * (A_DOUBLES + B_DOUBLES);
+    {
+        double* sA = lds;
         double* sB = sA + A_DOUBLES;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it] * a_sign;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
-        __syncthreads();
-        if (c + 1 < nchunks) {
-            A += a_step;
-            B += b_step;
+    }
+    if (nchunks > 1) {
+        A += a_step;
+        B += b_step;
 #pragma unroll
-            for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
+        for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
 #pragma unroll
-            for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
-        }
+        for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
+    }
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const double* sA = lds + (c & 1) * (A_DOUBLES + B_DOUBLES);
+        const double* sB = sA + A_DOUBLES;
+        double* nA = lds + ((c + 1) & 1) * (A_DOUBLES + B_DOUBLES);
+        double* nB = nA + A_DOUBLES;
 #pragma unroll
         for (int ks = 0; ks < GPRN_KC / 4; ++ks) {
             double af[MI], bf[NI];
@@ -139,7 +150,24 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (ks == 1 && c + 1 < nchunks) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) *reinterpret_cast<v2d*>(nA + a_l[it]) = ra[it] * a_sign;
+#pragma unroll
+                for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v2d*>(nB + b_l[it]) = rb[it];
+                if (c + 2 < nchunks) {
+                    A += a_step;
+                    B += b_step;
+#pragma unroll
+                    for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
+#pragma unroll
+                    for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        __syncthreads();
     }
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
