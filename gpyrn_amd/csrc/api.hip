@@ -655,7 +655,6 @@ static int run_phase(gprn_ctx* c, bool weights)
     const size_t o = (size_t)c->slot0 * c->ld;
     if (ns) {
         TRY(vec_prep(c, weights, slotgp, ns));
-        TRY(vec_matvec_z(c, ns));
         TRY(vec_build_B(c, ns));
         TRY(factor_invert(c, ns));
         TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));

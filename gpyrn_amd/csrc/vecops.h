@@ -3,7 +3,6 @@
 #include "gprn_internal.h"
 
 int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots);
-int vec_matvec_z(gprn_ctx* c, int nslots);
 int vec_build_B(gprn_ctx* c, int nslots);
 int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* out);
 int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, int vin_by_gp,

@@ -2,8 +2,7 @@
 // (meanfield.py:651-710) that is not an N^3 contraction.  All batched over the
 // latent GPs of a phase ("slots") through grid.y / grid.z; HBM-bound.
 //
-//   k_prep_nodes / k_prep_weights   d, sqrt(d), right-hand side   meanfield.py:759-791, 838-864
-//   k_matvec_z                      z = s * (K pred)
+//   k_prep_nodes / k_prep_weights   d, sqrt(d), right-hand side, q = rhs/sqrt(d)   meanfield.py:759-791, 838-864
 //   k_build_B                       B = I + D^1/2 K D^1/2 (lower tiles)
 //   k_logdet                        2 sum log diag(L)             meanfield.py:1029,1062,1088,1091
 //   k_lower_matvec                  y = M v, M lower triangular
@@ -43,7 +42,8 @@ __global__ __launch_bounds__(256)
 void k_prep_nodes(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                   const double* __restrict__ mu, const double* __restrict__ var,
                   const double* __restrict__ yres, const double* __restrict__ variance,
-                  double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred)
+                  double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred,
+                  double* __restrict__ z)
 {
     const int slot = blockIdx.y, j = slot_gp[slot];
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -67,13 +67,15 @@ void k_prep_nodes(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
     d[o] = dsum;
     s[o] = sqrt(dsum);
     pred[o] = psum;
+    z[o] = psum / sqrt(dsum);           // q = D^-1/2 pred: Sigma pred = D^-1/2 (q - X^T X q)
 }
 
 __global__ __launch_bounds__(256)
 void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                     const double* __restrict__ mu, const double* __restrict__ var,
                     const double* __restrict__ yres, const double* __restrict__ variance,
-                    double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred)
+                    double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred,
+                    double* __restrict__ z)
 {
     const int slot = blockIdx.y, kk = slot_gp[slot] - q;
     const int j = kk / p, i = kk % p;
@@ -94,29 +96,7 @@ void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q
     d[o] = dv;
     s[o] = sqrt(dv);
     pred[o] = pv;
-}
-
-// z[m] = s[m] * sum_n K[m][n] pred[n]; one wave per row
-__global__ __launch_bounds__(256)
-void k_matvec_z(double* const* __restrict__ ptrs, int N, int ld,
-                const double* __restrict__ s, const double* __restrict__ pred,
-                double* __restrict__ z)
-{
-    const int slot = blockIdx.y;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= ld) return;
-    const double* K = ptrs[(size_t)slot * GPRN_NBUF + BUF_K] + (size_t)m * ld;
-    const double* v = pred + (size_t)slot * ld;
-    double acc = 0.0;
-    if (m < N) {
-        for (int n = 2 * lane; n < N; n += 128) {       // N even or odd: guard the tail
-            const v2d kv = *reinterpret_cast<const v2d*>(K + n);
-            acc += kv.x * v[n];
-            if (n + 1 < N) acc += kv.y * v[n + 1];
-        }
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) z[(size_t)slot * ld + m] = (m < N) ? s[(size_t)slot * ld + m] * acc : 0.0;
+    z[o] = pv / sqrt(dv);
 }
 
 // B = I + D^1/2 K D^1/2 on the lower tiles (diagonal tiles in full); identity padding
@@ -231,12 +211,13 @@ void k_colops_reduce(int ld, int T, const double* __restrict__ part,
     ct[(size_t)slot * ld + c] = b;
 }
 
-// new mu = (X^T X z)/s, new var = (1 - diag B^-1)/d into the state rows of the GP;
+// new mu = Sigma pred = (q - X^T X q)/s  (q = pred/s: no product with K needed),
+// new var = (1 - diag B^-1)/d into the state rows of the GP;
 // trBinv[gp] = sum diag B^-1
 __global__ __launch_bounds__(256)
 void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                 const double* __restrict__ d, const double* __restrict__ s,
-                const double* __restrict__ cs, const double* __restrict__ ct,
+                const double* __restrict__ z, const double* __restrict__ cs, const double* __restrict__ ct,
                 double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv)
 {
     __shared__ double sh[4];
@@ -249,7 +230,7 @@ void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
         const size_t o = (size_t)slot * ld + n;
         const double binv = cs[o];
         tr += binv;
-        mu[row * N + n] = ct[o] / s[o];
+        mu[row * N + n] = (z[o] - ct[o]) / s[o];
         var[row * N + n] = (1.0 - binv) / d[o];
     }
     tr = block_sum(tr, sh);
@@ -365,21 +346,11 @@ int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots)
     if (weights)
         hipLaunchKernelGGL(k_prep_weights, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d + o, c->d_s + o, c->d_pred + o);
+                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o);
     else
         hipLaunchKernelGGL(k_prep_nodes, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d + o, c->d_s + o, c->d_pred + o);
-    LAUNCH_END(c);
-}
-
-int vec_matvec_z(gprn_ctx* c, int nslots)
-{
-    if (!nslots) return GPRN_OK;
-    prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_matvec_z, dim3(c->ld / 4, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld,
-                       c->d_pred + (size_t)c->slot0 * c->ld, c->d_z + (size_t)c->slot0 * c->ld);
+                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o);
     LAUNCH_END(c);
 }
 
@@ -430,7 +401,7 @@ int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots)
     prof_begin(c, GPRN_T_VEC);
     const size_t o = (size_t)c->slot0 * c->ld;
     hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
-                       c->p, c->q, c->d_d + o, c->d_s + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
+                       c->p, c->q, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
                        c->d_trBinv);
     LAUNCH_END(c);
 }

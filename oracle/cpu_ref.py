@@ -12,7 +12,7 @@ Two restatements of one sweep (= one `ELBOaux` call, meanfield.py:651-710):
   7 N^3 flop per latent GP.  This is what bench.py times as `cpu_baseline`.
 * form "B"    -- the algebra the HIP path executes: B = I + D^1/2 K D^1/2 =
   L L^T, X = L^-1; diag Sigma = (1 - colnorm2(X)) / d, log det Sigma =
-  log det K - log det B, tr(K^-1 Sigma) = tr(B^-1), Sigma v = D^-1/2 X^T X D^1/2 K v.
+  log det K - log det B, tr(K^-1 Sigma) = tr(B^-1), Sigma v = D^-1/2 (q - X^T X q), q = D^-1/2 v.
   2/3 N^3 per GP (+1/3 N^3 for the cumulative-trace quirk Q1 when q >= 2).
 
 Pinned against tests/golden/*.npz, which oracle/gen_golden.py produced by
@@ -169,8 +169,8 @@ def _gp_update_B(K, d, pred, need_inverse=False):
     L = np.linalg.cholesky(B)
     X = solve_triangular(L, np.eye(L.shape[0]), lower=True)
     binv_diag = np.sum(X * X, axis=0)
-    z = s * (K @ pred)
-    sig_pred = (X.T @ (X @ z)) / s
+    q = pred / s                          # Sigma pred = D^-1/2 (I - B^-1) D^-1/2 pred
+    sig_pred = (q - X.T @ (X @ q)) / s
     logdetB = 2.0 * np.sum(np.log(np.diag(L)))
     Binv = X.T @ X if need_inverse else None
     return (1.0 - binv_diag) / d, sig_pred, logdetB, np.sum(binv_diag), Binv, s
