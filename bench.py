@@ -146,6 +146,13 @@ def main():
             times.append(ctx.barrier_max(time.perf_counter() - t0))
             trips.append(it)
         calc = {'elbocalc_per_s': 1.0 / min(times), 'ms': 1e3 * min(times), 'loop_trips': trips[-1]}
+        if world == 1:
+            # GPRN prediction at 1000 new times from the converged state
+            # (8 x {fill, chol + inverse, K* fill, X K*^T} on the device + the O(pqN*) mix on the host)
+            g.predict(nn=1000)
+            t0 = time.perf_counter()
+            g.predict(nn=1000)
+            calc['predict_1000_ms'] = 1e3 * (time.perf_counter() - t0)
 
     if rank == 0:
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)

@@ -50,6 +50,7 @@ SIGNATURES = {
     'gprn_set_muvar': (c_int, [c_void_p, _dp, _dp]),
     'gprn_get_muvar': (c_int, [c_void_p, _dp, _dp]),
     'gprn_sweep': (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
+    'gprn_predict': (c_int, [c_void_p, c_int, _dp, _dp, _dp]),
     'gprn_keep_sigma': (c_int, [c_void_p, c_int]),
     'gprn_get_matrix': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_get_logdet_K': (c_int, [c_void_p, _dp]),
@@ -216,6 +217,16 @@ class Context:
         info = self._check(self._lib.gprn_sweep(self._h, int(n), int(bool(commit)),
                                                 _ptr(elbo), _ptr(parts)), 'sweep')
         return elbo, parts, info
+
+    def predict(self, tstar):
+        """Conditional mean / variance of every latent GP at `tstar`: two (G, n*) arrays
+        (rows of GPs owned by other ranks stay zero) and the LAPACK-style info."""
+        ts = _f64(np.ravel(tstar))
+        mean = np.zeros((self.G, ts.size))
+        var = np.zeros((self.G, ts.size))
+        info = self._check(self._lib.gprn_predict(self._h, ts.size, _ptr(ts), _ptr(mean), _ptr(var)),
+                           'predict')
+        return mean, var, info
 
     def keep_sigma(self, on=True):
         self._check(self._lib.gprn_keep_sigma(self._h, int(bool(on))), 'keep_sigma')

@@ -111,6 +111,10 @@ static void free_problem(gprn_ctx* c)
     for (auto& p : c->wsX) dev_free(p);
     c->K.clear(); c->KLinv.clear(); c->Kinv.clear(); c->Sig.clear(); c->wsB.clear(); c->wsX.clear();
     dev_free(c->d_logdetK);
+    for (auto& p : c->predKs) dev_free(p);
+    for (auto& p : c->predWT) dev_free(p);
+    c->predKs.clear(); c->predWT.clear(); c->pred_cap = 0;
+    dev_free(c->tab_pred); dev_free(c->d_slotgp_all);
     dev_free(c->tab_node); dev_free(c->tab_weight); dev_free(c->tab_setup);
     dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
     dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
@@ -785,6 +789,113 @@ extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
     return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ prediction
+// Conditional mean / variance of every latent GP at new times, from the current variational
+// state: replaces _gp.GP.prediction (_gp.py:107-138) as called by inference._Prediction
+// (meanfield.py:1289-1381): cov = K + 1.25e-12 I + diag(var), sol = cov^-1 mu,
+// mean* = K* sol, var*_i = k(t*_i,t*_i) + 1.25e-12 - |L^-1 K*_i|^2.  Here: fused fills,
+// the blocked factor+inverse (X = L^-1), sol = X^T X mu, W^T = K* X^T by the tile kernel.
+extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
+{
+    if (!c || !c->N || ns <= 0 || !tstar || !mean_out || !var_out) return bad(c, "predict: bad argument");
+    if (!c->have_muvar) return bad(c, "predict: set_muvar (or a sweep) first");
+    if (c->owner.empty()) return bad(c, "predict: call set_owners first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(build_tables(c));
+    std::vector<int> gps = c->loc_nodes;
+    gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
+    const int nloc = (int)gps.size();
+    if (!nloc) return GPRN_OK;
+    for (int g : gps)
+        if (!c->kspec[g].set || c->kspec[g].uploaded)
+            return bad(c, "predict: needs device-evaluable kernels (host-uploaded K has no K*)");
+    const int ld = c->ld, N = c->N, T = c->T;
+    const int ns_pad = ((ns + GPRN_TILE - 1) / GPRN_TILE) * GPRN_TILE;
+    const size_t need = (size_t)ns_pad * ld;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->predKs.size() != (size_t)c->nslot || c->pred_cap < need) {
+        for (auto& p : c->predKs) dev_free(p);
+        for (auto& p : c->predWT) dev_free(p);
+        c->predKs.assign(c->nslot, nullptr); c->predWT.assign(c->nslot, nullptr);
+        for (int s = 0; s < c->nslot; ++s) {
+            TRY(dev_alloc(c, &c->predKs[s], need));
+            TRY(dev_alloc(c, &c->predWT[s], need));
+        }
+        c->pred_cap = need;
+        dev_free(c->tab_pred); dev_free(c->d_slotgp_all);
+        TRY(dev_alloc(c, &c->tab_pred, (size_t)c->nslot * GPRN_NBUF));
+        TRY(dev_alloc(c, &c->d_slotgp_all, c->nslot));
+    }
+    double *d_ts = nullptr, *d_kss = nullptr, *d_mean = nullptr, *d_pvar = nullptr;
+    TileTask* d_t = nullptr;
+    int rc = GPRN_OK, first = 0;
+    std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
+    std::vector<int> staterow(nloc);
+    std::vector<TileTask> tasks;
+    std::vector<double> hm, hv;
+    auto row_of = [&](int g) {
+        if (g < c->q) return g;
+        const int kk = g - c->q, j = kk / c->p, i = kk % c->p;
+        return (1 + i) * c->q + j;
+    };
+#define PTRY(expr) do { rc = (expr); if (rc) goto done; } while (0)
+#define PHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); rc = GPRN_E_HIP; goto done; } } while (0)
+    PTRY(dev_alloc(c, &d_ts, ns));
+    PTRY(dev_alloc(c, &d_kss, (size_t)nloc * ns_pad));
+    PTRY(dev_alloc(c, &d_mean, (size_t)nloc * ns_pad));
+    PTRY(dev_alloc(c, &d_pvar, (size_t)nloc * ns_pad));
+    PHIP(hipMemcpy(d_ts, tstar, ns * sizeof(double), hipMemcpyHostToDevice));
+    for (int s = 0; s < nloc; ++s) {
+        rows[(size_t)s * GPRN_NBUF + BUF_B] = c->wsB[s];
+        rows[(size_t)s * GPRN_NBUF + BUF_X] = c->wsX[s];
+        rows[(size_t)s * GPRN_NBUF + BUF_K] = c->predKs[s];
+        rows[(size_t)s * GPRN_NBUF + BUF_KLINV] = c->predWT[s];
+        staterow[s] = row_of(gps[s]);
+    }
+    PTRY(upload_table(c, c->tab_pred, rows));
+    PHIP(hipMemcpy(c->d_slotgp_all, staterow.data(), nloc * sizeof(int), hipMemcpyHostToDevice));
+    for (int s = 0; s < nloc; ++s) {
+        const KernelSpec& ks = c->kspec[gps[s]];
+        PTRY(launch_fill(c, ks, c->wsB[s], 1.25e-12, c->d_var + (size_t)staterow[s] * N));
+        PTRY(launch_fill_rect(c, ks, 1.25e-12, d_ts, ns, ns_pad, c->predKs[s], d_kss + (size_t)s * ns_pad));
+    }
+    PHIP(hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    c->d_ptrs = c->tab_pred;
+    c->slot0 = 0;
+    c->d_info_cur = c->d_info;
+    PTRY(factor_invert(c, nloc));
+    PTRY(vec_lower_matvec(c, BUF_X, c->d_mu, N, 1, c->d_slotgp_all, nloc, c->d_u));   // u = X mu
+    PTRY(vec_colops(c, nloc));                                                          // ct = X^T u
+    for (int bt = 0; bt < ns_pad / GPRN_TILE; ++bt)
+        for (int at = 0; at < T; ++at)
+            tasks.push_back(TileTask{(int64_t)bt * GPRN_TILE * ld + (int64_t)at * GPRN_TILE,
+                                     (int64_t)bt * GPRN_TILE * ld, (int64_t)at * GPRN_TILE * ld,
+                                     (at + 1) * GPRN_TILE, BUF_KLINV, BUF_K, BUF_X,
+                                     tile_modes(CM_SET, 0, 0)});
+    PTRY(dev_alloc(c, &d_t, tasks.size()));
+    PHIP(hipMemcpyAsync(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, c->stream));
+    PTRY(launch_tiles(c, d_t, tasks.size(), c->d_ptrs, nloc, ld, GPRN_T_UPDATE));
+    PTRY(vec_pred_rows(c, nloc, ns, ns_pad, c->d_ct, d_kss, d_mean, d_pvar));
+    hm.resize((size_t)nloc * ns_pad); hv.resize((size_t)nloc * ns_pad);
+    PHIP(hipMemcpyAsync(hm.data(), d_mean, hm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PHIP(hipMemcpyAsync(hv.data(), d_pvar, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PHIP(hipStreamSynchronize(c->stream));
+    for (int s = 0; s < nloc; ++s) {
+        memcpy(mean_out + (size_t)gps[s] * ns, &hm[(size_t)s * ns_pad], ns * sizeof(double));
+        memcpy(var_out + (size_t)gps[s] * ns, &hv[(size_t)s * ns_pad], ns * sizeof(double));
+    }
+    c->info_gp = -1;
+    rc = check_info(c, c->d_info, gps, &first);
+    if (!rc) rc = first;
+done:
+#undef PTRY
+#undef PHIP
+    hipStreamSynchronize(c->stream);
+    dev_free(d_ts); dev_free(d_kss); dev_free(d_mean); dev_free(d_pvar); dev_free(d_t);
+    c->factored = c->factored;      // the priors' factors live in K/KLinv, not in the workspaces
+    return rc;
 }
 
 // ------------------------------------------------------------------ diagnostics

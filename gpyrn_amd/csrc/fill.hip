@@ -17,6 +17,7 @@
 struct FillProgram {
     int n_ops;
     int nugget;
+    double nugget_val;        // 1e-6 (meanfield.py:433) for the priors, 1.25e-12 (_gp.py:47) for prediction
     int32_t ops[3 * GPRN_MAX_OPS];
     double par[GPRN_MAX_KPARAMS];
 };
@@ -161,7 +162,8 @@ __device__ __forceinline__ double eval_program(const FillProgram& pg, double ti,
 // 256 threads write 2 KiB contiguous.  Padded region (>= N) becomes identity so
 // the blocked factorisation can run on whole tiles.
 __global__ __launch_bounds__(256)
-void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld)
+void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld,
+            const double* __restrict__ diag_add)
 {
     const int n = blockIdx.x * 256 + threadIdx.x;
     const int m0 = blockIdx.y * 8;
@@ -175,7 +177,10 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
         if (m < N && n < N) {
             v = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, t[m], tn, m == n)
                                 : eval_program(pg, t[m], tn, m == n);
-            if (pg.nugget && m == n) v += 1e-6;
+            if (m == n) {
+                if (pg.nugget) v += pg.nugget_val;
+                if (diag_add) v += diag_add[m];
+            }
         } else {
             v = (m == n) ? 1.0 : 0.0;
         }
@@ -183,18 +188,68 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
     }
 }
 
-int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K)
+static void make_program(const KernelSpec& ks, double nugget_val, FillProgram& pg)
 {
-    FillProgram pg;
     pg.n_ops = ks.n_ops;
     pg.nugget = ks.nugget;
+    pg.nugget_val = nugget_val;
     for (int i = 0; i < 3 * ks.n_ops; ++i) pg.ops[i] = ks.ops[i];
     for (int i = 0; i < ks.n_params; ++i) pg.par[i] = ks.params[i];
     for (int i = ks.n_params; i < GPRN_MAX_KPARAMS; ++i) pg.par[i] = 0.0;
     for (int i = 3 * ks.n_ops; i < 3 * GPRN_MAX_OPS; ++i) pg.ops[i] = 0;
+}
+
+int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val, const double* diag_add)
+{
+    FillProgram pg;
+    make_program(ks, nugget_val, pg);
     prof_begin(c, GPRN_T_FILL);
     dim3 grid((c->ld + 255) / 256, (c->ld + 7) / 8);
-    hipLaunchKernelGGL(k_fill, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld);
+    hipLaunchKernelGGL(k_fill, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// Rectangular cross-covariance K*[i][n] = k(t*_i, t_n), no nugget (_gp.py:50-61, meanfield.py:455-471),
+// rows padded to a multiple of 128 with zeros; and the prior variance at the prediction points,
+// kss[i] = k(t*_i, t*_i) + nugget (the diagonal of _gp.py:40-48 evaluated at tstar).
+__global__ __launch_bounds__(256)
+void k_fill_rect(FillProgram pg, const double* __restrict__ ts, int ns, int ns_pad,
+                 const double* __restrict__ t, int N, int ld, double* __restrict__ Ks,
+                 double* __restrict__ kss)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * 8;
+    if (n >= ld) return;
+    const double tn = (n < N) ? t[n] : 0.0;
+#pragma unroll 1
+    for (int r = 0; r < 8; ++r) {
+        const int i = i0 + r;
+        if (i >= ns_pad) break;
+        double v = 0.0;
+        if (i < ns && n < N)
+            v = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, ts[i], tn, false)
+                                : eval_program(pg, ts[i], tn, false);
+        Ks[(size_t)i * ld + n] = v;
+        if (n == 0 && i < ns) {
+            double d = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, ts[i], ts[i], true)
+                                       : eval_program(pg, ts[i], ts[i], true);
+            if (pg.nugget) d += pg.nugget_val;
+            kss[i] = d;
+        }
+    }
+}
+
+int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const double* d_tstar,
+                     int ns, int ns_pad, double* Ks, double* kss)
+{
+    FillProgram pg;
+    make_program(ks, nugget_val, pg);
+    prof_begin(c, GPRN_T_FILL);
+    dim3 grid((c->ld + 255) / 256, (ns_pad + 7) / 8);
+    hipLaunchKernelGGL(k_fill_rect, grid, dim3(256), 0, c->stream, pg, d_tstar, ns, ns_pad, c->d_time,
+                       c->N, c->ld, Ks, kss);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

@@ -123,6 +123,11 @@ struct gprn_ctx {
     int out_cap = 0;
     int* d_info = nullptr;           // [3][nslot] first failing pivot per slot: setup, node phase, weight phase
     int* d_info_cur = nullptr;       // the row factor_invert writes to
+    // prediction scratch (gprn_predict): K* and (X K*^T)^T per local GP, [ns_pad x ld] each
+    std::vector<double*> predKs, predWT;
+    size_t pred_cap = 0;
+    double **tab_pred = nullptr;
+    int* d_slotgp_all = nullptr;
     // scratch of the diagnostic entry points
     double* d_test[3] = {nullptr, nullptr, nullptr};
     size_t test_cap[3] = {0, 0, 0};
@@ -142,7 +147,10 @@ struct gprn_ctx {
 void prof_begin(gprn_ctx* c, int fam, hipStream_t stream = nullptr);   // nullptr = ctx->stream
 void prof_end(gprn_ctx* c);
 
-int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K);
+int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val = 1e-6,
+                const double* diag_add = nullptr);
+int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const double* d_tstar,
+                     int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
 enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,

@@ -14,3 +14,5 @@ int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double
 int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out);
 int vec_elbo(gprn_ctx* c, double* out4);
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);
+int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,
+                  double* mean, double* var);

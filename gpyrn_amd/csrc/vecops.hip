@@ -453,3 +453,39 @@ int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out)
                        c->N, c->ld, out);
     LAUNCH_END(c);
 }
+
+// ---- prediction (gprn_predict): mean[i] = sum_n Ks[i][n] sol[n];  q[i] = sum_a WT[i][a]^2
+__global__ __launch_bounds__(256)
+void k_pred_rows(double* const* __restrict__ ptrs, int ns, int N, int ld, int ns_pad,
+                 const double* __restrict__ sol, const double* __restrict__ kss,
+                 double* __restrict__ mean, double* __restrict__ var)
+{
+    const int slot = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= ns) return;
+    const double* Ks = ptrs[(size_t)slot * GPRN_NBUF + BUF_K] + (size_t)i * ld;
+    const double* WT = ptrs[(size_t)slot * GPRN_NBUF + BUF_KLINV] + (size_t)i * ld;
+    const double* s = sol + (size_t)slot * ld;
+    double m = 0.0, q = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        m += Ks[n] * s[n];
+        const double w = WT[n];
+        q += w * w;
+    }
+    m = wave_sum(m);
+    q = wave_sum(q);
+    if (lane == 0) {
+        mean[(size_t)slot * ns_pad + i] = m;
+        var[(size_t)slot * ns_pad + i] = kss[(size_t)slot * ns_pad + i] - q;
+    }
+}
+
+int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,
+                  double* mean, double* var)
+{
+    if (!nslots) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_pred_rows, dim3((ns + 3) / 4, nslots), dim3(256), 0, c->stream,
+                       (double* const*)c->d_ptrs, ns, c->N, c->ld, ns_pad, sol, kss, mean, var);
+    LAUNCH_END(c);
+}

@@ -483,24 +483,150 @@ class inference:
         that parameter, '-name' all but it, a list optimises those named.
         """
         from scipy.optimize import minimize
-        if vars is not None:
-            if isinstance(vars, str):
-                if '-' in vars:
-                    self.thaw_parameter(name='*')
-                    self.freeze_parameter(name=vars.replace('-', ''))
-                else:
-                    self.freeze_parameter(name='*')
-                    self.thaw_parameter(name=vars)
-            elif isinstance(vars, list):
-                self.freeze_parameter(name='*')
-                for name in vars:
-                    self.thaw_parameter(name=name)
-            else:
-                raise ValueError(f'`vars` should be str or list, got {type(vars)}')
+        self._select_vars(vars)
         kwargs.setdefault('method', 'Nelder-Mead')
         res = minimize(self.nELBO, self.get_parameters(), **kwargs)
         self.set_parameters(res.x)
         return res
+
+
+    # ------------------------------------------------------------ prediction
+    def _Prediction(self, nodes=None, weights=None, means=None, jitters=None,
+                    tstar=None, mu=None, var=None, separate=False):
+        """
+        GPRN predictive mean and variance at `tstar` (default: the data times)
+        from variational means/variances `mu`, `var` (default: the converged
+        ones of the last ELBOcalc, else the `_initMuVar` start point) --
+        meanfield.py:1289-1381.  Every latent GP's conditional mean/variance
+        (the reference's `_gp.GP.prediction`, one Cholesky + N* solves each) is
+        computed on the GPU (`gprn_predict`); the O(p q N*) combination below is
+        the reference's, including the jitter added once per node.
+
+        Returns (mean (N*, p), variance (N*, p)) and, with `separate`, the
+        object array [node means (q, N*), weight means (q*p, N*)].
+        """
+        nodes, weights, means, jitters = self._get_components(nodes, weights, means, jitters)
+        tstar = self.time if tstar is None else np.atleast_1d(np.asarray(tstar, dtype=float))
+        if mu is None and var is None:
+            if self._mu is None and self._var is None:
+                mu, var = self._initMuVar(nodes, weights, jitters)
+            else:
+                mu, var = self._mu, self._var
+
+        specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
+        if any(sp[0] == 'host' for sp in specs):
+            raise NotImplementedError('prediction needs built-in kernels: a user-defined '
+                                      'covFunction has no device form of its cross-covariance')
+        ctx = self._backend()
+        if ctx.world > 1:
+            raise NotImplementedError('call predict on an unsharded inference object')
+        key = tuple(self._spec_key(sp) for sp in specs)
+        if key != self._prior_key:
+            for gp, sp in enumerate(specs):
+                self._send_spec(ctx, gp, sp)
+            self._prior_key = None             # the priors must be refactored before the next sweep
+        ctx.set_muvar(np.asarray(mu, dtype=float), np.asarray(var, dtype=float))
+        gmean, gvar, info = ctx.predict(tstar)
+        self.last_info = info
+
+        q, p = self.q, self.p
+        nPred, nVar = gmean[:q], gvar[:q]
+        wPred, wVar = gmean[q:], gvar[q:]
+        wP, wV = wPred.reshape(q, p, tstar.size), wVar.reshape(q, p, tstar.size)
+        meanVal = np.array(np.array_split(self._mean(means, tstar), p))
+        jitt2 = np.array(jitters)**2
+        predictives = np.zeros((tstar.size, p))
+        predictivesVar = np.zeros((tstar.size, p))
+        for i in range(p):
+            predictives[:, i] += meanVal[i]
+            for j in range(q):
+                predictives[:, i] += nPred[j] * wP[j, i]
+                predictivesVar[:, i] += wP[j, i] * wP[j, i] * nVar[j] \
+                    + wV[j, i] * (nVar[j] + nPred[j] * nPred[j]) + jitt2[i]
+        if separate:
+            return predictives, predictivesVar, np.array([nPred, wPred], dtype=object)
+        return predictives, predictivesVar
+
+    def predict(self, tstar=None, nn=1000):
+        """
+        GPRN prediction at `tstar`, or on `nn` points spanning the data padded by
+        20 % on each side (meanfield.py:1383-1400).  Returns (tstar, mean,
+        standard deviation, [node means, weight means]).
+        """
+        if tstar is None:
+            lo, hi = self.time.min(), self.time.max()
+            span = np.ptp(self.time)
+            tstar = np.linspace(lo - 0.2 * span, hi + 0.2 * span, nn)
+        mean, variance, parts = self._Prediction(tstar=tstar, separate=True)
+        return tstar, mean, np.sqrt(variance), parts
+
+    def mcmc(self, priors, p0=None, vars=None, niter=500, **kwargs):
+        """
+        Sample the posterior of the free parameters with emcee, the ELBO (100
+        sweeps at most, warm-started) standing in for the marginal likelihood
+        (meanfield.py:1154-1286).  `priors`: dict name -> frozen scipy.stats
+        distribution.  emcee is imported here, not at package import; without it
+        this raises ImportError.  Returns the sampler.
+        """
+        assert self._components_set, _NOT_SET
+        from emcee import EnsembleSampler
+        self._select_vars(vars)
+        names = np.array(list(self.parameters_dict.keys()))[~self.frozen_mask]
+
+        def draw():
+            return np.array([priors[n].rvs() for n in names])
+
+        def logprior(x):
+            return float(sum(priors[n].logpdf(v) for v, n in zip(x, names)))
+
+        def logposterior(x):
+            lp = logprior(x)
+            if np.isneginf(lp):
+                return -np.inf, -np.inf
+            elbo = -self.nELBO(x, max_iter=100)
+            return lp + elbo, elbo
+
+        ndim = len(names)
+        nwalkers = 2 * ndim
+        if p0 is None:
+            p0 = np.array([draw() for _ in range(nwalkers)])
+        else:
+            from emcee.utils import sample_ellipsoid
+            sigma = [priors[n].std() if callable(priors[n].std) else priors[n].std for n in names]
+            p0 = sample_ellipsoid(p0, np.diag(sigma) / 100, size=nwalkers)
+            for i, x in enumerate(p0):
+                if np.isneginf(logprior(x)):
+                    p0[i] = draw()
+        sampler = EnsembleSampler(nwalkers, ndim, logposterior, **kwargs)
+        old_tau = np.inf
+        for _ in sampler.sample(p0, iterations=niter, progress=False):
+            if sampler.iteration % 10:
+                continue
+            tau = sampler.get_autocorr_time(tol=0)
+            if np.all(tau * 100 < sampler.iteration) and \
+                    np.all(np.abs(old_tau - tau) / tau < 0.01):
+                break
+            old_tau = tau
+        return sampler
+
+    def _select_vars(self, vars):
+        """ Freeze/thaw by the `vars` convention shared by optimize and mcmc:
+        'name' frees only that parameter, '-name' all but it, a list frees those. """
+        if vars is None:
+            return
+        if isinstance(vars, str):
+            if '-' in vars:
+                self.thaw_parameter(name='*')
+                self.freeze_parameter(name=vars.replace('-', ''))
+            else:
+                self.freeze_parameter(name='*')
+                self.thaw_parameter(name=vars)
+        elif isinstance(vars, list):
+            self.freeze_parameter(name='*')
+            for name in vars:
+                self.thaw_parameter(name=name)
+        else:
+            raise ValueError(f'`vars` should be str or list, got {type(vars)}')
 
 
 def ctx_device(ctx):

@@ -120,6 +120,13 @@ int gprn_get_muvar(gprn_ctx* ctx, double* mu, double* var);
 int gprn_sweep(gprn_ctx* ctx, int n_sweeps, int commit,
                double* elbo_out, double* parts_out);
 
+/* ---- prediction: conditional mean and variance of every latent GP at `ns` new
+ * times from the current variational state (gprn_set_muvar or the last sweep): replaces
+ * _gp.GP.prediction (_gp.py:107-138) under inference._Prediction (meanfield.py:1289-1381).
+ * mean_out, var_out: (q + q*p, ns) row-major, row = latent GP index; rows of GPs owned by other
+ * ranks are left untouched.  Needs device-evaluable kernels (gprn_set_kernel). */
+int gprn_predict(gprn_ctx* ctx, int ns, const double* tstar, double* mean_out, double* var_out);
+
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */
 enum {
     GPRN_M_K = 0,        /* prior covariance K_gp (N,N) */

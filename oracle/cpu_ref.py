@@ -261,3 +261,43 @@ def elbo_calc(Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var,
             if crit < 1e-3 and crit != 0:
                 break
     return E, mu, var, it, np.array(hist)
+
+
+# --------------------------------------------------------- prediction
+def gp_prediction(kernel, time, tstar, m, v):
+    """_gp.GP.prediction (_gp.py:107-138): conditional mean/variance of one latent GP at tstar,
+    with the 1.25e-12 nugget of _gp.py:47 (one-argument kernels)."""
+    r = time[:, None] - time[None, :]
+    cov = kernel(r) + 1.25e-12 * np.eye(time.size) + np.diag(v)
+    L = np.linalg.cholesky(cov)
+    Ks = kernel(tstar[:, None] - time[None, :])
+    sol = cho_solve((L, True), m)
+    W = solve_triangular(L, Ks.T, lower=True)
+    kss = kernel(np.zeros(tstar.size)) + 1.25e-12
+    return Ks @ sol, kss - np.sum(W * W, axis=0)
+
+
+def prediction(time, tstar, nodes, weights, means, jitters, mu, var, p, q):
+    """inference._Prediction (meanfield.py:1289-1381); returns (mean (N*,p), var (N*,p), node
+    means (q,N*), weight means (q*p,N*))."""
+    N = time.size
+    muF, muW = split_u(mu, p, q, N)
+    varF, varW = split_u(var, p, q, N)
+    nP, nV, wP, wV = [], [], [], []
+    for j in range(q):
+        a, b = gp_prediction(nodes[j], time, tstar, muF[j], varF[j])
+        nP.append(a); nV.append(b)
+        for i in range(p):
+            a, b = gp_prediction(weights[j * p + i], time, tstar, muW[i, j], varW[i, j])
+            wP.append(a); wV.append(b)
+    nP, nV, wP, wV = map(np.array, (nP, nV, wP, wV))
+    wPq, wVq = wP.reshape(q, p, -1), wV.reshape(q, p, -1)
+    jitt2 = np.asarray(jitters, dtype=float) ** 2
+    mean = np.zeros((tstar.size, p))
+    variance = np.zeros((tstar.size, p))
+    for i in range(p):
+        mean[:, i] += np.zeros(tstar.size) if means[i] is None else means[i](tstar)
+        for j in range(q):
+            mean[:, i] += nP[j] * wPq[j, i]
+            variance[:, i] += wPq[j, i] ** 2 * nV[j] + wVq[j, i] * (nV[j] + nP[j] ** 2) + jitt2[i]
+    return mean, variance, nP, wP

@@ -227,6 +227,20 @@ def gen_step_case(tag, N, p, q, node_kind, nonzero_means, nsweeps, full_calc,
           % (tag, N, p, q, nsweeps, elbo[0], time.time() - t0))
 
 
+def gen_predict(tag, nstar=37):
+    """inference._Prediction (meanfield.py:1289-1381) on the state after the forced sweeps of `tag`."""
+    meta = json.load(open(os.path.join(OUT, tag + '.json')))
+    d = np.load(os.path.join(OUT, tag + '.npz'))
+    spec = (meta['nodes'], meta['weights'], meta['means'], meta['jitters'])
+    g, t, ys, es = make_ref(meta['N'], meta['p'], meta['q'], spec, meta['seed'])
+    span = t.max() - t.min()
+    tstar = np.linspace(t.min() - 0.2 * span, t.max() + 0.2 * span, nstar)
+    mean, var, sep = g._Prediction(tstar=tstar, mu=d['mu_final'], var=d['var_final'], separate=True)
+    np.savez_compressed(os.path.join(OUT, 'pred_' + tag + '.npz'), tstar=tstar, mean=mean, var=var,
+                        node_means=np.array(sep[0], dtype=float), weight_means=np.array(sep[1], dtype=float))
+    print('pred_%s: %d points, mean[0]=%s' % (tag, nstar, mean[0]))
+
+
 def gen_api():
     """Parameter plumbing contracts, meanfield.py:180-379."""
     spec = model_spec(2, 2, 'QP', True)
@@ -288,3 +302,6 @@ if __name__ == '__main__':
     for c in cases:
         if want(c[0]):
             gen_step_case(*c)
+    for tag in ('step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'):
+        if want('pred_' + tag):
+            gen_predict(tag)

@@ -63,3 +63,16 @@ def test_elbo_calc_trajectory(tag, form):
     np.testing.assert_allclose(E, float(d['calc_elbo']), rtol=1e-8)
     np.testing.assert_allclose(mu, d['calc_mu'], rtol=1e-6, atol=1e-8)
     assert hist[0] == hist[1]          # Q7: first sweep's update is discarded
+
+
+@pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'])
+def test_prediction(tag):
+    meta, d = _cases.load(tag)
+    g = np.load(_cases.GOLDEN + '/pred_' + tag + '.npz')
+    nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+    mean, var, nP, wP = cpu_ref.prediction(d['time'], g['tstar'], nodes, weights, means, jit,
+                                           d['mu_final'], d['var_final'], meta['p'], meta['q'])
+    np.testing.assert_allclose(nP, g['node_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(wP, g['weight_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mean, g['mean'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var, g['var'], rtol=1e-6, atol=1e-9)

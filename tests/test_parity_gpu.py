@@ -204,3 +204,31 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     out = g.ELBOcalc()
     assert out[3] == ref[3] and out[0] == ref[0]
     assert np.array_equal(out[1], ref[1])
+
+
+# ----------------------------------------------------------------- prediction
+@pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'])
+def test_prediction_matches_reference(tag):
+    """inference._Prediction / predict (meanfield.py:1289-1400) on the GPU against the
+    reference's own output for the same variational state."""
+    meta, d, g = _model(tag)
+    ref = np.load(os.path.join(_cases.GOLDEN, 'pred_' + tag + '.npz'))
+    mean, var, parts = g._Prediction(tstar=ref['tstar'], mu=d['mu_final'], var=d['var_final'],
+                                     separate=True)
+    assert g.last_info == 0
+    np.testing.assert_allclose(np.array(parts[0], dtype=float), ref['node_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(parts[1], dtype=float), ref['weight_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mean, ref['mean'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var, ref['var'], rtol=1e-6, atol=1e-9)
+    # the ELBO path still works afterwards (priors are refactored on demand)
+    if 'calc_elbo' in d:
+        np.testing.assert_allclose(g.ELBOcalc()[0], float(d['calc_elbo']), rtol=RTOL)
+
+
+def test_predict_default_grid_shapes():
+    meta, d, g = _model('step_p3q2')
+    g.ELBOcalc()
+    t, mean, std, parts = g.predict(nn=300)
+    assert t.shape == (300,) and mean.shape == (300, 3) and std.shape == (300, 3)
+    assert np.all(np.isfinite(mean)) and np.all(std > 0)
+    assert np.array(parts[0], dtype=float).shape == (2, 300)
