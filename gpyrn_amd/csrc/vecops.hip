@@ -10,7 +10,7 @@
 //   k_finalize                      new mu, new var = diag Sigma, tr(B^-1)
 //   k_q1_rows / k_sum_rows          <K_j^-1, Sigma_k> for the cumulative-trace quirk, :1039-1041
 //   k_dot_self                      a.a  (mu^T K^-1 mu via a = L_K^-1 mu, :1032,1050)
-//   k_elbo                          expected log-likelihood (:895-990) + assembly (:709)
+//   k_loglike_partial / k_elbo_final  expected log-likelihood (:895-990) + assembly (:709)
 #include "gprn_internal.h"
 #include "vecops.h"
 
@@ -280,20 +280,18 @@ void k_dot_self(const int* __restrict__ slot_gp, int N, int ld, const double* __
     if (threadIdx.x == 0) out[slot_gp[slot]] = acc;
 }
 
-// Expected log-likelihood (meanfield.py:895-990; y_raw is the RAW data, quirk Q3)
-// and the final assembly  ELBO = (LogL + LogP + Ent) / q  (:709).
-// out[0..3] = ELBO, LogL, LogP, Ent.  One block.
+// Expected log-likelihood (meanfield.py:895-990; y_raw is the RAW data, quirk Q3): partial sums
+// of its three terms over a slice of the time stamps per block (fixed slices -> deterministic).
+#define ELBO_BLOCKS 32
 __global__ __launch_bounds__(256)
-void k_elbo(int N, int p, int q, const double* __restrict__ mu, const double* __restrict__ var,
-            const double* __restrict__ yraw, const double* __restrict__ variance,
-            const double* __restrict__ logdetK, const double* __restrict__ logdetB,
-            const double* __restrict__ trBinv, const double* __restrict__ muKmu,
-            const double* __restrict__ q1, double* __restrict__ out)
+void k_loglike_partial(int N, int p, int q, const double* __restrict__ mu, const double* __restrict__ var,
+                       const double* __restrict__ yraw, const double* __restrict__ variance,
+                       double* __restrict__ part /* [ELBO_BLOCKS][3] */)
 {
     __shared__ double sh[4];
     const double TWO_PI = 6.283185307179586;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    for (int n = threadIdx.x; n < N; n += 256) {
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += 256 * ELBO_BLOCKS) {
         for (int i = 0; i < p; ++i) {
             const double vi = variance[(size_t)i * N + n];
             const size_t wrow = (size_t)(1 + i) * q;
@@ -314,24 +312,40 @@ void k_elbo(int N, int p, int q, const double* __restrict__ mu, const double* __
     t2 = block_sum(t2, sh);
     t3 = block_sum(t3, sh);
     if (threadIdx.x == 0) {
-        const int G = q + q * p;
-        const double logl = -0.5 * t1 - 0.5 * t2 - 0.5 * t3;
-        double ent = 0.0, logp = 0.0;
-        for (int g = 0; g < G; ++g) {
-            ent += 0.5 * (logdetK[g] - logdetB[g]);
-            double tr = trBinv[g];
-            if (g < q)
-                for (int k = 0; k < g; ++k) tr += q1[g * q + k];   // cumulative sumSigmaF, quirk Q1
-            logp += -0.5 * logdetK[g] - 0.5 * (muKmu[g] + tr);
-        }
-        const double c = (double)q * (p + 1) * N;
-        ent += 0.5 * c * (1.0 + log(TWO_PI));
-        logp += -0.5 * c * log(TWO_PI);
-        out[0] = (logl + logp + ent) / q;
-        out[1] = logl;
-        out[2] = logp;
-        out[3] = ent;
+        part[3 * blockIdx.x] = t1;
+        part[3 * blockIdx.x + 1] = t2;
+        part[3 * blockIdx.x + 2] = t3;
     }
+}
+
+// Final assembly  ELBO = (LogL + LogP + Ent) / q  (meanfield.py:709, :1023-1065, :1085-1093).
+// out[0..3] = ELBO, LogL, LogP, Ent.
+__global__ void k_elbo_final(int N, int p, int q, const double* __restrict__ part,
+                             const double* __restrict__ logdetK, const double* __restrict__ logdetB,
+                             const double* __restrict__ trBinv, const double* __restrict__ muKmu,
+                             const double* __restrict__ q1, double* __restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    const double TWO_PI = 6.283185307179586;
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    for (int b = 0; b < ELBO_BLOCKS; ++b) { t1 += part[3 * b]; t2 += part[3 * b + 1]; t3 += part[3 * b + 2]; }
+    const int G = q + q * p;
+    const double logl = -0.5 * t1 - 0.5 * t2 - 0.5 * t3;
+    double ent = 0.0, logp = 0.0;
+    for (int g = 0; g < G; ++g) {
+        ent += 0.5 * (logdetK[g] - logdetB[g]);
+        double tr = trBinv[g];
+        if (g < q)
+            for (int k = 0; k < g; ++k) tr += q1[g * q + k];   // cumulative sumSigmaF, quirk Q1
+        logp += -0.5 * logdetK[g] - 0.5 * (muKmu[g] + tr);
+    }
+    const double c = (double)q * (p + 1) * N;
+    ent += 0.5 * c * (1.0 + log(TWO_PI));
+    logp += -0.5 * c * log(TWO_PI);
+    out[0] = (logl + logp + ent) / q;
+    out[1] = logl;
+    out[2] = logp;
+    out[3] = ent;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -428,9 +442,10 @@ int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a,
 int vec_elbo(gprn_ctx* c, double* out4)
 {
     prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_elbo, dim3(1), dim3(256), 0, c->stream, c->N, c->p, c->q, c->d_mu,
-                       c->d_var, c->d_yraw, c->d_variance, c->d_logdetK, c->d_logdetB,
-                       c->d_trBinv, c->d_muKmu, c->d_q1, out4);
+    hipLaunchKernelGGL(k_loglike_partial, dim3(ELBO_BLOCKS), dim3(256), 0, c->stream, c->N, c->p, c->q,
+                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, c->d_part /* free here */);
+    hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(64), 0, c->stream, c->N, c->p, c->q, c->d_part,
+                       c->d_logdetK, c->d_logdetB, c->d_trBinv, c->d_muKmu, c->d_q1, out4);
     LAUNCH_END(c);
 }
 
