@@ -12,6 +12,7 @@
 #define GPRN_KC 16             // K chunk staged through LDS per pipeline stage
 #define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
 #define GPRN_OUTER 4           // tiles per outer panel: bulk updates contract over 4*128 = 512
+#define GPRN_OUTER_SMALL 16    // ... when batch x tiles <= 32 (latency-bound: measured +11 % at N=2048, batch 1)
 
 // Pointers fetched from a device pointer table are generic to the compiler, which then emits
 // FLAT loads; those also tick the LDS counter (lgkmcnt), so the wait before the first MFMA of
@@ -136,9 +137,11 @@ struct gprn_ctx {
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
-    std::vector<StepRange> steps;    // T entries
+    // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
+    // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
+    std::vector<StepRange> steps[2]; // T entries each
     struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
-    std::vector<OuterRange> outers;
+    std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
 };
