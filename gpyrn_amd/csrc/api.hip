@@ -45,6 +45,7 @@ static void prof_collect(gprn_ctx* c)
 {
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->stream2);
+    hipStreamSynchronize(c->stream3);
     for (auto& r : c->prof.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -144,12 +145,17 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
     gprn_ctx* c = new gprn_ctx();
     c->device = device_id;
-    // Two streams: `stream` carries everything incl. the latency chain of the factorisation,
-    // `stream2` the bulk trailing updates running behind it (look-ahead).
+    // Three streams: `stream` carries everything incl. the latency chain of the factorisation,
+    // `stream3` the in-panel work that is off that chain, `stream2` the bulk trailing updates
+    // running behind both (look-ahead).
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_diag, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_minil, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
@@ -176,6 +182,11 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     dev_free(c->d_tasks);
     dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
     hipStreamSynchronize(c->stream2);
+    hipStreamSynchronize(c->stream3);
+    hipEventDestroy(c->ev_diag);
+    hipEventDestroy(c->ev_minil);
+    hipEventDestroy(c->ev_inner);
+    hipStreamDestroy(c->stream3);
     hipEventDestroy(c->ev_panel);
     hipEventDestroy(c->ev_rest);
     hipEventDestroy(c->ev_next);

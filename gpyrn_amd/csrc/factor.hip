@@ -396,10 +396,11 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
     }
 }
 
-int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info)
+int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream)
 {
-    prof_begin(c, GPRN_T_DIAG);
-    hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, c->stream,
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_DIAG, stream);
+    hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, stream,
                        (double* const*)d_ptrs, ld, kblk, d_info);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
@@ -425,6 +426,15 @@ static inline int64_t toff(int ti, int tj, int ld) {
 // The outer update is split into the part the next panel needs ("next": its
 // columns of B, its rows of R) and the rest, so the next panel's latency chain
 // can run while the rest streams on a second HIP stream.
+// GPRN_SCHED=1: every in-panel launch on the chain stream; default (2): split schedule, see
+// factor_invert_split
+static bool split_sched()
+{
+    static int mode = 0;
+    if (!mode) { const char* e = getenv("GPRN_SCHED"); mode = e && atoi(e) == 1 ? 1 : 2; }
+    return mode == 2;
+}
+
 int ensure_tasks(gprn_ctx* c)
 {
     const int T = c->T, ld = c->ld;
@@ -469,18 +479,25 @@ int ensure_tasks(gprn_ctx* c)
         gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
-        // pass 0: the next panel's first column of B / first row of R (what its first tile step
-        // needs); pass 1: the rest of the next panel's columns / rows; pass 2: everything else
+        // pass 0 ("first"): the next panel's first column of B / first row of R -- what its first
+        // tile step needs -- and, in the split schedule, the next panel's diagonal and sub-diagonal
+        // tiles (the chain stream owns those); pass 1 ("next"): the rest of the next panel's
+        // columns / rows; pass 2 ("rest"): everything beyond
+        const bool split = split_sched();
+        auto clsB = [&](int i, int j) {
+            if (j == k1 || (split && j < n1 && i <= j + 1)) return 0;
+            return j < n1 ? 1 : 2;
+        };
+        auto clsR = [&](int i) { return i == k1 ? 0 : (i < n1 ? 1 : 2); };
         for (int pass = 0; pass < 3; ++pass) {
             const size_t begin = v.size();
-            auto cls = [&](int t) { return t == k1 ? 0 : (t < n1 ? 1 : 2); };
             for (int i = k1; i < T; ++i) {
                 for (int j = k1; j <= i; ++j) {
-                    if (cls(j) != pass) continue;
+                    if (clsB(i, j) != pass) continue;
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k0, ld), toff(j, k0, ld), kw,
                                          BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
                 }
-                if (cls(i) != pass) continue;
+                if (clsR(i) != pass) continue;
                 for (int cc = 0; cc < k0; ++cc)
                     v.push_back(TileTask{toff(i, cc, ld), toff(i, k0, ld), toff(k0, cc, ld), kw,
                                          BUF_X, BUF_B, BUF_X, tile_modes(CM_SUB, 0, 1)});
@@ -525,10 +542,83 @@ int ensure_tasks(gprn_ctx* c)
     return GPRN_OK;
 }
 
+// Split schedule.  Per tile step k the only launches on the chain stream are the diagonal
+// block, the ONE panel tile below it (L_{k+1,k}) and the ONE in-panel update that completes the
+// next diagonal tile (B_{k+1,k+1}); the remaining panel tiles and in-panel updates of the step run on
+// `stream3` beside the next diagonal block.  Order of read-modify-writes on a tile is kept by
+// events: stream3 starts step k's panel after diag(k) and its updates after L_{k+1,k}; the chain
+// takes L_{k+2,k+1} only after stream3 finished step k's updates.  The last step of an outer
+// panel stays whole on the chain (the outer update needs all of it).
+static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
+{
+    int rc;
+    bool rest_pending = false, next_pending = false;
+    hipStream_t s0 = c->stream, s1 = c->stream3, s2 = c->stream2;
+    static size_t big = 0;                         // tasks x batch above which 128x128 workgroups pay
+    if (!big) { const char* e = getenv("GPRN_FEW_TASKS"); big = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
+    auto shape_upd = [&](size_t n) { return n * (size_t)nbatch > big ? TS_128x128 : TS_64x64; };
+    auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL) {
+        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape);
+    };
+    for (size_t J = 0; J < c->outers[set].size(); ++J) {
+        const gprn_ctx::OuterRange& o = c->outers[set][J];
+        for (int k = o.k0; k < o.k1; ++k) {
+            const gprn_ctx::StepRange& s = c->steps[set][k];
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
+            if (k > o.k0) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_inner, 0));
+            if (k == o.k1 - 1) {                       // no in-panel columns right of the last step
+                if ((rc = tiles(s.panel0, s.npanel_l, s0, TS_64x128))) return rc;
+                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s0, TS_128x64))) return rc;
+                continue;
+            }
+            HIP_TRY(c, hipEventRecord(c->ev_diag, s0));
+            // chain: L_{k+1,k}, then B_{k+1,k+1}
+            if ((rc = tiles(s.panel0, 1, s0, TS_64x128))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_minil, s0));
+            if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
+            // beside it: the rest of the panel, then the rest of the in-panel updates
+            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_diag, 0));
+            if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
+            if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
+            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_minil, 0));
+            if (next_pending) {                        // the other columns / rows of this panel
+                HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_next, 0));
+                next_pending = false;
+            }
+            if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_inner, s1));
+        }
+        if (next_pending) {                            // one-step panel: nothing consumed it yet
+            HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_next, 0));
+            next_pending = false;
+        }
+        if (o.nfirst + o.nnext + o.nrest == 0) continue;
+        // Outer update of panel J.  On the chain stream what the chain touches in the next panel
+        // (its first column of B and first row of R, its diagonal and sub-diagonal tiles); the
+        // rest of the next panel and everything beyond go to the bulk stream.
+        HIP_TRY(c, hipEventRecord(c->ev_panel, s0));
+        if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_rest, 0));
+        if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
+        HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_panel, 0));
+        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext)))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_next, s2));
+        next_pending = o.nnext > 0;
+        if (o.nrest) {
+            if ((rc = tiles(o.rest0, o.nrest, s2, TS_128x128, GPRN_T_UPDATE))) return rc;
+            HIP_TRY(c, hipEventRecord(c->ev_rest, s2));
+            rest_pending = true;
+        }
+    }
+    if (next_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_next, 0));
+    if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_rest, 0));
+    return GPRN_OK;
+}
+
 int factor_invert(gprn_ctx* c, int nbatch)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
+    if (split_sched()) return factor_invert_split(c, nbatch, nbatch * c->T <= 32 ? 1 : 0);
     bool rest_pending = false, next_pending = false;
     // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
     // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.

@@ -72,7 +72,9 @@ struct gprn_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
+    hipStream_t stream3 = nullptr;   // in-panel work that is off the chain (panel rest, inner rest)
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr;
     hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;
@@ -158,7 +160,8 @@ int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const
 enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128);
-int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info);
+int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
+                hipStream_t stream = nullptr);
 // factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
 int factor_invert(gprn_ctx* c, int nbatch);
 int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
