@@ -3,6 +3,13 @@
 #include "vecops.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <atomic>
 #include <math.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
@@ -399,9 +406,138 @@ static int rccl_load(std::string* err)
         }                                                                            \
     } while (0)
 
+// ---- rehearsal transport (GPRN_COMM_TRANSPORT=shm) ----
+// The same collectives through a POSIX shared-memory segment and host copies, so that several
+// ranks can run the sharded path on ONE GPU (RCCL refuses two ranks on one device).  For the
+// tests of a one-GPU box only: every operation synchronises the stream and crosses PCIe twice.
+struct ShmComm {
+    struct Header { std::atomic<int> count; std::atomic<int> sense; };
+    static constexpr size_t kHeader = 4096, kSlot = 1 << 20;   // bytes; one slot per rank
+    int world = 1, rank = 0, local_sense = 0;
+    Header* hdr = nullptr;
+    char* slots = nullptr;
+    std::string name;
+    size_t bytes() const { return kHeader + (size_t)world * kSlot; }
+};
+
+static bool shm_transport()
+{
+    const char* e = getenv("GPRN_COMM_TRANSPORT");
+    return e && !strcmp(e, "shm");
+}
+
+static int shm_barrier(gprn_ctx* c, ShmComm* sc)
+{
+    sc->local_sense ^= 1;
+    if (sc->hdr->count.fetch_add(1) + 1 == sc->world) {
+        sc->hdr->count.store(0);
+        sc->hdr->sense.store(sc->local_sense);
+        return GPRN_OK;
+    }
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (long spin = 0; sc->hdr->sense.load() != sc->local_sense; ++spin) {
+        sched_yield();
+        if ((spin & 1023) == 1023) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (t1.tv_sec - t0.tv_sec > 120) { c->err = "shm transport: barrier timed out (a rank died?)"; return GPRN_E_COMM; }
+        }
+    }
+    return GPRN_OK;
+}
+
+static int shm_open_comm(gprn_ctx* c, int world, int rank, const char* id128)
+{
+    ShmComm* sc = new ShmComm();
+    sc->world = world; sc->rank = rank;
+    char nm[64] = "/gprn_";
+    for (int i = 0; i < 16; ++i) snprintf(nm + 6 + 2 * i, 3, "%02x", (unsigned char)id128[8 + i]);
+    sc->name = nm;
+    int fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)sc->bytes()) != 0) {
+        if (fd >= 0) close(fd);
+        delete sc; c->err = "shm transport: cannot create the segment"; return GPRN_E_COMM;
+    }
+    void* m = mmap(nullptr, sc->bytes(), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { delete sc; c->err = "shm transport: mmap failed"; return GPRN_E_COMM; }
+    sc->hdr = (ShmComm::Header*)m;                 // a fresh segment is zero-filled: count 0, sense 0
+    sc->slots = (char*)m + ShmComm::kHeader;
+    c->shm = sc;
+    int rc = shm_barrier(c, sc);                   // everybody is attached
+    if (rc == GPRN_OK && rank == 0) shm_unlink(nm);    // the mapping outlives the name
+    return rc;
+}
+
+static void shm_close_comm(gprn_ctx* c)
+{
+    ShmComm* sc = (ShmComm*)c->shm;
+    if (!sc) return;
+    munmap((void*)sc->hdr, sc->bytes());
+    delete sc;
+    c->shm = nullptr;
+}
+
+// buf (device, n doubles) of `root` -> buf of every rank
+static int shm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
+{
+    ShmComm* sc = (ShmComm*)c->shm;
+    if (n * sizeof(double) > ShmComm::kSlot) { c->err = "shm transport: message too large"; return GPRN_E_COMM; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (sc->rank == root) HIP_TRY(c, hipMemcpy(sc->slots, buf, n * sizeof(double), hipMemcpyDeviceToHost));
+    TRY(shm_barrier(c, sc));
+    if (sc->rank != root) HIP_TRY(c, hipMemcpy(buf, sc->slots, n * sizeof(double), hipMemcpyHostToDevice));
+    return shm_barrier(c, sc);
+}
+
+// sum or max over ranks, in rank order on every rank (identical bits everywhere)
+static int shm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max)
+{
+    ShmComm* sc = (ShmComm*)c->shm;
+    if (n * sizeof(double) > ShmComm::kSlot) { c->err = "shm transport: message too large"; return GPRN_E_COMM; }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(sc->slots + (size_t)sc->rank * ShmComm::kSlot, buf, n * sizeof(double), hipMemcpyDeviceToHost));
+    TRY(shm_barrier(c, sc));
+    std::vector<double> acc(n);
+    for (size_t i = 0; i < n; ++i) {
+        double v = ((const double*)sc->slots)[i];
+        for (int r = 1; r < sc->world; ++r) {
+            const double w = ((const double*)(sc->slots + (size_t)r * ShmComm::kSlot))[i];
+            v = is_max ? std::max(v, w) : v + w;
+        }
+        acc[i] = v;
+    }
+    HIP_TRY(c, hipMemcpy(buf, acc.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    return shm_barrier(c, sc);
+}
+
+// ---- the three collectives of the path, on whichever transport the context has ----
+static int comm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
+{
+    if (c->shm) return shm_broadcast(c, buf, n, root);
+    NCCL_TRY(c, g_rccl.Broadcast(buf, buf, n, ncclDouble, root, (ncclComm_t)c->comm, c->stream));
+    return GPRN_OK;
+}
+
+static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max = false)
+{
+    if (c->shm) return shm_allreduce(c, buf, n, is_max);
+    NCCL_TRY(c, g_rccl.AllReduce(buf, buf, n, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream));
+    return GPRN_OK;
+}
+
+static bool comm_active(const gprn_ctx* c) { return c->comm || c->shm; }
+
 extern "C" int gprn_comm_unique_id(char* id128)
 {
     if (!id128) return GPRN_E_ARG;
+    if (shm_transport()) {                         // 128 random bytes name the segment
+        memset(id128, 0, 128);
+        memcpy(id128, "gprnshm", 8);
+        int fd = open("/dev/urandom", O_RDONLY);
+        if (fd < 0 || read(fd, id128 + 8, 16) != 16) { if (fd >= 0) close(fd); return GPRN_E_COMM; }
+        close(fd);
+        return GPRN_OK;
+    }
     if (rccl_load(nullptr)) return GPRN_E_COMM;
     ncclUniqueId id;
     if (g_rccl.GetUniqueId(&id) != ncclSuccess) return GPRN_E_COMM;
@@ -413,6 +549,7 @@ static void comm_teardown(gprn_ctx* c)
 {
     if (c->comm && g_rccl_handle) g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
+    shm_close_comm(c);
 }
 
 extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id128)
@@ -425,6 +562,7 @@ extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id12
     // a one-rank communicator is legal RCCL and lets a single GPU exercise every collective call
     if (world == 1 && !getenv("GPRN_FORCE_RCCL")) return GPRN_OK;
     if (!id128) return bad(c, "comm_init: id required");
+    if (!memcmp(id128, "gprnshm", 8)) return shm_open_comm(c, world, rank, id128);
     TRY(rccl_load(&c->err));
     ncclUniqueId id;
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
@@ -449,11 +587,11 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 {
     if (!c || !value) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->comm) {
+    if (comm_active(c)) {
         double* d = nullptr;
         TRY(dev_alloc(c, &d, 1));
         HIP_TRY(c, hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
-        NCCL_TRY(c, g_rccl.AllReduce(d, d, 1, ncclDouble, ncclMax, (ncclComm_t)c->comm, c->stream));
+        TRY(comm_allreduce(c, d, 1, true));
         HIP_TRY(c, hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         hipFree(d);
@@ -466,28 +604,27 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 // rows of the (p+1, q, N) state owned by other ranks arrive from their owners
 static int exchange_rows(gprn_ctx* c, bool weights)
 {
-    if (!c->comm) return GPRN_OK;
+    if (!comm_active(c)) return GPRN_OK;
     const int g0 = weights ? c->q : 0, g1 = weights ? c->G : c->q;
-    NCCL_TRY(c, g_rccl.GroupStart());
+    if (c->comm) NCCL_TRY(c, g_rccl.GroupStart());
     for (int g = g0; g < g1; ++g) {
         size_t row;
         if (g < c->q) row = g;
         else { const int kk = g - c->q, j = kk / c->p, i = kk % c->p; row = (size_t)(1 + i) * c->q + j; }
         double* m = c->d_mu + row * c->N;
         double* v = c->d_var + row * c->N;
-        NCCL_TRY(c, g_rccl.Broadcast(m, m, c->N, ncclDouble, c->owner[g], (ncclComm_t)c->comm, c->stream));
-        NCCL_TRY(c, g_rccl.Broadcast(v, v, c->N, ncclDouble, c->owner[g], (ncclComm_t)c->comm, c->stream));
+        TRY(comm_broadcast(c, m, c->N, c->owner[g]));
+        TRY(comm_broadcast(c, v, c->N, c->owner[g]));
     }
-    NCCL_TRY(c, g_rccl.GroupEnd());
+    if (c->comm) NCCL_TRY(c, g_rccl.GroupEnd());
     return GPRN_OK;
 }
 
 static int reduce_scalars(gprn_ctx* c)
 {
-    if (!c->comm) return GPRN_OK;
+    if (!comm_active(c)) return GPRN_OK;
     const size_t n = 3 * (size_t)c->G + (size_t)c->q * c->q;
-    NCCL_TRY(c, g_rccl.AllReduce(c->d_scal, c->d_scal, n, ncclDouble, ncclSum, (ncclComm_t)c->comm, c->stream));
-    return GPRN_OK;
+    return comm_allreduce(c, c->d_scal, n);
 }
 
 // ------------------------------------------------------------------ tables
@@ -649,9 +786,7 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
         HIP_TRY(c, hipMemcpy(h.data(), c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
         for (int g = 0; g < c->G; ++g) if (c->owner[g] != c->rank) h[g] = 0.0;
         HIP_TRY(c, hipMemcpy(c->d_logdetK, h.data(), c->G * sizeof(double), hipMemcpyHostToDevice));
-        if (c->comm)
-            NCCL_TRY(c, g_rccl.AllReduce(c->d_logdetK, c->d_logdetK, c->G, ncclDouble, ncclSum,
-                                         (ncclComm_t)c->comm, c->stream));
+        if (comm_active(c)) TRY(comm_allreduce(c, c->d_logdetK, c->G));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->factored = true;

@@ -96,6 +96,7 @@ struct gprn_ctx {
     std::vector<int> owner;          // G entries (empty until known when world > 1)
     std::vector<int> loc_nodes, loc_weights;   // latent GPs of this rank, ascending = slot order
     void* comm = nullptr;            // ncclComm_t
+    void* shm = nullptr;             // ShmComm: rehearsal transport of one-GPU boxes (api.hip)
 
     // ---- per latent GP, persistent across sweeps (only for GPs this rank needs)
     std::vector<KernelSpec> kspec;   // G

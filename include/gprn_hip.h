@@ -88,7 +88,12 @@ int gprn_set_data(gprn_ctx* ctx, int N, int p, int q,
 
 /* ---- multi-GPU sharding (new): one context per rank/GPU.
  * comm_init before set_data; set_owners after set_data and before set_kernel:
- * latent GP g is factored and updated by rank owner[g] (q + q*p entries). */
+ * latent GP g is factored and updated by rank owner[g] (q + q*p entries).
+ * Transport: RCCL (ncclUniqueId in id128).  With GPRN_COMM_TRANSPORT=shm in the
+ * environment comm_unique_id returns the name of a host shared-memory segment instead
+ * and the same three collectives (row broadcast, scalar all-reduce, barrier) cross it by
+ * host copies: a rehearsal transport so that several ranks can share ONE GPU in tests
+ * (RCCL refuses that); not a production path. */
 int gprn_comm_unique_id(char* id128);
 int gprn_comm_init(gprn_ctx* ctx, int world, int rank, const char* id128);
 int gprn_set_owners(gprn_ctx* ctx, const int* owner);

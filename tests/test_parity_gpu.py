@@ -206,6 +206,59 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     assert np.array_equal(out[1], ref[1])
 
 
+@pytest.mark.parametrize('tag,world', [('step_p3q2', 2), ('step_p2q3', 3), ('mid_N300_p3q2', 2),
+                                       ('mid_N512_p3q2', 4)])
+def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
+    """The sharded path of the library itself (owners, helper K_j^-1 factorisations, row
+    broadcasts, scalar all-reduce) with `world` processes sharing this box's one GPU.  RCCL
+    refuses two ranks on one device, so the collectives travel through the library's host
+    shared-memory rehearsal transport (GPRN_COMM_TRANSPORT=shm); everything else is the code
+    that runs under RCCL.  Every rank must reproduce the reference's golden values."""
+    import subprocess
+    import sys
+    meta, d = _cases.load(tag)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs, outs = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', GPRN_COMM_TRANSPORT='shm')
+        out = str(tmp_path / f'rank{r}.npz')
+        outs.append(out)
+        procs.append(subprocess.Popen(
+            [sys.executable, '-m', 'tests._shard_worker', tag, out, f'{os.getpid()}_{tag}_{world}'],
+            cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q_ in procs:
+                q_.kill()
+            raise
+        logs.append(o.decode(errors='replace'))
+    assert all(pr.returncode == 0 for pr in procs), '\n'.join(logs)
+    for r, out in enumerate(outs):
+        res = np.load(out)
+        assert int(res['rank']) == r and int(res['world']) == world and int(res['sw_info']) == 0
+        np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
+        np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
+        np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(res['sw_var'], d['var_final'], rtol=1e-6, atol=1e-12)
+        ld = res['logdet_K']
+        np.testing.assert_allclose(ld[:meta['q']], 2 * d['logdiag_Lf'], rtol=1e-9)
+        np.testing.assert_allclose(ld[meta['q']:], 2 * d['logdiag_Lw'], rtol=1e-9)
+        if 'calc_elbo' in d:
+            assert int(res['calc_iter']) == int(d['calc_iter'])
+            np.testing.assert_allclose(res['calc_history'], d['calc_elbo_array'], rtol=RTOL)
+            np.testing.assert_allclose(res['calc_mu'], d['calc_mu'], rtol=1e-6, atol=1e-8)
+    # every rank holds the same bits (the all-reduce sums in rank order on every rank)
+    first = np.load(outs[0])
+    for out in outs[1:]:
+        other = np.load(out)
+        assert np.array_equal(first['sw_elbo'], other['sw_elbo'])
+        assert np.array_equal(first['sw_mu'], other['sw_mu'])
+
+
 # ----------------------------------------------------------------- prediction
 @pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'])
 def test_prediction_matches_reference(tag):
