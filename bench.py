@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 from gpyrn_amd import _hip, covfunc, meanfunc, sharding, synth  # noqa: E402
 import gpyrn_amd as gpyrn  # noqa: E402
 
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet, fp64 matrix (= fp64 vector); see DESIGN.md §6
 TILE = 128
 
@@ -95,6 +96,8 @@ def main():
     ap.add_argument('--config', type=int, default=3)
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-calc', action='store_true')
+    ap.add_argument('--shape', default=None,
+                    help='N,p,q of an ad-hoc problem (experiments; not a BASELINE config)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -105,6 +108,8 @@ def main():
                      '(one rank per GPU)')
         a.gpus = world
     N, p, q, kind = synth.CONFIGS[a.config]
+    if a.shape:
+        N, p, q = (int(x) for x in a.shape.split(','))
     comm = sharding.Comm() if world > 1 else None
 
     t, ys, es = synth.rv_series(N, p)
@@ -117,6 +122,7 @@ def main():
     ctx = g._setup_device(nodes, weights, means, jit)     # fill + chol(K): once per ELBOcalc
     ctx.barrier_max(0.0)
     t_setup = time.time() - t0
+    ms_fill, n_fill = 0.0, 0
     mu0, var0 = g._initMuVar(nodes, weights, jit)
     ctx.set_muvar(mu0, var0)
 
@@ -145,6 +151,13 @@ def main():
             _, _, _, it = g.ELBOcalc()
             times.append(ctx.barrier_max(time.perf_counter() - t0))
             trips.append(it)
+        # the covariance fills of one more set-up, timed per launch (HIP events; code is warm here)
+        for j, node in enumerate(nodes):
+            node.pars[1] *= 1.0 + 1e-3
+        ctx.profile_enable(['fill'])
+        g._setup_device(nodes, weights, means, jit)
+        ms_fill, n_fill = ctx.profile_read()['fill']
+        ctx.profile_enable([])
         calc = {'elbocalc_per_s': 1.0 / min(times), 'ms': 1e3 * min(times), 'loop_trips': trips[-1]}
         if world == 1:
             # GPRN prediction at 1000 new times from the converged state
@@ -171,10 +184,22 @@ def main():
             'vs_baseline': None,
             'dtype': 'f64',
             'data': 'synthetic',
-            'config': {'workload': 'BASELINE config %d: N=%d, p=%d outputs, q=%d nodes, %s nodes / SE '
-                                   'weights, synthetic RV series (seed 0)' % (a.config, N, p, q, kind),
+            'config': {'workload': '%s: N=%d, p=%d outputs, q=%d nodes, %s nodes / SE '
+                                   'weights, synthetic RV series (seed 0)'
+                                   % ('ad-hoc shape' if a.shape else 'BASELINE config %d' % a.config,
+                                      N, p, q, kind),
                        'latent_gps': q * (p + 1), 'sharding': 'latent GPs over %d rank(s)' % world},
             'sweep_tflops': sweep_flops(N, p, q) * a.steps / dt / 1e12,
+            # BASELINE metric, second half: fp64 rate of the Cholesky work.  The sweep's N^3 work IS
+            # the G fused Cholesky + triangular-inverse factorisations (+ q-1 X^T X products); this is
+            # that flop count over the whole sweep time, O(N^2) kernels and exchanges included.
+            'cholesky_gflops': sweep_flops(N, p, q) * a.steps / dt / 1e9,
+            # fused covariance fill at setup: 8 N^2 bytes written per matrix, against the HBM peak
+            # (it is fp64-VALU-bound, not HBM-bound: a division and exp/sin per element)
+            'fill': ({'GBps': n_fill * 8.0 * N * N / (ms_fill * 1e-3) / 1e9, 'launches': n_fill,
+                      'peak_GBps': HBM_PEAK_GBPS,
+                      'frac': n_fill * 8.0 * N * N / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                     if ms_fill > 0 else None),
             'setup_s': t_setup,
             'full_elbocalc': calc,
             'elbo_last': float(elbo[-1]), 'info': int(info),
@@ -183,7 +208,7 @@ def main():
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,
-                'traffic': pmc_traffic() if world == 1 and a.config == 3 else None,
+                'traffic': pmc_traffic() if world == 1 and a.config == 3 and not a.shape else None,
                 'measured_mfma_ceiling': ctx.mfma_peak(2, 4000),
                 'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
                 'flops_per_launch': (fl / n_upd) if n_upd else None,

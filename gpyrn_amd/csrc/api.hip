@@ -871,6 +871,7 @@ extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_ou
         HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int it = 0; it < n_sweeps; ++it) {
         HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), c->stream));
         TRY(run_phase(c, false));
@@ -888,9 +889,15 @@ extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_ou
         HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
     }
+    timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1);
     std::vector<double> h(4 * (size_t)n_sweeps);
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (getenv("GPRN_DEBUG_TIMING")) {
+        timespec ts2; clock_gettime(CLOCK_MONOTONIC, &ts2);
+        auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
+        fprintf(stderr, "[gprn] %d sweeps: host enqueue %.3f ms, until results %.3f ms\n", n_sweeps, ms(ts0, ts1), ms(ts0, ts2));
+    }
     for (int it = 0; it < n_sweeps; ++it) {
         elbo_out[it] = h[4 * it];
         if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];

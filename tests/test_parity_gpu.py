@@ -207,7 +207,7 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
 
 
 @pytest.mark.parametrize('tag,world', [('step_p3q2', 2), ('step_p2q3', 3), ('mid_N300_p3q2', 2),
-                                       ('mid_N512_p3q2', 4)])
+                                       ('mid_N512_p3q2', 4), ('step_p1q1', 3)])   # last: a rank owning nothing
 def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
     """The sharded path of the library itself (owners, helper K_j^-1 factorisations, row
     broadcasts, scalar all-reduce) with `world` processes sharing this box's one GPU.  RCCL
