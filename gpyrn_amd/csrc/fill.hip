@@ -158,9 +158,20 @@ __device__ __forceinline__ double eval_program(const FillProgram& pg, double ti,
     return st[0];
 }
 
+// One instantiation per built-in kernel id (KID >= 0: the switch in eval_kernel folds away, each
+// kernel carries only its own registers -- the all-in-one version needed 288 VGPRs, one wave per
+// SIMD, and ran 8x slower) plus the generic postfix-program version (KID = -1) for composites.
+template <int KID>
+__device__ __forceinline__ double eval_any(const FillProgram& pg, double ti, double tj, bool diag)
+{
+    if constexpr (KID >= 0) return eval_kernel(KID, pg.par, ti, tj, diag);
+    else return eval_program(pg, ti, tj, diag);
+}
+
 // one block = 8 rows x 256 columns; each thread 8 rows x 1 column -> per row the
 // 256 threads write 2 KiB contiguous.  Padded region (>= N) becomes identity so
 // the blocked factorisation can run on whole tiles.
+template <int KID>
 __global__ __launch_bounds__(256)
 void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld,
             const double* __restrict__ diag_add)
@@ -175,8 +186,7 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
         if (m >= ld) break;
         double v;
         if (m < N && n < N) {
-            v = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, t[m], tn, m == n)
-                                : eval_program(pg, t[m], tn, m == n);
+            v = eval_any<KID>(pg, t[m], tn, m == n);
             if (m == n) {
                 if (pg.nugget) v += pg.nugget_val;
                 if (diag_add) v += diag_add[m];
@@ -186,6 +196,17 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
         }
         K[(size_t)m * ld + n] = v;
     }
+}
+
+// host-side choice of the instantiation: the id of a one-kernel program, else the generic one
+#define GPRN_FOR_EACH_KID(X) \
+    X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
+    X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+static_assert(GPRN_K_COUNT == 24, "add the new kernel id to GPRN_FOR_EACH_KID");
+
+static int program_kid(const FillProgram& pg)
+{
+    return (pg.n_ops == 1 && pg.ops[1] >= 0 && pg.ops[1] < GPRN_K_COUNT && pg.ops[2] == 0) ? pg.ops[1] : -1;
 }
 
 static void make_program(const KernelSpec& ks, double nugget_val, FillProgram& pg)
@@ -205,7 +226,12 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val,
     make_program(ks, nugget_val, pg);
     prof_begin(c, GPRN_T_FILL);
     dim3 grid((c->ld + 255) / 256, (c->ld + 7) / 8);
-    hipLaunchKernelGGL(k_fill, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add);
+    switch (program_kid(pg)) {
+#define X(id) case id: hipLaunchKernelGGL(k_fill<id>, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add); break;
+    GPRN_FOR_EACH_KID(X)
+#undef X
+    default: hipLaunchKernelGGL(k_fill<-1>, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add);
+    }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -214,6 +240,7 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val,
 // Rectangular cross-covariance K*[i][n] = k(t*_i, t_n), no nugget (_gp.py:50-61, meanfield.py:455-471),
 // rows padded to a multiple of 128 with zeros; and the prior variance at the prediction points,
 // kss[i] = k(t*_i, t*_i) + nugget (the diagonal of _gp.py:40-48 evaluated at tstar).
+template <int KID>
 __global__ __launch_bounds__(256)
 void k_fill_rect(FillProgram pg, const double* __restrict__ ts, int ns, int ns_pad,
                  const double* __restrict__ t, int N, int ld, double* __restrict__ Ks,
@@ -229,12 +256,10 @@ void k_fill_rect(FillProgram pg, const double* __restrict__ ts, int ns, int ns_p
         if (i >= ns_pad) break;
         double v = 0.0;
         if (i < ns && n < N)
-            v = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, ts[i], tn, false)
-                                : eval_program(pg, ts[i], tn, false);
+            v = eval_any<KID>(pg, ts[i], tn, false);
         Ks[(size_t)i * ld + n] = v;
         if (n == 0 && i < ns) {
-            double d = (pg.n_ops == 1) ? eval_kernel(pg.ops[1], pg.par, ts[i], ts[i], true)
-                                       : eval_program(pg, ts[i], ts[i], true);
+            double d = eval_any<KID>(pg, ts[i], ts[i], true);
             if (pg.nugget) d += pg.nugget_val;
             kss[i] = d;
         }
@@ -248,8 +273,12 @@ int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const
     make_program(ks, nugget_val, pg);
     prof_begin(c, GPRN_T_FILL);
     dim3 grid((c->ld + 255) / 256, (ns_pad + 7) / 8);
-    hipLaunchKernelGGL(k_fill_rect, grid, dim3(256), 0, c->stream, pg, d_tstar, ns, ns_pad, c->d_time,
-                       c->N, c->ld, Ks, kss);
+    switch (program_kid(pg)) {
+#define X(id) case id: hipLaunchKernelGGL(k_fill_rect<id>, grid, dim3(256), 0, c->stream, pg, d_tstar, ns, ns_pad, c->d_time, c->N, c->ld, Ks, kss); break;
+    GPRN_FOR_EACH_KID(X)
+#undef X
+    default: hipLaunchKernelGGL(k_fill_rect<-1>, grid, dim3(256), 0, c->stream, pg, d_tstar, ns, ns_pad, c->d_time, c->N, c->ld, Ks, kss);
+    }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
