@@ -167,6 +167,27 @@ def main():
             g.predict(nn=1000)
             calc['predict_1000_ms'] = 1e3 * (time.perf_counter() - t0)
 
+    # SURVEY.md 8f-1, the other way to use N GPUs: independent ELBO evaluations (optimiser
+    # populations, emcee walkers), every rank with the whole problem on its own GPU, no
+    # exchange -- aggregate full ELBOcalc evaluations per second over all ranks (weak scaling).
+    pool = None
+    if world > 1 and not a.no_calc:
+        local_dev = comm.local_rank % max(1, _hip.device_count())
+        g1 = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair], device=local_dev)
+        n1, w1, m1, j1 = synth.build_components(covfunc, meanfunc, spec)
+        g1.set_components(n1, w1, m1, j1)
+        g1.ELBOcalc()                                            # allocations, code, first factors
+        reps = 2
+        ctx.barrier_max(0.0)
+        t0 = time.perf_counter()
+        for rep in range(reps):
+            for node in n1:
+                node.pars[1] *= 1.0 + 1e-3 * (rep + 1 + rank)   # every evaluation refills and refactors
+            g1.ELBOcalc()
+        dt_pool = ctx.barrier_max(time.perf_counter() - t0)
+        pool = {'elbocalc_per_s_all_ranks': world * reps / dt_pool, 'ms_per_elbocalc': 1e3 * dt_pool / reps,
+                'scaling': 'weak', 'note': 'one independent full ELBOcalc stream per rank'}
+
     if rank == 0:
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
         ms_upd, n_upd = prof['update']
@@ -202,6 +223,7 @@ def main():
                      if ms_fill > 0 else None),
             'setup_s': t_setup,
             'full_elbocalc': calc,
+            'independent_evaluations': pool,
             'elbo_last': float(elbo[-1]), 'info': int(info),
             'roofline': {
                 'kernel': 'k_tile_gemm<128,128> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',

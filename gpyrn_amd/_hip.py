@@ -57,6 +57,7 @@ SIGNATURES = {
     'gprn_profile_enable': (c_int, [c_void_p, c_int]),
     'gprn_profile_read': (c_int, [c_void_p, _dp, POINTER(c_int64), c_int]),
     'gprn_test_gemm': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, _dp, _dp, _dp]),
+    'gprn_comm_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
@@ -175,6 +176,12 @@ class Context:
         v = c_double(float(value))
         self._check(self._lib.gprn_comm_barrier_max(self._h, byref(v)), 'barrier_max')
         return v.value
+
+    def allreduce_sum(self, values):
+        """Sum of a float64 vector over the ranks of this context's communicator."""
+        buf = np.array(values, dtype=np.float64).ravel()
+        self._check(self._lib.gprn_comm_allreduce_sum(self._h, _ptr(buf), buf.size), 'allreduce_sum')
+        return buf
 
     def set_kernel(self, gp, ops, params, add_nugget):
         flat = np.ascontiguousarray(np.asarray(ops, dtype=np.int32).reshape(-1, 3))

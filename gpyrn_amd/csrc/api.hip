@@ -601,6 +601,25 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
     return GPRN_OK;
 }
 
+// sum of a caller-owned host vector over the ranks (every rank gets the result): what a pool
+// of independent ELBO evaluations (emcee walkers) needs to share its values
+extern "C" int gprn_comm_allreduce_sum(gprn_ctx* c, double* buf, int n)
+{
+    if (!c || !buf || n < 0) return bad(c, "comm_allreduce_sum: bad argument");
+    if (!comm_active(c) || n == 0) return GPRN_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    double* d = nullptr;
+    TRY(dev_alloc(c, &d, (size_t)n));
+    int rc = GPRN_OK;
+    if (hipMemcpyAsync(d, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = GPRN_E_HIP;
+    if (rc == GPRN_OK) rc = comm_allreduce(c, d, (size_t)n);
+    if (rc == GPRN_OK && hipMemcpyAsync(buf, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = GPRN_E_HIP;
+    if (rc == GPRN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = GPRN_E_HIP;
+    hipFree(d);
+    if (rc == GPRN_E_HIP) c->err = "comm_allreduce_sum: copy failed";
+    return rc;
+}
+
 // rows of the (p+1, q, N) state owned by other ranks arrive from their owners
 static int exchange_rows(gprn_ctx* c, bool weights)
 {

@@ -560,13 +560,29 @@ class inference:
         mean, variance, parts = self._Prediction(tstar=tstar, separate=True)
         return tstar, mean, np.sqrt(variance), parts
 
+    def nELBO_batch(self, parameter_sets, max_iter=None, pool=None):
+        """
+        ``nELBO`` for several free-parameter vectors: ``[nELBO(p) for p in
+        parameter_sets]``.  With ``pool`` (``sharding.EvalPool``; every rank holds
+        this same problem on its own GPU) the vectors are split over the ranks and
+        every rank returns the full list.  Not in the reference, which evaluates
+        optimiser populations and emcee walkers one by one (meanfield.py:1222-1260).
+        The parameters of ``self`` end up at the last vector this rank evaluated.
+        """
+        assert self._components_set, _NOT_SET
+        sets = [np.array(x, dtype=float) for x in parameter_sets]
+        f = lambda x: float(self.nELBO(x, max_iter=max_iter))
+        return list(map(f, sets)) if pool is None else pool.map(f, sets)
+
     def mcmc(self, priors, p0=None, vars=None, niter=500, **kwargs):
         """
         Sample the posterior of the free parameters with emcee, the ELBO (100
         sweeps at most, warm-started) standing in for the marginal likelihood
         (meanfield.py:1154-1286).  `priors`: dict name -> frozen scipy.stats
         distribution.  emcee is imported here, not at package import; without it
-        this raises ImportError.  Returns the sampler.
+        this raises ImportError.  Returns the sampler.  ``pool=sharding.EvalPool()``
+        (forwarded to emcee with the other keyword arguments) spreads the walkers
+        over the GPUs of the node.
         """
         assert self._components_set, _NOT_SET
         from emcee import EnsembleSampler

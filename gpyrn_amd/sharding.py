@@ -11,6 +11,12 @@ One process per GPU (``python -m torch.distributed.run`` or any launcher that
 sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT); the ncclUniqueId travels
 through a file in /tmp keyed by the launcher's pid, so no torch import is
 needed here.
+
+A second, coarser way to use several GPUs is `EvalPool`: every rank keeps the WHOLE
+problem on its own GPU and the ranks split a list of independent evaluations
+(parameter vectors of an optimiser population, emcee walkers -- the reference
+evaluates those one by one, meanfield.py:1222-1260); no N x N data and no per-sweep
+exchange at all, one small all-reduce per batch.
 """
 import os
 import time
@@ -94,3 +100,56 @@ class Comm:
                 os.unlink(self._path)
             except OSError:
                 pass
+
+
+class EvalPool:
+    """``map`` over the ranks of one node, for independent evaluations.
+
+    SPMD: every rank runs the same script and calls ``pool.map(func, items)`` with
+    the same ``items``; rank r evaluates ``items[r::world]`` on its own GPU and one
+    all-reduce hands every rank the full result list, in order.  ``func`` must
+    return a float or a fixed-length tuple of floats (emcee's log-probability with
+    blobs).  This is the ``pool`` protocol of ``emcee.EnsembleSampler`` and of
+    ``inference.nELBO_batch``; seed the ranks identically so that they propose the
+    same walkers.
+
+    The pool owns a small library context used only for the collective; the
+    ``inference`` objects doing the work are ordinary unsharded ones created with
+    ``device=pool.device``.
+    """
+
+    def __init__(self, comm=None):
+        from . import _hip
+        self.comm = Comm() if comm is None else comm
+        self.world, self.rank = self.comm.world, self.comm.rank
+        self.device = self.comm.local_rank % max(1, _hip.device_count())
+        self._ctx = _hip.Context(self.device)
+        if self.world > 1:
+            self._ctx.comm_init(self.world, self.rank, self.comm.unique_id())
+
+    def map(self, func, items):
+        items = list(items)
+        n = len(items)
+        if n == 0:
+            return []
+        mine = range(self.rank, n, self.world)
+        local = {i: func(items[i]) for i in mine}
+        if self.world == 1:
+            return [local[i] for i in range(n)]
+        import numpy as np
+        # width of one result: known on the ranks that evaluated something, shared by a max
+        first = next(iter(local.values())) if local else 0.0
+        scalar = np.ndim(first) == 0
+        width = int(self._ctx.barrier_max(1 if scalar else len(first)))
+        scalar = bool(self._ctx.barrier_max(0.0 if scalar else 1.0) == 0.0)
+        buf = np.zeros((n, width))
+        for i, v in local.items():
+            buf[i] = np.atleast_1d(np.asarray(v, dtype=float))
+        # a sum with zeros elsewhere; -inf and nan survive it
+        buf = self._ctx.allreduce_sum(buf).reshape(n, width)
+        if scalar:
+            return [float(buf[i, 0]) for i in range(n)]
+        return [tuple(float(x) for x in buf[i]) for i in range(n)]
+
+    def close(self):
+        self.comm.cleanup()

@@ -98,6 +98,9 @@ int gprn_comm_unique_id(char* id128);
 int gprn_comm_init(gprn_ctx* ctx, int world, int rank, const char* id128);
 int gprn_set_owners(gprn_ctx* ctx, const int* owner);
 int gprn_comm_barrier_max(gprn_ctx* ctx, double* value); /* all-reduce(max) + sync */
+/* sum of a host vector over the ranks, result on every rank (pool of independent ELBO
+ * evaluations across GPUs: meanfield.py:1222-1260 evaluates its walkers one by one) */
+int gprn_comm_allreduce_sum(gprn_ctx* ctx, double* buf, int n);
 
 /* ---- per-ELBOcalc setup: meanfield.py:618-624 ----
  * set_kernel: latent GP `gp` gets K = expr(t_i, t_j) (+ 1e-6 I when add_nugget,

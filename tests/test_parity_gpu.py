@@ -206,26 +206,18 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     assert np.array_equal(out[1], ref[1])
 
 
-@pytest.mark.parametrize('tag,world', [('step_p3q2', 2), ('step_p2q3', 3), ('mid_N300_p3q2', 2),
-                                       ('mid_N512_p3q2', 4), ('step_p1q1', 3)])   # last: a rank owning nothing
-def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
-    """The sharded path of the library itself (owners, helper K_j^-1 factorisations, row
-    broadcasts, scalar all-reduce) with `world` processes sharing this box's one GPU.  RCCL
-    refuses two ranks on one device, so the collectives travel through the library's host
-    shared-memory rehearsal transport (GPRN_COMM_TRANSPORT=shm); everything else is the code
-    that runs under RCCL.  Every rank must reproduce the reference's golden values."""
+def _run_ranks(module, tag, world, tmp_path):
     import subprocess
     import sys
-    meta, d = _cases.load(tag)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', GPRN_COMM_TRANSPORT='shm')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', GPRN_COMM_TRANSPORT='shm')
         out = str(tmp_path / f'rank{r}.npz')
         outs.append(out)
         procs.append(subprocess.Popen(
-            [sys.executable, '-m', 'tests._shard_worker', tag, out, f'{os.getpid()}_{tag}_{world}'],
+            [sys.executable, '-m', module, tag, out, f'{os.getpid()}_{module}_{tag}_{world}'],
             cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for pr in procs:
@@ -237,8 +229,20 @@ def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
             raise
         logs.append(o.decode(errors='replace'))
     assert all(pr.returncode == 0 for pr in procs), '\n'.join(logs)
-    for r, out in enumerate(outs):
-        res = np.load(out)
+    return [np.load(o) for o in outs]
+
+
+@pytest.mark.parametrize('tag,world', [('step_p3q2', 2), ('step_p2q3', 3), ('mid_N300_p3q2', 2),
+                                       ('mid_N512_p3q2', 4), ('step_p1q1', 3)])   # last: a rank owning nothing
+def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
+    """The sharded path of the library itself (owners, helper K_j^-1 factorisations, row
+    broadcasts, scalar all-reduce) with `world` processes sharing this box's one GPU.  RCCL
+    refuses two ranks on one device, so the collectives travel through the library's host
+    shared-memory rehearsal transport (GPRN_COMM_TRANSPORT=shm); everything else is the code
+    that runs under RCCL.  Every rank must reproduce the reference's golden values."""
+    meta, d = _cases.load(tag)
+    results = _run_ranks('tests._shard_worker', tag, world, tmp_path)
+    for r, res in enumerate(results):
         assert int(res['rank']) == r and int(res['world']) == world and int(res['sw_info']) == 0
         np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
         np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
@@ -252,11 +256,23 @@ def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
             np.testing.assert_allclose(res['calc_history'], d['calc_elbo_array'], rtol=RTOL)
             np.testing.assert_allclose(res['calc_mu'], d['calc_mu'], rtol=1e-6, atol=1e-8)
     # every rank holds the same bits (the all-reduce sums in rank order on every rank)
-    first = np.load(outs[0])
-    for out in outs[1:]:
-        other = np.load(out)
+    first = results[0]
+    for other in results[1:]:
         assert np.array_equal(first['sw_elbo'], other['sw_elbo'])
         assert np.array_equal(first['sw_mu'], other['sw_mu'])
+
+
+def test_eval_pool_splits_independent_evaluations(tmp_path):
+    """sharding.EvalPool: three ranks, each with the whole problem on the (shared)
+    GPU, split five nELBO evaluations; every rank gets all five values, bit-identical to
+    evaluating them one by one."""
+    for res in _run_ranks('tests._pool_worker', 'step_p3q2', 3, tmp_path):
+        assert int(res['world']) == 3
+        assert np.array_equal(res['pooled'], res['serial'])
+        np.testing.assert_allclose(res['batch'], res['serial'], rtol=1e-2)   # warm starts differ
+        odd = res['odd']
+        assert odd.shape == (7, 2) and np.array_equal(odd[:, 0], np.arange(7.0))
+        assert np.isneginf(odd[1, 1]) and np.isnan(odd[2, 1]) and odd[6, 1] == 3.0
 
 
 # ----------------------------------------------------------------- prediction
