@@ -161,3 +161,47 @@ def test_two_ranks_gloo_match_unsharded(tag, tmp_path):
         np.testing.assert_allclose(r0['elbo'][s], E, rtol=1e-12)
     np.testing.assert_allclose(r0['mu'], mu, rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(r0['var'], var, rtol=1e-10, atol=1e-14)
+
+
+def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
+    """EvalPool.map: rank r evaluates items r::world, a sum over ranks with zeros elsewhere
+    rebuilds the full list (scalars, tuples, -inf, nan).  The library context is replaced by a
+    recorder; the two ranks run one after the other and their buffers are summed by hand."""
+    from gpyrn_amd import _hip, sharding
+
+    class FakeCtx:
+        def __init__(self, device):
+            self.sent = None
+
+        def comm_init(self, world, rank, uid):
+            pass
+
+        def barrier_max(self, v=0.0):
+            return float(v)
+
+        def allreduce_sum(self, buf):
+            self.sent = np.array(buf, dtype=float)
+            return FakeCtx.total if FakeCtx.total is not None else self.sent
+
+    monkeypatch.setattr(_hip, 'Context', FakeCtx)
+    monkeypatch.setattr(_hip, 'device_count', lambda: 1)
+
+    class NoRendezvous(sharding.Comm):
+        def unique_id(self, timeout=0):
+            return b'\0' * 128
+
+    f = lambda i: (float(i), -np.inf if i == 1 else (np.nan if i == 2 else 0.5 * i))
+    FakeCtx.total = None
+    pools = [sharding.EvalPool(NoRendezvous(world=2, rank=r, local_rank=r)) for r in range(2)]
+    calls = [[], []]
+    for r, pool in enumerate(pools):                 # first pass: record what each rank contributes
+        pool.map(lambda i, r=r: (calls[r].append(i), f(i))[1], range(5))
+    assert calls == [[0, 2, 4], [1, 3]]
+    with np.errstate(invalid='ignore'):
+        FakeCtx.total = pools[0]._ctx.sent + pools[1]._ctx.sent
+    for pool in pools:                               # second pass: the summed buffer comes back
+        out = pool.map(f, range(5))
+        assert [o[0] for o in out] == [0.0, 1.0, 2.0, 3.0, 4.0]
+        assert np.isneginf(out[1][1]) and np.isnan(out[2][1]) and out[4][1] == 2.0
+    one = sharding.EvalPool(NoRendezvous(world=1, rank=0, local_rank=0))
+    assert one.map(lambda x: x * 2.0, [1.0, 2.0]) == [2.0, 4.0]
