@@ -93,13 +93,6 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const double a_sign = (c_mode == CM_SET) ? 1.0 : -1.0;
     gptr_t Cw = C + (size_t)(wr * (BM / 2) + fk) * ld + wc * (BN / 2) + fr;
     v4d acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc[i][j][r] = (c_mode == CM_SUB) ? Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] : 0.0;
 
     const int nchunks = t.klen / GPRN_KC;
     // (de-phasing co-resident workgroups by half a chunk measured no gain; PMC: MFMA pipe busy 78 %
@@ -115,6 +108,25 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
+    // The C tile is requested AFTER the first operand chunk: memory returns in order, so the
+    // LDS staging below waits only for the chunk, and the first MFMA of each accumulator only for
+    // its own four values -- most of the 128 KiB tile streams in behind the first MFMAs.
+    __builtin_amdgcn_sched_barrier(0);
+    if (c_mode == CM_SUB) {                      // one uniform branch around all 16*MI*NI/4 loads
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] = Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16];
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+    }
+    __builtin_amdgcn_sched_barrier(0);
     {
         double* sA = lds;
         double* sB = sA + A_DOUBLES;
