@@ -618,7 +618,9 @@ int factor_invert(gprn_ctx* c, int nbatch)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
-    if (split_sched()) return factor_invert_split(c, nbatch, nbatch * c->T <= 32 ? 1 : 0);
+    static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
+    if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
+    if (split_sched()) return factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
     bool rest_pending = false, next_pending = false;
     // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
     // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.

@@ -198,6 +198,57 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
     }
 }
 
+// Every built-in but Polynomial is an even function of t_i - t_j evaluated through r*r, |r| or
+// sin/cos pairs whose signs cancel, i.e. K is symmetric to the last bit: compute the lower 64x64
+// tiles only and write each one twice, the mirror image through an LDS transpose (both writes
+// 512-byte row segments).  Halves the VALU work, which is what bounds the fill.
+template <int KID>
+__global__ __launch_bounds__(256)
+void k_fill_sym(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld,
+                const double* __restrict__ diag_add)
+{
+    __shared__ double tile[64][65];
+    // lower-triangular tile index -> (bi, bj), bi >= bj
+    const int L = blockIdx.x;
+    int bi = (int)((sqrt(8.0 * L + 1.0) - 1.0) * 0.5);
+    while ((bi + 1) * (bi + 2) / 2 <= L) ++bi;
+    while (bi * (bi + 1) / 2 > L) --bi;
+    const int bj = L - bi * (bi + 1) / 2;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = bj * 64 + tx;
+    const double tn = (n < N) ? t[n] : 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + 4 * i, m = bi * 64 + r;
+        double v;
+        if (m < N && n < N) {
+            v = eval_any<KID>(pg, t[m], tn, m == n);
+            if (m == n) {
+                if (pg.nugget) v += pg.nugget_val;
+                if (diag_add) v += diag_add[m];
+            }
+        } else {
+            v = (m == n) ? 1.0 : 0.0;
+        }
+        K[(size_t)m * ld + n] = v;
+        tile[r][tx] = v;
+    }
+    if (bi == bj) return;                          // a diagonal tile is complete as computed
+    __syncthreads();
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int r = ty + 4 * i;                  // row of the mirrored tile = column of the computed one
+        K[(size_t)(bj * 64 + r) * ld + bi * 64 + tx] = tile[tx][r];
+    }
+}
+
+static bool program_is_even(const FillProgram& pg)
+{
+    for (int o = 0; o < pg.n_ops; ++o)
+        if (pg.ops[3 * o] == GPRN_OP_PUSH && pg.ops[3 * o + 1] == GPRN_K_POLYNOMIAL) return false;
+    return true;
+}
+
 // host-side choice of the instantiation: the id of a one-kernel program, else the generic one
 #define GPRN_FOR_EACH_KID(X) \
     X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) \
@@ -225,6 +276,21 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val,
     FillProgram pg;
     make_program(ks, nugget_val, pg);
     prof_begin(c, GPRN_T_FILL);
+    static int use_sym = -1;                       // GPRN_FILL_SYM=0: always the full-matrix kernel
+    if (use_sym < 0) { const char* e = getenv("GPRN_FILL_SYM"); use_sym = e ? atoi(e) : 1; }
+    if (use_sym && program_is_even(pg)) {          // ld is a multiple of 128
+        const int nb = c->ld / 64;
+        dim3 tri(nb * (nb + 1) / 2);
+        switch (program_kid(pg)) {
+#define X(id) case id: hipLaunchKernelGGL(k_fill_sym<id>, tri, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add); break;
+        GPRN_FOR_EACH_KID(X)
+#undef X
+        default: hipLaunchKernelGGL(k_fill_sym<-1>, tri, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add);
+        }
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+        return GPRN_OK;
+    }
     dim3 grid((c->ld + 255) / 256, (c->ld + 7) / 8);
     switch (program_kid(pg)) {
 #define X(id) case id: hipLaunchKernelGGL(k_fill<id>, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add); break;
