@@ -186,6 +186,45 @@ def test_cfg3_properties_full_size():
         np.testing.assert_allclose(e_a[:2], dd['elbo_sweeps'], rtol=RTOL)
 
 
+def test_cfg5_size_factorisation_against_lapack():
+    """BASELINE config 5's matrix size (N=16384: 128 tiles, 2.1 GB per matrix, offsets beyond
+    2^31 bytes) on one node + one weight GP.  No reference value exists at this size, so the
+    blocked factor+inverse is checked against LAPACK on the SAME device-filled matrix: log det K,
+    and chol(K)^-1 u against a triangular solve; then sweeps must be finite, positive and
+    repeatable bit for bit."""
+    import scipy.linalg as sl
+    N, p, q = 16384, 1, 1
+    t, ys, es = synth.rv_series(N, p)
+    spec = synth.component_spec(p, q, 'QP')
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+    ctx = g._setup_device(nodes, weights, means, jit)
+    assert g.last_info == 0
+    ld = ctx.get_logdet_K()
+    rng = np.random.RandomState(1)
+    u = rng.standard_normal(N)
+    for gp in (0, 1):                                # node (QuasiPeriodic), weight (SquaredExponential)
+        K = ctx.get_matrix(_hip.M_K, gp)
+        assert np.array_equal(K, K.T)
+        L = np.linalg.cholesky(K)
+        np.testing.assert_allclose(ld[gp], 2 * np.log(np.diag(L)).sum(), rtol=1e-10)
+        del K
+        X = ctx.get_matrix(_hip.M_KLINV, gp)
+        want = sl.solve_triangular(L, u, lower=True, check_finite=False)
+        np.testing.assert_allclose(X @ u, want, rtol=0, atol=1e-7 * np.abs(want).max())
+        del X, L
+    mu0, var0 = g._initMuVar(nodes, weights, jit)
+    ctx.set_muvar(mu0, var0)
+    e_a, _, info = ctx.sweep(2, commit=True)
+    assert info == 0 and np.all(np.isfinite(e_a))
+    mu, var = ctx.get_muvar()
+    assert np.all(var > 0) and np.all(np.isfinite(mu))
+    ctx.set_muvar(mu0, var0)
+    e_b, _, _ = ctx.sweep(2, commit=True)
+    assert np.array_equal(e_a, e_b)
+
+
 def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     """Every collective of the sharded sweep (grouped row broadcasts, scalar all-reduce,
     barrier) executed for real on RCCL with world = 1: results must not change."""
