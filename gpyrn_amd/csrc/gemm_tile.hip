@@ -205,7 +205,11 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // for the bulk stream measured worse).  GPRN_BULK_PAD_KB overrides.
     static int pad_kb = -1;
     if (pad_kb < 0) { const char* e = getenv("GPRN_BULK_PAD_KB"); pad_kb = e ? atoi(e) : 16; }
-    const size_t dyn = (stream == c->stream2) ? (size_t)pad_kb * 1024 : 0;
+    static int pad_fams = -1;                      // GPRN_PAD_FAMS: bit per family that gets the pad (default: the
+                                                   // bulk update and the X^T X product; the next-panel launches measured
+                                                   // slightly better without it)
+    if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_LAUUM)); }
+    const size_t dyn = (stream == c->stream2 && ((pad_fams >> fam) & 1)) ? (size_t)pad_kb * 1024 : 0;
     double* const* tab = (double* const*)d_ptrs;
     switch (shape) {
     case TS_64x64:
