@@ -600,8 +600,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_rest, 0));
         if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
         HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_panel, 0));
-        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext)))) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_next, s2));
+        static int next_side = -1;                 // GPRN_NEXT_ON_SIDE=1 (experiment): next-panel update on stream3
+        if (next_side < 0) { const char* e = getenv("GPRN_NEXT_ON_SIDE"); next_side = e ? atoi(e) : 0; }
+        hipStream_t sn = next_side ? s1 : s2;
+        if (next_side) {
+            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_panel, 0));
+            if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_rest, 0));
+        }
+        if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext)))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_next, sn));
         next_pending = o.nnext > 0;
         if (o.nrest) {
             if ((rc = tiles(o.rest0, o.nrest, s2, TS_128x128, GPRN_T_UPDATE))) return rc;

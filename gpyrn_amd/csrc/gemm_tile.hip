@@ -95,7 +95,8 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     v4d acc[MI][NI];
 
     const int nchunks = t.klen / GPRN_KC;
-    // (de-phasing co-resident workgroups by half a chunk measured no gain; PMC: MFMA pipe busy 78 %
+    // (de-phasing co-resident workgroups by half a chunk and s_setprio around the MFMA clusters
+    // measured no gain; PMC: MFMA pipe busy 78 %
     // of the cycles at an effective 2.13 GHz, no LDS bank conflicts -- DESIGN.md section 8)
     // Software pipeline over K-chunks, one barrier per chunk:
     //   registers hold chunk c+1 (requested during chunk c-1 ... c), LDS stage c&1 holds chunk c.
