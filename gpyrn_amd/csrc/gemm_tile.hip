@@ -151,18 +151,32 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
         const double* sB = sA + A_DOUBLES;
         double* nA = lds + ((c + 1) & 1) * (A_DOUBLES + B_DOUBLES);
         double* nB = nA + A_DOUBLES;
+        // Operand fragments of k4-step ks+1 are fetched from LDS before the MFMAs of step ks are
+        // issued: a lone wave per SIMD (bulk launches run at one workgroup per CU) then does not
+        // drain the matrix pipe at every step waiting for its own ds_reads (44 -> 46 TF at K = 512
+        // and one workgroup per CU).  Carrying the fetch-ahead across the chunk boundary as well
+        // (barrier after the third step, first fragments of the next chunk read during the fourth)
+        // measured no further gain.
+        double af[2][MI], bf[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[0][i] = sA[a_frag + i * 16 * a_rs];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[0][j] = sB[b_frag + j * 16 * b_rs];
 #pragma unroll
         for (int ks = 0; ks < GPRN_KC / 4; ++ks) {
-            double af[MI], bf[NI];
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < GPRN_KC / 4) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = sA[a_frag + i * 16 * a_rs + ks * 4 * a_ks];
+                for (int i = 0; i < MI; ++i) af[nxt][i] = sA[a_frag + i * 16 * a_rs + (ks + 1) * 4 * a_ks];
 #pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = sB[b_frag + j * 16 * b_rs + ks * 4 * b_ks];
+                for (int j = 0; j < NI; ++j) bf[nxt][j] = sB[b_frag + j * 16 * b_rs + (ks + 1) * 4 * b_ks];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
             if (ks == 1 && c + 1 < nchunks) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -210,7 +224,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
                                                    // bulk update and the X^T X product; the next-panel launches measured
                                                    // slightly better without it)
     if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_LAUUM)); }
-    const size_t dyn = (stream == c->stream2 && ((pad_fams >> fam) & 1)) ? (size_t)pad_kb * 1024 : 0;
+    static int pad_all = -1;                       // GPRN_PAD_ALL=1 (probes): pad on every stream
+    if (pad_all < 0) { const char* e = getenv("GPRN_PAD_ALL"); pad_all = e ? atoi(e) : 0; }
+    const size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)pad_kb * 1024 : 0;
     double* const* tab = (double* const*)d_ptrs;
     switch (shape) {
     case TS_64x64:
