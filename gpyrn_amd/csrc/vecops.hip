@@ -110,22 +110,28 @@ void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __
     const double* sv = s + (size_t)slot * ld;
     const int n = tj * GPRN_TILE + 2 * (threadIdx.x & 63);
     const double s0 = sv[n], s1 = sv[n + 1];
-    for (int it = 0; it < 32; ++it) {
-        const int m = ti * GPRN_TILE + (threadIdx.x >> 6) + 4 * it;
-        const size_t o = (size_t)m * ld + n;
-        v2d out;
-        if (m < N) {
-            const v2d kv = *reinterpret_cast<const v2d*>(K + o);
-            const double sm = sv[m];
-            out.x = (n < N) ? sm * s0 * kv.x : 0.0;
-            out.y = (n + 1 < N) ? sm * s1 * kv.y : 0.0;
-        } else {
-            out.x = 0.0;
-            out.y = 0.0;
+    // four rows per pass, all loads issued before the first store: a thread keeps 64 B in flight
+    // instead of 16 (the kernel is latency-limited otherwise: 3.4 TB/s)
+    for (int it0 = 0; it0 < 32; it0 += 4) {
+        v2d kv[4];
+        double sm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = ti * GPRN_TILE + (threadIdx.x >> 6) + 4 * (it0 + u);
+            const bool in = m < N;
+            kv[u] = in ? *reinterpret_cast<const v2d*>(K + (size_t)m * ld + n) : v2d{0.0, 0.0};
+            sm[u] = in ? sv[m] : 0.0;
         }
-        if (m == n) out.x += 1.0;
-        if (m == n + 1) out.y += 1.0;
-        *reinterpret_cast<v2d*>(B + o) = out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int m = ti * GPRN_TILE + (threadIdx.x >> 6) + 4 * (it0 + u);
+            v2d out;
+            out.x = (n < N) ? sm[u] * s0 * kv[u].x : 0.0;
+            out.y = (n + 1 < N) ? sm[u] * s1 * kv[u].y : 0.0;
+            if (m == n) out.x += 1.0;
+            if (m == n + 1) out.y += 1.0;
+            *reinterpret_cast<v2d*>(B + (size_t)m * ld + n) = out;
+        }
     }
 }
 
@@ -180,10 +186,19 @@ void k_colops_partial(double* const* __restrict__ ptrs, int ld, int T,
     const double* uv = u + (size_t)slot * ld;
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     double cs = 0.0, ct = 0.0;
-    for (int r = ch * GPRN_TILE + rl; r < (ch + 1) * GPRN_TILE; r += 4) {
-        const double x = X[(size_t)r * ld + c0 + cl];
-        cs += x * x;
-        ct += x * uv[r];
+    // eight rows per pass, loads first (latency-limited otherwise); accumulation order unchanged
+    for (int r0 = ch * GPRN_TILE + rl; r0 < (ch + 1) * GPRN_TILE; r0 += 32) {
+        double x[8], w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            x[k] = X[(size_t)(r0 + 4 * k) * ld + c0 + cl];
+            w[k] = uv[r0 + 4 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cs += x[k] * x[k];
+            ct += x[k] * w[k];
+        }
     }
     shs[rl][cl] = cs;
     sht[rl][cl] = ct;
