@@ -187,6 +187,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     comm_teardown(c);
     free_problem(c);
     dev_free(c->d_tasks);
+    if (c->d_sig) hipFree(c->d_sig);
     dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
     hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream3);

@@ -253,7 +253,8 @@ __device__ __forceinline__ v4d get16(const double* __restrict__ T)
 // the diagonal sub-tile as they stood after update(kb-1), both published to LDS in phase kb-1,
 // so the 16-pivot chains (the serial part) never wait for the bulk of the update.
 __global__ __launch_bounds__(256)
-void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info)
+void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info,
+                  unsigned* sig_slot, unsigned sig_value)
 {
     __shared__ __attribute__((aligned(16))) double PA[2 * 128 * PP];   // published column panels (by parity)
     __shared__ __attribute__((aligned(16))) double PB[128 * PP];       // current column after scaling by X_kb^T
@@ -394,14 +395,16 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
             }
         }
     }
+    signal_done(sig_slot, sig_value);
 }
 
-int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream)
+int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
+                Signal sig)
 {
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
     hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, stream,
-                       (double* const*)d_ptrs, ld, kblk, d_info);
+                       (double* const*)d_ptrs, ld, kblk, d_info, sig.slot, sig.value);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -552,72 +555,98 @@ int ensure_tasks(gprn_ctx* c)
 static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
 {
     int rc;
-    bool rest_pending = false, next_pending = false;
     hipStream_t s0 = c->stream, s1 = c->stream3, s2 = c->stream2;
     static size_t big = 0;                         // tasks x batch above which 128x128 workgroups pay
     if (!big) { const char* e = getenv("GPRN_FEW_TASKS"); big = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
     auto shape_upd = [&](size_t n) { return n * (size_t)nbatch > big ? TS_128x128 : TS_64x64; };
-    auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL) {
-        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape);
+    auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL,
+                     Signal sig = Signal{nullptr, 0}) {
+        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig);
     };
+    // Cross-stream dependencies travel through 32-bit flags in device memory instead of events:
+    // hipStreamWriteValue32 / hipStreamWaitValue32 cost less than an event record / wait pair
+    // (+3 % sweeps/s at N = 4096, +14 % at N = 2048), and the chain's two small kernels raise
+    // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
+    // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
+    static int use_flags = -1;
+    if (use_flags < 0) { const char* e = getenv("GPRN_FLAGS"); use_flags = e ? atoi(e) : 1; }
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_KINDS };
+    if (use_flags && c->sig_T < c->T) {
+        if (c->d_sig) hipFree(c->d_sig);
+        c->d_sig = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_sig, (size_t)c->T * F_KINDS * 2 * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_sig, 0, (size_t)c->T * F_KINDS * 2 * sizeof(unsigned)));
+        c->sig_T = c->T;
+        c->epoch = 0;
+    }
+    const unsigned epoch = ++c->epoch;
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest};
+    auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
+    auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
+        return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
+    };
+    auto raise = [&](hipStream_t st, int idx, int kind) {
+        return use_flags ? hipStreamWriteValue32(st, slot(idx, kind) + 1, epoch, 0) : hipEventRecord(events[kind], st);
+    };
+    auto await = [&](hipStream_t st, int idx, int kind) {
+        return use_flags ? hipStreamWaitValue32(st, slot(idx, kind) + 1, epoch, hipStreamWaitValueGte, 0xffffffffu)
+                         : hipStreamWaitEvent(st, events[kind], 0);
+    };
+    int rest_J = -1, next_J = -1;                  // outer panels whose rest / next update is not joined yet
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
             const gprn_ctx::StepRange& s = c->steps[set][k];
-            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
-            if (k > o.k0) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_inner, 0));
-            if (k == o.k1 - 1) {                       // no in-panel columns right of the last step
+            const bool last = (k == o.k1 - 1);     // no in-panel columns right of the last step
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0,
+                                  last ? Signal{nullptr, 0} : in_kernel(k, F_DIAG)))) return rc;
+            if (k > o.k0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            if (last) {
                 if ((rc = tiles(s.panel0, s.npanel_l, s0, TS_64x128))) return rc;
                 if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s0, TS_128x64))) return rc;
                 continue;
             }
-            HIP_TRY(c, hipEventRecord(c->ev_diag, s0));
+            if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             // chain: L_{k+1,k}, then B_{k+1,k+1}
-            if ((rc = tiles(s.panel0, 1, s0, TS_64x128))) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_minil, s0));
+            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL)))) return rc;
+            if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
             if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
-            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_diag, 0));
+            HIP_TRY(c, await(s1, k, F_DIAG));
             if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
             if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
-            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_minil, 0));
-            if (next_pending) {                        // the other columns / rows of this panel
-                HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_next, 0));
-                next_pending = false;
+            HIP_TRY(c, await(s1, k, F_MINIL));
+            if (next_J >= 0) {                         // the other columns / rows of this panel
+                HIP_TRY(c, await(s1, next_J, F_NEXT));
+                next_J = -1;
             }
+            // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write)
             if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_inner, s1));
+            HIP_TRY(c, raise(s1, k, F_INNER));
         }
-        if (next_pending) {                            // one-step panel: nothing consumed it yet
-            HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_next, 0));
-            next_pending = false;
+        if (next_J >= 0) {                             // one-step panel: nothing consumed it yet
+            HIP_TRY(c, await(s0, next_J, F_NEXT));
+            next_J = -1;
         }
         if (o.nfirst + o.nnext + o.nrest == 0) continue;
         // Outer update of panel J.  On the chain stream what the chain touches in the next panel
         // (its first column of B and first row of R, its diagonal and sub-diagonal tiles); the
         // rest of the next panel and everything beyond go to the bulk stream.
-        HIP_TRY(c, hipEventRecord(c->ev_panel, s0));
-        if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_rest, 0));
+        HIP_TRY(c, raise(s0, (int)J, F_PANEL));
+        if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
         if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
-        HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_panel, 0));
-        static int next_side = -1;                 // GPRN_NEXT_ON_SIDE=1 (experiment): next-panel update on stream3
-        if (next_side < 0) { const char* e = getenv("GPRN_NEXT_ON_SIDE"); next_side = e ? atoi(e) : 0; }
-        hipStream_t sn = next_side ? s1 : s2;
-        if (next_side) {
-            HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_panel, 0));
-            if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_rest, 0));
-        }
-        if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext)))) return rc;
-        HIP_TRY(c, hipEventRecord(c->ev_next, sn));
-        next_pending = o.nnext > 0;
+        HIP_TRY(c, await(s2, (int)J, F_PANEL));
+        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext)))) return rc;
+        HIP_TRY(c, raise(s2, (int)J, F_NEXT));
+        if (o.nnext > 0) next_J = (int)J;
         if (o.nrest) {
             if ((rc = tiles(o.rest0, o.nrest, s2, TS_128x128, GPRN_T_UPDATE))) return rc;
-            HIP_TRY(c, hipEventRecord(c->ev_rest, s2));
-            rest_pending = true;
+            HIP_TRY(c, raise(s2, (int)J, F_REST));
+            rest_J = (int)J;
         }
     }
-    if (next_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_next, 0));
-    if (rest_pending) HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_rest, 0));
+    if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
+    if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
     return GPRN_OK;
 }
 

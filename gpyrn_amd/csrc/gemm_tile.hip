@@ -35,7 +35,8 @@ typedef const GPRN_GLOBAL v2d* gv2d_t;
 //   64x64                for everything that is not in place.
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2)
-void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld)
+void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
+                 unsigned* sig_slot, unsigned sig_value)
 {
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
     constexpr int MI = BM / 32, NI = BN / 32;                   // 16x16 MFMA tiles per wave (2x2 waves)
@@ -205,13 +206,17 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = acc[i][j][r];
+    signal_done(sig_slot, sig_value);
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream, int shape)
+                 int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig)
 {
-    if (ntasks == 0 || nbatch == 0) return GPRN_OK;
     if (!stream) stream = c->stream;
+    if (ntasks == 0 || nbatch == 0) {              // nothing to wait for: raise the flag from the stream
+        if (sig.slot) HIP_TRY(c, hipStreamWriteValue32(stream, sig.slot + 1, sig.value, 0));
+        return GPRN_OK;
+    }
     prof_begin(c, fam, stream);
     // Bulk launches on the look-ahead stream ask for 16 KiB of unused dynamic LDS on top of the
     // 72 KiB image: one workgroup per CU instead of two.  Workgroups are never preempted and stream
@@ -231,19 +236,19 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     switch (shape) {
     case TS_64x64:
         hipLaunchKernelGGL((k_tile_gemm<64, 64>), dim3((unsigned)ntasks * 4, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
         break;
     case TS_64x128:
         hipLaunchKernelGGL((k_tile_gemm<64, 128>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
         break;
     case TS_128x64:
         hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
         break;
     default:
         hipLaunchKernelGGL((k_tile_gemm<128, 128>), dim3((unsigned)ntasks, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
     }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -137,6 +137,9 @@ struct gprn_ctx {
     size_t test_cap[3] = {0, 0, 0};
     // tile-task lists for the factorisation at the current T (device)
     TileTask* d_tasks = nullptr;
+    unsigned* d_sig = nullptr;       // completion signals of the chain: (tile step, kind) -> {counter, flag}
+    int sig_T = 0;
+    unsigned epoch = 0;              // value the flags take in the current factor_invert call
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
@@ -159,10 +162,33 @@ int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const
                      int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
 enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
+// Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
+// finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
+// picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
+// record packet behind the kernel, no event wait packet on the consumer.
+struct Signal { unsigned* slot; unsigned value; };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128);
+                 int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
+                 Signal sig = Signal{nullptr, 0});
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
-                hipStream_t stream = nullptr);
+                hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0});
+
+#ifdef __HIPCC__
+// end of a kernel: every thread of the workgroup calls it
+__device__ __forceinline__ void signal_done(unsigned* slot, unsigned value)
+{
+    if (!slot) return;                              // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                            // this workgroup's writes, agent scope
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (atomicAdd(slot, 1u) + 1 == total) {
+            atomicExch(slot, 0u);
+            __hip_atomic_store(slot + 1, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+#endif
 // factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
 int factor_invert(gprn_ctx* c, int nbatch);
 int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
