@@ -161,6 +161,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_diag, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_first, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_minil, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
@@ -192,6 +193,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream3);
     hipEventDestroy(c->ev_diag);
+    hipEventDestroy(c->ev_first);
     hipEventDestroy(c->ev_minil);
     hipEventDestroy(c->ev_inner);
     hipStreamDestroy(c->stream3);

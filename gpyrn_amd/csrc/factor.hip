@@ -431,12 +431,13 @@ static inline int64_t toff(int ti, int tj, int ld) {
 // can run while the rest streams on a second HIP stream.
 // GPRN_SCHED=1: every in-panel launch on the chain stream; default (2): split schedule, see
 // factor_invert_split
-static bool split_sched()
+static int sched_mode()
 {
     static int mode = 0;
-    if (!mode) { const char* e = getenv("GPRN_SCHED"); mode = e && atoi(e) == 1 ? 1 : 2; }
-    return mode == 2;
+    if (!mode) { const char* e = getenv("GPRN_SCHED"); mode = e && atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3; }
+    return mode;
 }
+static bool split_sched() { return sched_mode() >= 2; }
 
 int ensure_tasks(gprn_ctx* c)
 {
@@ -479,20 +480,23 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
             s.nupd = v.size() - s.upd0;
         }
-        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0};
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
         // pass 0 ("first"): the next panel's first column of B / first row of R -- what its first
         // tile step needs -- and, in the split schedule, the next panel's diagonal and sub-diagonal
         // tiles (the chain stream owns those); pass 1 ("next"): the rest of the next panel's
         // columns / rows; pass 2 ("rest"): everything beyond
-        const bool split = split_sched();
+        // GPRN_SCHED=3 cuts "first" once more: pass -1 ("c1") = B tiles (k1,k1) and (k1+1,k1), all the
+        // chain needs before the next diagonal block; the rest of "first" then runs on stream3
+        const bool split = split_sched(), lean = sched_mode() == 3;
         auto clsB = [&](int i, int j) {
+            if (lean && j == k1 && i <= k1 + 1) return -1;
             if (j == k1 || (split && j < n1 && i <= j + 1)) return 0;
             return j < n1 ? 1 : 2;
         };
         auto clsR = [&](int i) { return i == k1 ? 0 : (i < n1 ? 1 : 2); };
-        for (int pass = 0; pass < 3; ++pass) {
+        for (int pass = -1; pass < 3; ++pass) {
             const size_t begin = v.size();
             for (int i = k1; i < T; ++i) {
                 for (int j = k1; j <= i; ++j) {
@@ -509,7 +513,8 @@ int ensure_tasks(gprn_ctx* c)
                                          (k1 - cc) * GPRN_TILE, BUF_X, BUF_B, BUF_X,
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
-            if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
+            if (pass == -1) { o.c1_0 = begin; o.nc1 = v.size() - begin; }
+            else if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
             else if (pass == 1) { o.next0 = begin; o.nnext = v.size() - begin; }
             else {
                 // Workgroups are dispatched in task order and are not preempted: with the short
@@ -570,7 +575,8 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     static int use_flags = -1;
     if (use_flags < 0) { const char* e = getenv("GPRN_FLAGS"); use_flags = e ? atoi(e) : 1; }
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_KINDS };
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_KINDS };
+    const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
         c->d_sig = nullptr;
@@ -580,7 +586,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         c->epoch = 0;
     }
     const unsigned epoch = ++c->epoch;
-    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest};
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
@@ -592,15 +598,28 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         return use_flags ? hipStreamWaitValue32(st, slot(idx, kind) + 1, epoch, hipStreamWaitValueGte, 0xffffffffu)
                          : hipStreamWaitEvent(st, events[kind], 0);
     };
-    int rest_J = -1, next_J = -1;                  // outer panels whose rest / next update is not joined yet
+    int rest_J = -1, next_J = -1, first_J = -1;    // outer panels whose rest / next / first update is not joined yet
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
             const gprn_ctx::StepRange& s = c->steps[set][k];
             const bool last = (k == o.k1 - 1);     // no in-panel columns right of the last step
+            const bool outer_follows = o.nc1 + o.nfirst + o.nnext + o.nrest > 0;
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0,
-                                  last ? Signal{nullptr, 0} : in_kernel(k, F_DIAG)))) return rc;
+                                  last && !(lean && outer_follows) ? Signal{nullptr, 0} : in_kernel(k, F_DIAG)))) return rc;
             if (k > o.k0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            if (last && lean && outer_follows) {
+                // chain: the two panel rows the c1 update reads; stream3: the rest of the panel
+                const size_t nmini = std::min<size_t>(2, s.npanel_l);
+                if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
+                if ((rc = tiles(s.panel0, nmini, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL)))) return rc;
+                if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
+                HIP_TRY(c, await(s1, k, F_DIAG));
+                if ((rc = tiles(s.panel0 + nmini, s.npanel_l - nmini, s1, TS_64x128))) return rc;
+                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
+                HIP_TRY(c, await(s1, k, F_MINIL));
+                continue;
+            }
             if (last) {
                 if ((rc = tiles(s.panel0, s.npanel_l, s0, TS_64x128))) return rc;
                 if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s0, TS_128x64))) return rc;
@@ -610,6 +629,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // chain: L_{k+1,k}, then B_{k+1,k+1}
             if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL)))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
+            if (first_J >= 0) {                        // B_{k+1,k+1} carries the previous panel's update
+                HIP_TRY(c, await(s0, first_J, F_FIRST));
+                first_J = -1;
+            }
             if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
             HIP_TRY(c, await(s1, k, F_DIAG));
@@ -628,13 +651,30 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             HIP_TRY(c, await(s0, next_J, F_NEXT));
             next_J = -1;
         }
-        if (o.nfirst + o.nnext + o.nrest == 0) continue;
+        if (first_J >= 0) {                            // (a one-step panel)
+            HIP_TRY(c, await(s0, first_J, F_FIRST));
+            first_J = -1;
+        }
+        if (o.nc1 + o.nfirst + o.nnext + o.nrest == 0) continue;
         // Outer update of panel J.  On the chain stream what the chain touches in the next panel
         // (its first column of B and first row of R, its diagonal and sub-diagonal tiles); the
         // rest of the next panel and everything beyond go to the bulk stream.
-        HIP_TRY(c, raise(s0, (int)J, F_PANEL));
-        if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
-        if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
+        if (lean) {
+            // chain: the two tiles the next diagonal block and L_{k1+1,k1} need; stream3 (which has
+            // the whole panel once it has seen the chain's two rows): everything else of "first"
+            if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
+            if ((rc = tiles(o.c1_0, o.nc1, s0, TS_64x64))) return rc;
+            HIP_TRY(c, raise(s1, (int)J, F_PANEL));
+            if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, F_REST));
+            if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+            if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst)))) return rc;
+            HIP_TRY(c, raise(s1, (int)J, F_FIRST));
+            if (o.nfirst > 0) first_J = (int)J;
+        } else {
+            HIP_TRY(c, raise(s0, (int)J, F_PANEL));
+            if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
+            if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
+        }
         HIP_TRY(c, await(s2, (int)J, F_PANEL));
         if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext)))) return rc;
         HIP_TRY(c, raise(s2, (int)J, F_NEXT));
@@ -645,6 +685,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             rest_J = (int)J;
         }
     }
+    if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
     return GPRN_OK;

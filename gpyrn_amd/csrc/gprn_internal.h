@@ -74,7 +74,7 @@ struct gprn_ctx {
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
     hipStream_t stream3 = nullptr;   // in-panel work that is off the chain (panel rest, inner rest)
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
-    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
     hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;
@@ -146,7 +146,7 @@ struct gprn_ctx {
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
-    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest; };  // per outer panel of GPRN_OUTER tiles
+    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1; };  // per outer panel of GPRN_OUTER tiles
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
