@@ -811,6 +811,7 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
         if (comm_active(c)) TRY(comm_allreduce(c, c->d_logdetK, c->G));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    TRY(factor_check_waits(c));
     c->factored = true;
     return first_info;
 }
@@ -924,6 +925,7 @@ extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_ou
         elbo_out[it] = h[4 * it];
         if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];
     }
+    TRY(factor_check_waits(c));
     int first = 0;
     c->info_gp = -1;
     TRY(check_info(c, c->d_info + (size_t)c->nslot, c->loc_nodes, &first));

@@ -565,8 +565,8 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (!big) { const char* e = getenv("GPRN_FEW_TASKS"); big = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
     auto shape_upd = [&](size_t n) { return n * (size_t)nbatch > big ? TS_128x128 : TS_64x64; };
     auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL,
-                     Signal sig = Signal{nullptr, 0}) {
-        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig);
+                     Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr}) {
+        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, aw);
     };
     // Cross-stream dependencies travel through 32-bit flags in device memory instead of events:
     // hipStreamWriteValue32 / hipStreamWaitValue32 cost less than an event record / wait pair
@@ -576,12 +576,13 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     static int use_flags = -1;
     if (use_flags < 0) { const char* e = getenv("GPRN_FLAGS"); use_flags = e ? atoi(e) : 1; }
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_KINDS };
+    static_assert(F_KINDS == 7, "factor_check_waits reads the word behind T * 7 flag pairs");
     const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
         c->d_sig = nullptr;
-        HIP_TRY(c, hipMalloc(&c->d_sig, (size_t)c->T * F_KINDS * 2 * sizeof(unsigned)));
-        HIP_TRY(c, hipMemset(c->d_sig, 0, (size_t)c->T * F_KINDS * 2 * sizeof(unsigned)));
+        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
         c->sig_T = c->T;
         c->epoch = 0;
     }
@@ -593,6 +594,11 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     };
     auto raise = [&](hipStream_t st, int idx, int kind) {
         return use_flags ? hipStreamWriteValue32(st, slot(idx, kind) + 1, epoch, 0) : hipEventRecord(events[kind], st);
+    };
+    // the chain's L_{k+1,k} launch (2 workgroups per matrix) waits for stream3's flag itself: the
+    // stream wait is a 5 us kernel of its own on this runtime (__amd_rocclr_streamOpsWait)
+    auto in_kernel_wait = [&](int idx, int kind) {
+        return Await{slot(idx, kind) + 1, epoch, c->d_sig + (size_t)c->sig_T * F_KINDS * 2};
     };
     auto await = [&](hipStream_t st, int idx, int kind) {
         return use_flags ? hipStreamWaitValue32(st, slot(idx, kind) + 1, epoch, hipStreamWaitValueGte, 0xffffffffu)
@@ -607,12 +613,14 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             const bool outer_follows = o.nc1 + o.nfirst + o.nnext + o.nrest > 0;
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0,
                                   last && !(lean && outer_follows) ? Signal{nullptr, 0} : in_kernel(k, F_DIAG)))) return rc;
-            if (k > o.k0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            const bool spin = use_flags && k > o.k0 && (!last || (lean && outer_follows));
+            const Await inner_done = spin ? in_kernel_wait(k - 1, F_INNER) : Await{nullptr, 0, nullptr};
+            if (k > o.k0 && !spin) HIP_TRY(c, await(s0, k - 1, F_INNER));
             if (last && lean && outer_follows) {
                 // chain: the two panel rows the c1 update reads; stream3: the rest of the panel
                 const size_t nmini = std::min<size_t>(2, s.npanel_l);
                 if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
-                if ((rc = tiles(s.panel0, nmini, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL)))) return rc;
+                if ((rc = tiles(s.panel0, nmini, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), inner_done))) return rc;
                 if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
                 HIP_TRY(c, await(s1, k, F_DIAG));
                 if ((rc = tiles(s.panel0 + nmini, s.npanel_l - nmini, s1, TS_64x128))) return rc;
@@ -627,7 +635,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             }
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             // chain: L_{k+1,k}, then B_{k+1,k+1}
-            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL)))) return rc;
+            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), inner_done))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
             if (first_J >= 0) {                        // B_{k+1,k+1} carries the previous panel's update
                 HIP_TRY(c, await(s0, first_J, F_FIRST));
@@ -688,6 +696,20 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
+    return GPRN_OK;
+}
+
+// a dependency wait inside a chain kernel gave up (see Await): the results of that call are void
+int factor_check_waits(gprn_ctx* c)
+{
+    if (!c->d_sig) return GPRN_OK;
+    unsigned flag = 0;
+    HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * 7 * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (flag) {
+        hipMemset(c->d_sig + (size_t)c->sig_T * 7 * 2, 0, sizeof(unsigned));
+        c->err = "factorisation: a device-side dependency wait timed out";
+        return GPRN_E_HIP;
+    }
     return GPRN_OK;
 }
 

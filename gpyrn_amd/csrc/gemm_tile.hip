@@ -36,8 +36,10 @@ typedef const GPRN_GLOBAL v2d* gv2d_t;
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
-                 unsigned* sig_slot, unsigned sig_value)
+                 unsigned* sig_slot, unsigned sig_value,
+                 const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out)
 {
+    await_flag(wait_flag, wait_value, wait_timed_out);
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
     constexpr int MI = BM / 32, NI = BN / 32;                   // 16x16 MFMA tiles per wave (2x2 waves)
     constexpr int A_DOUBLES = 16 * BM + 256, B_DOUBLES = 16 * BN + 256;   // >= BM*18 and 16*(BM+16)
@@ -210,7 +212,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig)
+                 int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig, Await aw)
 {
     if (!stream) stream = c->stream;
     if (ntasks == 0 || nbatch == 0) {              // nothing to wait for: raise the flag from the stream
@@ -236,19 +238,19 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     switch (shape) {
     case TS_64x64:
         hipLaunchKernelGGL((k_tile_gemm<64, 64>), dim3((unsigned)ntasks * 4, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
         break;
     case TS_64x128:
         hipLaunchKernelGGL((k_tile_gemm<64, 128>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
         break;
     case TS_128x64:
         hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
         break;
     default:
         hipLaunchKernelGGL((k_tile_gemm<128, 128>), dim3((unsigned)ntasks, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

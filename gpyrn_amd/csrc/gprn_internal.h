@@ -167,13 +167,31 @@ enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
 // record packet behind the kernel, no event wait packet on the consumer.
 struct Signal { unsigned* slot; unsigned value; };
+// The other direction, for launches of a FEW workgroups only (a spinning launch that fills the GPU
+// could keep its own producer from being dispatched): every workgroup of the launch waits at its
+// start until *flag >= value; a wait that times out (about a second) sets *timed_out and goes on.
+struct Await { const unsigned* flag; unsigned value; unsigned* timed_out; };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
-                 Signal sig = Signal{nullptr, 0});
+                 Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr});
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0});
 
 #ifdef __HIPCC__
+// start of a kernel: every thread of the workgroup calls it
+__device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out)
+{
+    if (!flag) return;                              // uniform
+    if (threadIdx.x == 0) {
+        long spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1L << 24)) { atomicExch(timed_out, 1u); break; }
+        }
+    }
+    __syncthreads();
+}
+
 // end of a kernel: every thread of the workgroup calls it
 __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value)
 {
@@ -193,3 +211,4 @@ __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value)
 int factor_invert(gprn_ctx* c, int nbatch);
 int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
 int ensure_tasks(gprn_ctx* c);
+int factor_check_waits(gprn_ctx* c);   // error if an in-kernel dependency wait timed out since the last check
