@@ -395,7 +395,7 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
             }
         }
     }
-    signal_done(sig_slot, sig_value);
+    signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
@@ -550,6 +550,18 @@ int ensure_tasks(gprn_ctx* c)
     return GPRN_OK;
 }
 
+// One thread on a stream: raise a flag for whoever waits on the work before it, then hold the stream
+// until another flag is up -- a stream write and a stream wait of the runtime (two 5 us kernels) in one.
+__global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const unsigned* wait_flag,
+                            unsigned wait_value, unsigned* timed_out)
+{
+    if (threadIdx.x != 0) return;
+    if (raise_flag) __hip_atomic_store(raise_flag, raise_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (wait_flag) spin_until(wait_flag, wait_value, timed_out);
+}
+
+#define GPRN_FLAG_KINDS 8           // flag kinds per tile step / outer panel (factor_invert_split)
+
 // Split schedule.  Per tile step k the only launches on the chain stream are the diagonal
 // block, the ONE panel tile below it (L_{k+1,k}) and the ONE in-panel update that completes the
 // next diagonal tile (B_{k+1,k+1}); the remaining panel tiles and in-panel updates of the step run on
@@ -575,8 +587,8 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     static int use_flags = -1;
     if (use_flags < 0) { const char* e = getenv("GPRN_FLAGS"); use_flags = e ? atoi(e) : 1; }
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_KINDS };
-    static_assert(F_KINDS == 7, "factor_check_waits reads the word behind T * 7 flag pairs");
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
+    static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
@@ -587,7 +599,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         c->epoch = 0;
     }
     const unsigned epoch = ++c->epoch;
-    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first};
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
@@ -605,6 +617,34 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                          : hipStreamWaitEvent(st, events[kind], 0);
     };
     int rest_J = -1, next_J = -1, first_J = -1;    // outer panels whose rest / next / first update is not joined yet
+    int inner_k = -1;                              // tile step whose F_INNER flag stream3 still has to raise
+    unsigned* timed_out = c->d_sig ? c->d_sig + (size_t)c->sig_T * F_KINDS * 2 : nullptr;
+    // stream3 at the start of step k: raise F_INNER of the step before, then wait for diag(k)
+    auto side_sync = [&](int k) -> int {
+        if (!use_flags) {
+            if (inner_k >= 0) HIP_TRY(c, raise(s1, inner_k, F_INNER));
+            inner_k = -1;
+            HIP_TRY(c, await(s1, k, F_DIAG));
+            return GPRN_OK;
+        }
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, s1,
+                           inner_k >= 0 ? slot(inner_k, F_INNER) + 1 : (unsigned*)nullptr, epoch,
+                           (const unsigned*)(slot(k, F_DIAG) + 1), epoch, timed_out);
+        inner_k = -1;
+        HIP_TRY(c, hipGetLastError());
+        return GPRN_OK;
+    };
+    auto flush_inner = [&]() -> int {              // nothing else follows on stream3 soon
+        if (inner_k >= 0) HIP_TRY(c, raise(s1, inner_k, F_INNER));
+        inner_k = -1;
+        return GPRN_OK;
+    };
+    // the X part of the panel is a small launch: its last workgroup holds it open until L_{k+1,k} is
+    // there, so the in-panel updates behind it need no stream wait
+    auto x_part_then = [&](int k) {
+        return use_flags ? Signal{slot(k, F_XW), 0, slot(k, F_MINIL) + 1, epoch, timed_out}
+                         : Signal{nullptr, 0, nullptr, 0, nullptr};
+    };
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
@@ -622,13 +662,19 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
                 if ((rc = tiles(s.panel0, nmini, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), inner_done))) return rc;
                 if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
-                HIP_TRY(c, await(s1, k, F_DIAG));
+                if ((rc = side_sync(k))) return rc;
                 if ((rc = tiles(s.panel0 + nmini, s.npanel_l - nmini, s1, TS_64x128))) return rc;
-                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
-                HIP_TRY(c, await(s1, k, F_MINIL));
+                if (s.npanel > s.npanel_l && use_flags) {
+                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
+                                    x_part_then(k)))) return rc;
+                } else {
+                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
+                    HIP_TRY(c, await(s1, k, F_MINIL));
+                }
                 continue;
             }
             if (last) {
+                if ((rc = flush_inner())) return rc;
                 if ((rc = tiles(s.panel0, s.npanel_l, s0, TS_64x128))) return rc;
                 if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s0, TS_128x64))) return rc;
                 continue;
@@ -643,18 +689,25 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             }
             if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
-            HIP_TRY(c, await(s1, k, F_DIAG));
+            if ((rc = side_sync(k))) return rc;
             if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
-            if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
-            HIP_TRY(c, await(s1, k, F_MINIL));
+            if (s.npanel > s.npanel_l && use_flags) {
+                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
+                                x_part_then(k)))) return rc;
+            } else {
+                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
+                HIP_TRY(c, await(s1, k, F_MINIL));
+            }
             if (next_J >= 0) {                         // the other columns / rows of this panel
                 HIP_TRY(c, await(s1, next_J, F_NEXT));
                 next_J = -1;
             }
-            // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write)
+            // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write;
+            // the flag goes up with stream3's next synchronisation kernel)
             if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
-            HIP_TRY(c, raise(s1, k, F_INNER));
+            inner_k = k;
         }
+        if ((rc = flush_inner())) return rc;
         if (next_J >= 0) {                             // one-step panel: nothing consumed it yet
             HIP_TRY(c, await(s0, next_J, F_NEXT));
             next_J = -1;
@@ -704,9 +757,9 @@ int factor_check_waits(gprn_ctx* c)
 {
     if (!c->d_sig) return GPRN_OK;
     unsigned flag = 0;
-    HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * 7 * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (flag) {
-        hipMemset(c->d_sig + (size_t)c->sig_T * 7 * 2, 0, sizeof(unsigned));
+        hipMemset(c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0, sizeof(unsigned));
         c->err = "factorisation: a device-side dependency wait timed out";
         return GPRN_E_HIP;
     }

@@ -36,7 +36,7 @@ typedef const GPRN_GLOBAL v2d* gv2d_t;
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
-                 unsigned* sig_slot, unsigned sig_value,
+                 unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out)
 {
     await_flag(wait_flag, wait_value, wait_timed_out);
@@ -208,7 +208,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = acc[i][j][r];
-    signal_done(sig_slot, sig_value);
+    signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
@@ -238,19 +238,23 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     switch (shape) {
     case TS_64x64:
         hipLaunchKernelGGL((k_tile_gemm<64, 64>), dim3((unsigned)ntasks * 4, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
         break;
     case TS_64x128:
         hipLaunchKernelGGL((k_tile_gemm<64, 128>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
         break;
     case TS_128x64:
         hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
         break;
     default:
         hipLaunchKernelGGL((k_tile_gemm<128, 128>), dim3((unsigned)ntasks, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
     }
     prof_end(c);
     HIP_TRY(c, hipGetLastError());

@@ -166,43 +166,54 @@ enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
 // record packet behind the kernel, no event wait packet on the consumer.
-struct Signal { unsigned* slot; unsigned value; };
+struct Signal {
+    unsigned* slot; unsigned value;                // value 0: count the workgroups only, raise nothing
+    // optionally the last workgroup then holds the launch open until *then_wait >= then_value: the
+    // next launch of the stream starts behind that flag without a stream wait of its own
+    const unsigned* then_wait; unsigned then_value; unsigned* timed_out;
+};
 // The other direction, for launches of a FEW workgroups only (a spinning launch that fills the GPU
 // could keep its own producer from being dispatched): every workgroup of the launch waits at its
 // start until *flag >= value; a wait that times out (about a second) sets *timed_out and goes on.
 struct Await { const unsigned* flag; unsigned value; unsigned* timed_out; };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
-                 Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr});
+                 Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr});
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
-                hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0});
+                hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
+// spin of ONE thread until *flag >= value; gives up after about a second
+__device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value, unsigned* timed_out)
+{
+    long spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1L << 24)) { atomicExch(timed_out, 1u); break; }
+    }
+}
+
 // start of a kernel: every thread of the workgroup calls it
 __device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out)
 {
     if (!flag) return;                              // uniform
-    if (threadIdx.x == 0) {
-        long spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1L << 24)) { atomicExch(timed_out, 1u); break; }
-        }
-    }
+    if (threadIdx.x == 0) spin_until(flag, value, timed_out);
     __syncthreads();
 }
 
 // end of a kernel: every thread of the workgroup calls it
-__device__ __forceinline__ void signal_done(unsigned* slot, unsigned value)
+__device__ __forceinline__ void signal_done(unsigned* slot, unsigned value, const unsigned* then_wait,
+                                            unsigned then_value, unsigned* timed_out)
 {
     if (!slot) return;                              // uniform
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                            // this workgroup's writes, agent scope
+        if (value) __threadfence();                 // this workgroup's writes, agent scope
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
         if (atomicAdd(slot, 1u) + 1 == total) {
             atomicExch(slot, 0u);
-            __hip_atomic_store(slot + 1, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (value) __hip_atomic_store(slot + 1, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (then_wait) spin_until(then_wait, then_value, timed_out);
         }
     }
 }
