@@ -576,8 +576,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     static size_t big = 0;                         // tasks x batch above which 128x128 workgroups pay
     if (!big) { const char* e = getenv("GPRN_FEW_TASKS"); big = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
     auto shape_upd = [&](size_t n) { return n * (size_t)nbatch > big ? TS_128x128 : TS_64x64; };
+    // In this schedule the 64x128 and 128x64 shapes are used by the panel products only, whose B resp. A
+    // operand is the triangular X_kk: their kernels skip the block products that only meet its zero half
+    // (+2 % sweeps/s where the chain dominates; applying it to the chain's launch alone measured -2 %,
+    // a second code object for one small launch per step).  GPRN_TRI=0 switches it off.
+    static int tri = -1;
+    if (tri < 0) { const char* e = getenv("GPRN_TRI"); tri = e ? atoi(e) : 1; }
     auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL,
                      Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr}) {
+        if (tri) shape = shape == TS_64x128 ? TS_64x128_BTRI : (shape == TS_128x64 ? TS_128x64_ATRI : shape);
         return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, aw);
     };
     // Cross-stream dependencies travel through 32-bit flags in device memory instead of events:

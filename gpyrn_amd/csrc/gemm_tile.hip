@@ -33,7 +33,11 @@ typedef const GPRN_GLOBAL v2d* gv2d_t;
 //   64x128 (rows split)  is safe for in-place panel tasks whose C tile is their A operand,
 //   128x64 (cols split)  for in-place tasks whose C tile is their B operand,
 //   64x64                for everything that is not in place.
-template <int BM, int BN>
+// TRI: an operand of every task of the launch is the inverted diagonal block X_kk (lower triangular,
+// explicit zeros above): 1 = it is B, transposed (panel product L_ik = B_ik X_kk^T: k <= n),
+// 2 = it is A (X_kc = X_kk R_kc: k <= m).  K-chunks that only meet the zero half of a 16-wide
+// block are skipped -- 28 of 64 block products.
+template <int BM, int BN, int TRI = 0>
 __global__ __launch_bounds__(256, 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
@@ -87,6 +91,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const int fr = lane & 15, fk = lane >> 4;
     const int a_rs = a_mode ? 1 : 18, a_ks = a_mode ? BM + 16 : 1;
     const int b_rs = b_mode ? 1 : 18, b_ks = b_mode ? BN + 16 : 1;
+    const int mb16 = (sr * BM + wr * (BM / 2)) >> 4, nb16 = (sc * BN + wc * (BN / 2)) >> 4;   // wave's first 16-blocks
     const int a_frag = (wr * (BM / 2) + fr) * a_rs + fk * a_ks;
     const int b_frag = (wc * (BN / 2) + fr) * b_rs + fk * b_ks;
 
@@ -178,8 +183,11 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NI; ++j) {
+                    if (TRI == 1 && c > nb16 + j) continue;     // wave-uniform
+                    if (TRI == 2 && c > mb16 + i) continue;
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                }
             if (ks == 1 && c + 1 < nchunks) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -248,6 +256,16 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
         break;
     case TS_128x64:
         hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+        break;
+    case TS_64x128_BTRI:
+        hipLaunchKernelGGL((k_tile_gemm<64, 128, 1>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
+                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+        break;
+    case TS_128x64_ATRI:
+        hipLaunchKernelGGL((k_tile_gemm<128, 64, 2>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
                            dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
                            aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
         break;

@@ -161,7 +161,8 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val 
 int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const double* d_tstar,
                      int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
-enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3 };
+enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
+       TS_64x128_BTRI = 4, TS_128x64_ATRI = 5 };   // panel products with the triangular X_kk (gemm_tile.hip TRI)
 // Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
