@@ -3,7 +3,7 @@
 #include <stdio.h>
 void prof_begin(gprn_ctx*, int, hipStream_t) {}
 void prof_end(gprn_ctx*) {}
-int launch_tiles(gprn_ctx*, const TileTask*, size_t, double**, int, int, int, hipStream_t, int) { return 0; }
+int launch_tiles(gprn_ctx*, const TileTask*, size_t, double**, int, int, int, hipStream_t, int, Signal, Await) { return 0; }
 
 __global__ void k_bench(double* A, double* Xg, long long* out, int* info, int reps)
 {
