@@ -245,7 +245,7 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     assert np.array_equal(out[1], ref[1])
 
 
-def _run_ranks(module, tag, world, tmp_path):
+def _run_ranks(module, tag, world, tmp_path, extra_env=None):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -253,6 +253,7 @@ def _run_ranks(module, tag, world, tmp_path):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', GPRN_COMM_TRANSPORT='shm')
+        env.update(extra_env or {})
         out = str(tmp_path / f'rank{r}.npz')
         outs.append(out)
         procs.append(subprocess.Popen(
@@ -299,6 +300,22 @@ def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
     for other in results[1:]:
         assert np.array_equal(first['sw_elbo'], other['sw_elbo'])
         assert np.array_equal(first['sw_mu'], other['sw_mu'])
+
+
+@pytest.mark.parametrize('env', [{'GPRN_FLAGS': '0'}, {'GPRN_SCHED': '1'}, {'GPRN_SCHED': '2'},
+                                 {'GPRN_TRI': '0', 'GPRN_FILL_SYM': '0', 'GPRN_BULK_PAD_KB': '0'}],
+                         ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
+def test_schedule_and_kernel_variants_agree(env, tmp_path):
+    """The library's fallbacks (HIP events instead of device flags, the one- and three-stream
+    schedules without the lean panel boundary, full-matrix fill, no triangular skip, no LDS pad)
+    are switches read once per process: run each in its own process against the golden values."""
+    tag = 'mid_N512_p3q2'
+    meta, d = _cases.load(tag)
+    res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
+    assert int(res['sw_info']) == 0
+    np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
+    np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
+    np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
 
 
 def test_eval_pool_splits_independent_evaluations(tmp_path):
