@@ -32,7 +32,7 @@ TILE = 128
 
 def update_flops(T, n_gp, outer=4):
     """Algorithmic flops of the bulk-update launches of one sweep for n_gp latent GPs: the
-    K = 512 `k_tile_gemm<128,128>` launches on the look-ahead stream (csrc/factor.hip, the
+    K = 512 `k_tile_gemm<64,64>` launches on the look-ahead stream (csrc/factor.hip, the
     "rest" half of each outer update: trailing SYRK tiles and inverse rows beyond the next
     panel).  Diagonal SYRK tiles count their lower triangle only."""
     per_gp = 0.0
@@ -226,7 +226,7 @@ def main():
             'independent_evaluations': pool,
             'elbo_last': float(elbo[-1]), 'info': int(info),
             'roofline': {
-                'kernel': 'k_tile_gemm<128,128> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
+                'kernel': 'k_tile_gemm<64,64> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,

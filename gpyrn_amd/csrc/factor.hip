@@ -749,7 +749,14 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         HIP_TRY(c, raise(s2, (int)J, F_NEXT));
         if (o.nnext > 0) next_J = (int)J;
         if (o.nrest) {
-            if ((rc = tiles(o.rest0, o.nrest, s2, TS_128x128, GPRN_T_UPDATE))) return rc;
+            // 64x64 workgroups for the bulk as well: a quarter of the work per workgroup, so CUs come
+            // free four times as often for the chain's kernels (the diagonal block needs a SIMD without
+            // a 128x128 wave: 372 + 225 registers do not fit), and its waves can share a SIMD with
+            // them; stand-alone the two shapes are within 3 % at K = 512.  +1.6 % sweeps/s at config 3.
+            // GPRN_BULK_SHAPE=0 brings the 128x128 workgroups back.
+            static int bulk_shape = -1;
+            if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
+            if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE))) return rc;
             HIP_TRY(c, raise(s2, (int)J, F_REST));
             rest_J = (int)J;
         }
