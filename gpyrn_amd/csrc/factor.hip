@@ -594,7 +594,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     static int use_flags = -1;
-    if (use_flags < 0) { const char* e = getenv("GPRN_FLAGS"); use_flags = e ? atoi(e) : 1; }
+    if (use_flags < 0) {
+        const char* e = getenv("GPRN_FLAGS");
+        // tools that serialise kernels (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION=1; the HIP
+        // debugging switch AMD_SERIALIZE_KERNEL) would starve a kernel that waits for another: events then
+        const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
+        const char* ser = getenv("AMD_SERIALIZE_KERNEL");
+        const bool serialised = (pmc && atoi(pmc) != 0) || (ser && atoi(ser) != 0);
+        use_flags = e ? atoi(e) : (serialised ? 0 : 1);
+    }
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
