@@ -241,7 +241,15 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_LAUUM)); }
     static int pad_all = -1;                       // GPRN_PAD_ALL=1 (probes): pad on every stream
     if (pad_all < 0) { const char* e = getenv("GPRN_PAD_ALL"); pad_all = e ? atoi(e) : 0; }
-    const size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)pad_kb * 1024 : 0;
+    // Launches over one or two matrices (node half-sweep, sharded runs) ask for 64 KiB instead: with
+    // 104 KiB taken, the diagonal-block kernel (67 KiB) cannot land on a CU that runs a bulk workgroup at
+    // all and runs undisturbed on the next CU that comes free -- those phases are bound by the chain, not
+    // by the bulk (+3 % sweeps/s at config 3).  GPRN_PAD_SMALL_KB / GPRN_PAD_SMALL_BATCH override.
+    static int pad_small_kb = -1, pad_small_batch = -1;
+    if (pad_small_kb < 0) { const char* e = getenv("GPRN_PAD_SMALL_KB"); pad_small_kb = e ? atoi(e) : 64; }
+    if (pad_small_batch < 0) { const char* e = getenv("GPRN_PAD_SMALL_BATCH"); pad_small_batch = e ? atoi(e) : 2; }
+    const int kb = nbatch <= pad_small_batch ? pad_small_kb : pad_kb;
+    const size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
     double* const* tab = (double* const*)d_ptrs;
     switch (shape) {
     case TS_64x64:
