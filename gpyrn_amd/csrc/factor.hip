@@ -740,7 +740,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // chain: the two tiles the next diagonal block and L_{k1+1,k1} need; stream3 (which has
             // the whole panel once it has seen the chain's two rows): everything else of "first"
             if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
-            if ((rc = tiles(o.c1_0, o.nc1, s0, TS_64x64))) return rc;
+            // The bulk stream is released when these two tiles are done, not before: the next diagonal
+            // block is dispatched at that moment too and, from the higher-priority stream, takes its CUs
+            // before the bulk's workgroups flood them (+0.5 % sweeps/s).  GPRN_HOLD_BULK=0 switches it off.
+            static int hold = -1;
+            if (hold < 0) { const char* e = getenv("GPRN_HOLD_BULK"); hold = e ? atoi(e) : 1; }
+            const bool hold_bulk = use_flags && hold && o.nc1 > 0;
+            if ((rc = tiles(o.c1_0, o.nc1, s0, TS_64x64, GPRN_T_PANEL,
+                            hold_bulk ? in_kernel((int)J, F_XW) : Signal{nullptr, 0}))) return rc;
+            if (hold_bulk) HIP_TRY(c, await(s2, (int)J, F_XW));
             HIP_TRY(c, raise(s1, (int)J, F_PANEL));
             if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, F_REST));
             if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
