@@ -184,13 +184,13 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
-// spin of ONE thread until *flag >= value; gives up after about a second
+// spin of ONE thread until *flag >= value; gives up after a second or two
 __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value, unsigned* timed_out)
 {
     long spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1L << 24)) { atomicExch(timed_out, 1u); break; }
+        if (++spins > (1L << 20)) { atomicExch(timed_out, 1u); break; }
     }
 }
 
