@@ -601,7 +601,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
         const char* ser = getenv("AMD_SERIALIZE_KERNEL");
         const bool serialised = (pmc && atoi(pmc) != 0) || (ser && atoi(ser) != 0);
-        use_flags = e ? atoi(e) : (serialised ? 0 : 1);
+        int can = 0;                               // stream memory operations are optional in HIP
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
+        use_flags = e ? atoi(e) : ((serialised || !can) ? 0 : 1);
     }
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
