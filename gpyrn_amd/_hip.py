@@ -61,6 +61,7 @@ SIGNATURES = {
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
+    'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
 }
 
 _lib = None
@@ -247,6 +248,12 @@ class Context:
         out = np.empty(self.G)
         self._check(self._lib.gprn_get_logdet_K(self._h, _ptr(out)), 'get_logdet_K')
         return out
+
+    def option(self, name, value=-1):
+        """Read (value < 0) or set a per-context switch of the library; returns the previous value."""
+        old = c_int(0)
+        self._check(self._lib.gprn_set_option(self._h, name.encode(), int(value), byref(old)), 'set_option')
+        return old.value
 
     # -- timing --------------------------------------------------------------
     def profile_enable(self, families=T_NAMES):

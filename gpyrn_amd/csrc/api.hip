@@ -106,6 +106,51 @@ static void dev_free(T*& p) { if (p) hipFree(p); p = nullptr; }
 
 static int bad(gprn_ctx* c, const char* msg) { if (c) c->err = msg; return GPRN_E_ARG; }
 
+// Runs `body` (an entry point that factorises); when one of its in-kernel dependency waits gave up
+// (GPRN_E_WAIT_TIMEOUT: a serialising tool, a starved device, ...), the context is latched to the event
+// schedule and the body runs once more -- `body` must restore what it changed before it starts over.
+template <class F>
+static int with_event_fallback(gprn_ctx* c, const char* what, F&& body)
+{
+    int rc = body(false);
+    if (rc != GPRN_E_WAIT_TIMEOUT) return rc;
+    hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->stream3);
+    c->use_flags = 0;
+    c->fallbacks += 1;
+    fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms; re-running the call with "
+                    "HIP events (device-side waits are now off for this context)\n", what, c->wait_budget_ms);
+    rc = body(true);
+    if (rc == GPRN_E_WAIT_TIMEOUT) { c->err = "factorisation: dependency wait timed out on the event schedule too"; rc = GPRN_E_HIP; }
+    return rc;
+}
+
+// Per-context switches (tests, experiments).  Returns the previous value through *old when given.
+//   "flags"          1/0: device-side flags or HIP events for the factorisation's cross-stream dependencies
+//   "wait_budget_ms" wall-clock budget of one in-kernel wait
+//   "withhold_inner" test hook: the n-th F_INNER raise of every following call is skipped (0 = off)
+//   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
+extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
+{
+    if (!c || !name) return GPRN_E_ARG;
+    int* field = nullptr;
+    if (!strcmp(name, "flags")) { factor_use_flags(c); field = &c->use_flags; }
+    else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
+    else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
+    else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
+    else return bad(c, "set_option: unknown option");
+    if (old) *old = *field;
+    if (value >= 0) {
+        if (field == &c->use_flags && value) {
+            int can = 0;
+            if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
+            if (!can) return bad(c, "set_option: this device has no stream memory operations");
+        }
+        if (field == &c->wait_budget_ms && value < 1) return bad(c, "set_option: wait_budget_ms >= 1");
+        *field = value;
+    }
+    return GPRN_OK;
+}
+
 static void free_problem(gprn_ctx* c)
 {
     dev_free(c->d_time); dev_free(c->d_yraw); dev_free(c->d_yerr2); dev_free(c->d_yres);
@@ -728,6 +773,8 @@ static int check_info(gprn_ctx* c, const int* d_info, const std::vector<int>& gp
 
 // ------------------------------------------------------------------ setup
 // fill + chol(K) + chol(K)^-1 (+ K^-1 for the nodes that feed quirk Q1)
+static int factor_priors_impl(gprn_ctx* c);
+
 extern "C" int gprn_factor_priors(gprn_ctx* c)
 {
     if (!c || !c->N) return bad(c, "factor_priors: call set_data first");
@@ -735,6 +782,12 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
     if (c->owner.empty()) return bad(c, "factor_priors: call set_owners first");
     for (int g = 0; g < c->G; ++g)
         if (!c->kspec[g].set) return bad(c, "factor_priors: a latent GP has no kernel");
+    // (every K is refilled from its kernel spec -- or still holds the uploaded matrix -- so a re-run starts clean)
+    return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); });
+}
+
+static int factor_priors_impl(gprn_ctx* c)
+{
     TRY(build_tables(c));
     TRY(ensure_tasks(c));
     c->info_gp = -1;
@@ -877,19 +930,31 @@ static int mu_k_mu(gprn_ctx* c, bool weights)
     return vec_dot_self(c, slotgp, ns, a, c->d_muKmu);
 }
 
+static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out, bool retry);
+
 extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
 {
     if (!c || n_sweeps <= 0 || !elbo_out) return bad(c, "sweep: bad argument");
     if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
         return bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
     HIP_TRY(c, hipSetDevice(c->device));
+    return with_event_fallback(c, "sweep", [&](bool retry) {
+        return sweep_impl(c, n_sweeps, commit, elbo_out, parts_out, retry); });
+}
+
+static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out, bool retry)
+{
     if (n_sweeps > c->out_cap) {
         dev_free(c->d_out);
         TRY(dev_alloc(c, &c->d_out, 4 * (size_t)n_sweeps));
         c->out_cap = n_sweeps;
     }
     const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
-    if (!commit) {
+    // the state the call started from: what commit = 0 returns to, and what a re-run starts over from
+    if (retry) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
+    } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu_save, c->d_mu, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
     }
@@ -974,12 +1039,20 @@ extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
 // (meanfield.py:1289-1381): cov = K + 1.25e-12 I + diag(var), sol = cov^-1 mu,
 // mean* = K* sol, var*_i = k(t*_i,t*_i) + 1.25e-12 - |L^-1 K*_i|^2.  Here: fused fills,
 // the blocked factor+inverse (X = L^-1), sol = X^T X mu, W^T = K* X^T by the tile kernel.
+static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out);
+
 extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
 {
     if (!c || !c->N || ns <= 0 || !tstar || !mean_out || !var_out) return bad(c, "predict: bad argument");
     if (!c->have_muvar) return bad(c, "predict: set_muvar (or a sweep) first");
     if (c->owner.empty()) return bad(c, "predict: call set_owners first");
     HIP_TRY(c, hipSetDevice(c->device));
+    // (everything it factors is refilled from the kernel specs and the variational state)
+    return with_event_fallback(c, "predict", [&](bool) { return predict_impl(c, ns, tstar, mean_out, var_out); });
+}
+
+static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
+{
     TRY(build_tables(c));
     std::vector<int> gps = c->loc_nodes;
     gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
@@ -1064,7 +1137,8 @@ extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* me
         memcpy(var_out + (size_t)gps[s] * ns, &hv[(size_t)s * ns_pad], ns * sizeof(double));
     }
     c->info_gp = -1;
-    rc = check_info(c, c->d_info, gps, &first);
+    rc = factor_check_waits(c);
+    if (!rc) rc = check_info(c, c->d_info, gps, &first);
     if (!rc) rc = first;
 done:
 #undef PTRY
@@ -1148,10 +1222,20 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
 }
 
 // run the library's own factorisation on caller matrices: temporarily a tiny "problem"
+static int test_factor_impl(gprn_ctx* c, int n, int batch, const double* A, double* L,
+                            double* Linv, bool lauum, double* lauum_out);
+
 static int test_factor_common(gprn_ctx* c, int n, int batch, const double* A, double* L,
                               double* Linv, bool lauum, double* lauum_out)
 {
     if (!c || n <= 0 || n % GPRN_TILE || batch <= 0 || !A) return bad(c, "test_factor: bad argument");
+    return with_event_fallback(c, "test_factor", [&](bool) {
+        return test_factor_impl(c, n, batch, A, L, Linv, lauum, lauum_out); });
+}
+
+static int test_factor_impl(gprn_ctx* c, int n, int batch, const double* A, double* L,
+                            double* Linv, bool lauum, double* lauum_out)
+{
     TRY(test_setup(c, n, 2, batch));
     const size_t nn = (size_t)n * n;
     HIP_TRY(c, hipMemcpy(c->d_test[0], A, nn * batch * sizeof(double), hipMemcpyHostToDevice));
@@ -1184,6 +1268,7 @@ static int test_factor_common(gprn_ctx* c, int n, int batch, const double* A, do
             if (e == hipSuccess) rc = lauum_lower(c, 1);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && !rc) rc = factor_check_waits(c);
         if (e == hipSuccess && !rc) {
             if (lauum) e = hipMemcpy(lauum_out, c->d_test[0], nn * sizeof(double), hipMemcpyDeviceToHost);
             else {

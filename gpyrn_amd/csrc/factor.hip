@@ -563,6 +563,25 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
 
 #define GPRN_FLAG_KINDS 8           // flag kinds per tile step / outer panel (factor_invert_split)
 
+// Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
+// beside them: every switch that serialises kernels or starves the hardware queues means events.
+//   rocprofv3 --pmc (ROCPROF_COUNTER_COLLECTION=1), AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING,
+//   GPU_MAX_HW_QUEUES < 4 (three streams of this context + the null stream), no stream memory operations.
+// GPRN_FLAGS=0/1 overrides; gprn_set_option(ctx, "flags", v) sets it per context; a time-out latches 0.
+int factor_use_flags(gprn_ctx* c)
+{
+    if (c->use_flags >= 0) return c->use_flags;
+    auto on = [](const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; };
+    const char* e = getenv("GPRN_FLAGS");
+    const char* hq = getenv("GPU_MAX_HW_QUEUES");
+    const bool serialised = on("ROCPROF_COUNTER_COLLECTION") || on("AMD_SERIALIZE_KERNEL") ||
+                            on("HIP_LAUNCH_BLOCKING") || (hq && atoi(hq) > 0 && atoi(hq) < 4);
+    int can = 0;                               // stream memory operations are optional in HIP
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
+    c->use_flags = e ? (atoi(e) != 0 && can) : ((serialised || !can) ? 0 : 1);
+    return c->use_flags;
+}
+
 // Split schedule.  Per tile step k the only launches on the chain stream are the diagonal
 // block, the ONE panel tile below it (L_{k+1,k}) and the ONE in-panel update that completes the
 // next diagonal tile (B_{k+1,k+1}); the remaining panel tiles and in-panel updates of the step run on
@@ -593,18 +612,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // (+3 % sweeps/s at N = 4096, +14 % at N = 2048), and the chain's two small kernels raise
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
-    static int use_flags = -1;
-    if (use_flags < 0) {
-        const char* e = getenv("GPRN_FLAGS");
-        // tools that serialise kernels (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION=1; the HIP
-        // debugging switch AMD_SERIALIZE_KERNEL) would starve a kernel that waits for another: events then
-        const char* pmc = getenv("ROCPROF_COUNTER_COLLECTION");
-        const char* ser = getenv("AMD_SERIALIZE_KERNEL");
-        const bool serialised = (pmc && atoi(pmc) != 0) || (ser && atoi(ser) != 0);
-        int can = 0;                               // stream memory operations are optional in HIP
-        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
-        use_flags = e ? atoi(e) : ((serialised || !can) ? 0 : 1);
-    }
+    const int use_flags = factor_use_flags(c);
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
@@ -615,6 +623,13 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
         c->sig_T = c->T;
         c->epoch = 0;
+        c->sig_budget_ms = -1;
+    }
+    if (use_flags && c->sig_budget_ms != c->wait_budget_ms) {
+        // the word behind the sticky time-out word: budget of one in-kernel wait, 100 MHz ticks
+        const unsigned ticks = (unsigned)std::min<long long>(0xffffffffll, (long long)c->wait_budget_ms * 100000ll);
+        HIP_TRY(c, hipMemcpy(c->d_sig + (size_t)c->sig_T * F_KINDS * 2 + 1, &ticks, sizeof(unsigned), hipMemcpyHostToDevice));
+        c->sig_budget_ms = c->wait_budget_ms;
     }
     const unsigned epoch = ++c->epoch;
     hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr};
@@ -622,7 +637,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
     };
+    int inner_raises = 0;
+    auto withheld = [&](int kind) {                // test hook (gprn_set_option "withhold_inner")
+        return use_flags && kind == F_INNER && c->withhold_inner > 0 && ++inner_raises == c->withhold_inner;
+    };
     auto raise = [&](hipStream_t st, int idx, int kind) {
+        if (withheld(kind)) return hipSuccess;
         return use_flags ? hipStreamWriteValue32(st, slot(idx, kind) + 1, epoch, 0) : hipEventRecord(events[kind], st);
     };
     // the chain's L_{k+1,k} launch (2 workgroups per matrix) waits for stream3's flag itself: the
@@ -645,8 +665,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             HIP_TRY(c, await(s1, k, F_DIAG));
             return GPRN_OK;
         }
+        const bool skip = inner_k >= 0 && withheld(F_INNER);
         hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, s1,
-                           inner_k >= 0 ? slot(inner_k, F_INNER) + 1 : (unsigned*)nullptr, epoch,
+                           inner_k >= 0 && !skip ? slot(inner_k, F_INNER) + 1 : (unsigned*)nullptr, epoch,
                            (const unsigned*)(slot(k, F_DIAG) + 1), epoch, timed_out);
         inner_k = -1;
         HIP_TRY(c, hipGetLastError());
@@ -723,7 +744,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write;
             // the flag goes up with stream3's next synchronisation kernel)
             if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
-            inner_k = k;
+            if (use_flags) inner_k = k;                // raised by stream3's next synchronisation kernel
+            else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
+                                                       // chain's wait for step k is enqueued at step k + 1
         }
         if ((rc = flush_inner())) return rc;
         if (next_J >= 0) {                             // one-step panel: nothing consumed it yet
@@ -794,7 +817,7 @@ int factor_check_waits(gprn_ctx* c)
     if (flag) {
         hipMemset(c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0, sizeof(unsigned));
         c->err = "factorisation: a device-side dependency wait timed out";
-        return GPRN_E_HIP;
+        return GPRN_E_WAIT_TIMEOUT;
     }
     return GPRN_OK;
 }

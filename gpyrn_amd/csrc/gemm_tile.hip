@@ -223,8 +223,15 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
                  int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig, Await aw)
 {
     if (!stream) stream = c->stream;
-    if (ntasks == 0 || nbatch == 0) {              // nothing to wait for: raise the flag from the stream
-        if (sig.slot) HIP_TRY(c, hipStreamWriteValue32(stream, sig.slot + 1, sig.value, 0));
+    if (ntasks == 0 || nbatch == 0) {
+        // No kernel: keep what the launch would have done to the stream's order.  The waits it would have
+        // made become stream waits, and the flag (raised only by signals that carry a value: 0 means "count
+        // the workgroups", and flags never go down) is written from the stream.  Signals and waits exist in
+        // the flag schedule only, which requires stream memory operations (factor_use_flags).
+        if (aw.flag) HIP_TRY(c, hipStreamWaitValue32(stream, (void*)aw.flag, aw.value, hipStreamWaitValueGte, 0xffffffffu));
+        if (sig.slot && sig.value) HIP_TRY(c, hipStreamWriteValue32(stream, sig.slot + 1, sig.value, 0));
+        if (sig.slot && sig.then_wait)
+            HIP_TRY(c, hipStreamWaitValue32(stream, (void*)sig.then_wait, sig.then_value, hipStreamWaitValueGte, 0xffffffffu));
         return GPRN_OK;
     }
     prof_begin(c, fam, stream);

@@ -140,6 +140,14 @@ struct gprn_ctx {
     unsigned* d_sig = nullptr;       // completion signals of the chain: (tile step, kind) -> {counter, flag}
     int sig_T = 0;
     unsigned epoch = 0;              // value the flags take in the current factor_invert call
+    // How cross-stream dependencies of the factorisation travel (factor.hip): 1 = 32-bit flags in device
+    // memory (stream memory operations + in-kernel waits), 0 = HIP events, -1 = not decided yet.  Decided per
+    // context from the device and the environment; latched to 0 after an in-kernel wait timed out.
+    int use_flags = -1;
+    int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
+    int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
+    int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
+    int sig_budget_ms = -1;          // budget the device word holds
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
@@ -184,14 +192,28 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
-// spin of ONE thread until *flag >= value; gives up after a second or two
+// Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
+// timed_out[1] the budget of one wait in ticks of the 100 MHz constant clock (s_memrealtime): a wall-clock
+// bound, not a spin count -- on a shared device a legitimate wait can be long.  Once any wait of the call
+// has given up the others return at once (the results are void anyway; the host re-runs the call on events).
+// Relaxed polling and ONE acquire after the match (acquire loads in the loop cost 2-3x per hop).
 __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value, unsigned* timed_out)
 {
-    long spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1L << 20)) { atomicExch(timed_out, 1u); break; }
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long budget = timed_out ? (unsigned long long)timed_out[1] : 200000000ull;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) break;
+            if (timed_out && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
+                if (timed_out) atomicExch(timed_out, 1u);
+                break;
+            }
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // start of a kernel: every thread of the workgroup calls it
@@ -223,4 +245,7 @@ __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value, cons
 int factor_invert(gprn_ctx* c, int nbatch);
 int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
 int ensure_tasks(gprn_ctx* c);
-int factor_check_waits(gprn_ctx* c);   // error if an in-kernel dependency wait timed out since the last check
+// internal status: an in-kernel dependency wait gave up; the entry points of api.hip re-run the call on events
+#define GPRN_E_WAIT_TIMEOUT (-100)
+int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel dependency wait timed out since the last check
+int factor_use_flags(gprn_ctx* c);

@@ -154,6 +154,15 @@ int gprn_profile_enable(gprn_ctx* ctx, int family_mask);   /* bit f = time famil
 int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
                       int64_t* launches /*GPRN_T_COUNT*/, int reset);
 
+/* ---- per-context switches (tests, experiments; nothing in the reference corresponds) ----
+ * name: "flags" (1: the factorisation's cross-stream dependencies travel through device-side flags and
+ * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel
+ * wait timed out, in which case the call is re-run on events); "wait_budget_ms" (wall-clock budget of one
+ * in-kernel wait); "withhold_inner" (test hook: the n-th in-panel completion flag of every following call is
+ * never raised); "fallbacks" (read-only count of re-run calls).  value < 0 only reads; *old (may be NULL)
+ * receives the previous value. */
+int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
+
 /* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----
  * C (+)= A.B on host matrices through the MFMA tile kernel; modes as in
  * csrc/gemm_tile.hip (a_mode 0: A[m][k], 1: A[k][m]; b_mode 0: B[n][k], 1: B[k][n];

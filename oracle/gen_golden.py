@@ -269,6 +269,147 @@ def gen_api():
     print('api: %d parameters' % out['n_parameters'])
 
 
+def gen_traj_case(tag, N, p, q, node_kind, seed=0):
+    """Full ELBOcalc trajectory at a BASELINE config (meanfield.py:561-649): every ELBOaux value the loop
+    sees, iterNumber and the converged mu/var, then the warm start nELBO uses (meanfield.py:1102-1104)."""
+    t0 = time.time()
+    spec = model_spec(p, q, node_kind, False)
+    g, t, ys, es = make_ref(N, p, q, spec, seed)
+    rec = []
+    orig = g.ELBOaux
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        rec.append(float(r[0]))
+        print('   %s: ELBOaux #%d = %.15g (%.0fs)' % (tag, len(rec), rec[-1], time.time() - t0), flush=True)
+        return r
+    g.ELBOaux = spy
+    out = {}
+    E, muc, varc, it = g.ELBOcalc()
+    out['calc_elbo'] = np.array(float(E))
+    out['calc_mu'], out['calc_var'] = muc, varc
+    out['calc_iter'] = np.array(it)
+    out['calc_elbo_array'] = np.array(rec)
+    rec.clear()
+    E2, mu2, var2, it2 = g.ELBOcalc(mu='previous', var='previous')
+    out['warm_elbo'] = np.array(float(E2))
+    out['warm_iter'] = np.array(it2)
+    out['warm_elbo_array'] = np.array(rec)
+    out['warm_mu'], out['warm_var'] = mu2, var2
+    g.ELBOaux = orig
+    meta = {'N': N, 'p': p, 'q': q, 'seed': seed, 'nodes': spec[0], 'weights': spec[1],
+            'means': spec[2], 'jitters': spec[3]}
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **out)
+    with open(os.path.join(OUT, tag + '.json'), 'w') as fjs:
+        json.dump(meta, fjs, indent=1)
+    print('%s: N=%d p=%d q=%d calc_iter=%d ELBO=%.15g warm_iter=%d (%.1fs)'
+          % (tag, N, p, q, it, float(E), it2, time.time() - t0), flush=True)
+
+
+def gen_big_sweep(tag, N, seed=0):
+    """One reference-form sweep (ELBOaux body, meanfield.py:682-710) at a size beyond the other fixtures,
+    p = q = 1: scalars and the O(N) state only -- no matrix is stored."""
+    t0 = time.time()
+    spec = model_spec(1, 1, 'QP', False)
+    g, t, ys, es = make_ref(N, 1, 1, spec, seed)
+    mu0, var0 = g._initMuVar(g.nodes, g.weights, g.jitters)
+    Kf, Kw, Lf, Lw, y, j2 = setup_like_elbocalc(g)
+    print('   %s: setup done (%.0fs)' % (tag, time.time() - t0), flush=True)
+    out = {'logdiag_Lf': np.array([np.sum(np.log(np.diag(L))) for L in Lf]),
+           'logdiag_Lw': np.array([np.sum(np.log(np.diag(L))) for L in Lw])}
+    muF, muW = g._u_to_fhatW(mu0.flatten())
+    varF, varW = g._u_to_fhatW(var0.flatten())
+    sigF, muFn, sigW, muWn = g._updateSigMu(Kf, Kw, Lf, Lw, y, j2, muF, varF, muW, varW)
+    print('   %s: _updateSigMu done (%.0fs)' % (tag, time.time() - t0), flush=True)
+    muFn3 = muFn.reshape(1, g.q, g.N)
+    ent = float(g._entropy(sigF, sigW))
+    logp = float(g._expectedLogPrior(Kf, Kw, Lf, Lw, sigF, muFn3, sigW, muWn))
+    logl = float(g._expectedLogLike(y, j2, sigF, muFn3, sigW, muWn))
+    varFn = np.array([np.diag(s) for s in sigF])
+    varWn = np.array([[np.diag(s) for s in row] for row in sigW])
+    out['elbo_sweeps'] = np.array([(logl + logp + ent) / g.q])
+    out['parts_sweeps'] = np.array([[logl, logp, ent]])
+    out['mu_f_1'], out['mu_w_1'] = np.asarray(muFn), np.asarray(muWn)
+    out['var_f_1'], out['var_w_1'] = varFn, varWn
+    meta = {'N': N, 'p': 1, 'q': 1, 'seed': seed, 'nodes': spec[0], 'weights': spec[1],
+            'means': spec[2], 'jitters': spec[3], 'nsweeps': 1}
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **out)
+    with open(os.path.join(OUT, tag + '.json'), 'w') as fjs:
+        json.dump(meta, fjs, indent=1)
+    print('%s: N=%d ELBO=%.15g parts=%s (%.1fs)' % (tag, N, out['elbo_sweeps'][0], out['parts_sweeps'][0],
+                                                   time.time() - t0), flush=True)
+
+
+def gen_optimize(tag='opt_N64_p2q1'):
+    """inference.optimize (meanfield.py:1114-1152): a short deterministic Nelder-Mead run."""
+    N, p, q = 64, 2, 1
+    spec = model_spec(p, q, 'QP', True)
+    spec = (spec[0], spec[1], [('Constant', [0.7]), ('Linear', [0.01, -0.4])], spec[3])
+    g, t, ys, es = make_ref(N, p, q, spec)
+    x0 = g.get_parameters().copy()
+    calls = []
+    orig = g.nELBO
+
+    def spy(x, *a, **k):
+        v = orig(x, *a, **k)
+        calls.append([float(v)] + [float(xx) for xx in x])
+        return v
+    g.nELBO = spy
+    res = g.optimize(options={'maxiter': 10})
+    out = {'x0': x0.tolist(), 'x': res.x.tolist(), 'fun': float(res.fun), 'nfev': int(res.nfev),
+           'nit': int(res.nit), 'calls': calls, 'names': list(g.parameters_dict.keys()),
+           'N': N, 'p': p, 'q': q, 'nodes': spec[0], 'weights': spec[1], 'means': spec[2], 'jitters': spec[3]}
+    # vars= forms: only one parameter free / all but one
+    g2, *_ = make_ref(N, p, q, spec)
+    r2 = g2.optimize(vars='node1.P', options={'maxiter': 6})
+    out['vars_P'] = {'x': r2.x.tolist(), 'fun': float(r2.fun), 'mask': g2.frozen_mask.tolist(),
+                     'all': g2.get_parameters(include_frozen=True).tolist()}
+    with open(os.path.join(OUT, tag + '.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('%s: fun=%.12g nfev=%d' % (tag, out['fun'], out['nfev']))
+
+
+def gen_multiconstant(tag='multiconstant'):
+    """meanfunc.MultiConstant (meanfunc.py:138-187) alone and inside ELBOcalc via inference._mean."""
+    rng = np.random.RandomState(5)
+    N = 48
+    t = np.sort(rng.uniform(0, 90, N))
+    obsid = np.r_[np.full(17, 1), np.full(12, 2), np.full(19, 3)].astype(float)
+    m = rmean.MultiConstant([1.5, -0.75, 3.25], obsid, t)
+    tq = np.linspace(-5, 95, 31)
+    out = {'time': t, 'obsid': obsid, 'offsets': np.array([1.5, -0.75, 3.25]), 'at_time': m(t),
+           'tq': tq, 'at_tq': m(tq), 'time_bins': m.time_bins(), 'parsize': np.array(m._parsize)}
+    names = list(m._param_names)
+    # inside the model: one output with instrument offsets, one node, SE kernels
+    y = 2.0 * np.sin(2 * np.pi * t / 20) + np.take([1.5, -0.75, 0.0], obsid.astype(int) - 1) + 3.25 \
+        + rng.normal(0, 0.3, N)
+    e = rng.uniform(0.2, 0.4, N)
+    g = rinference(1, t, y, e)
+    g.set_components(rcov.SquaredExponential(1.1, 15.0), rcov.SquaredExponential(0.9, 40.0),
+                     rmean.MultiConstant([1.5, -0.75, 3.25], obsid, t), 0.4)
+    E, mu, var, it = g.ELBOcalc()
+    out.update(y=y, yerr=e, calc_elbo=np.array(float(E)), calc_mu=mu, calc_var=var, calc_iter=np.array(it),
+               mean_vec=g._mean(g.means))
+    out['pnames'] = np.array(list(g.parameters_dict.keys()))
+    out['pvalues'] = np.array(list(g.parameters_dict.values()), dtype=float)
+    np.savez_compressed(os.path.join(OUT, tag + '.npz'), **out)
+    print('%s: names=%s ELBO=%.12g iter=%d' % (tag, names, float(E), it))
+
+
+def gen_solar(tag='solar'):
+    """The reference's data file gpyrn/datasets/Solar_observations.txt (header line 1, 13 columns): per-column
+    sums and the first/last rows, for the loader test.  The values are data, read with numpy alone."""
+    path = os.path.join(REF, 'gpyrn', 'datasets', 'Solar_observations.txt')
+    with open(path) as f:
+        header = f.readline().split()
+    d = np.loadtxt(path, skiprows=1)
+    out = {'header': header, 'shape': list(d.shape), 'colsum': d.sum(axis=0).tolist(),
+           'first': d[0].tolist(), 'last': d[-1].tolist(), 'bytes': os.path.getsize(path)}
+    with open(os.path.join(OUT, tag + '.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('%s: shape %s header %s' % (tag, d.shape, header))
+
+
 if __name__ == '__main__':
     big = '--big' in sys.argv
     only = [a for a in sys.argv[1:] if not a.startswith('--')]
@@ -305,3 +446,18 @@ if __name__ == '__main__':
     for tag in ('step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'):
         if want('pred_' + tag):
             gen_predict(tag)
+    if want('optimize'):
+        gen_optimize()
+    if want('multiconstant'):
+        gen_multiconstant()
+    if want('solar'):
+        gen_solar()
+    if big:
+        # trajectories at the BASELINE configs (cfg 3: ~21 reference sweeps of ~35 s) and one reference-form
+        # sweep each at N = 8192 and N = 16384 (7.2.N^3 flop: minutes to tens of minutes, ~30 GB)
+        for tag, N, p, q in (('traj_cfg2_N2048', 2048, 1, 1), ('traj_cfg3_N4096', 4096, 3, 2)):
+            if want(tag):
+                gen_traj_case(tag, N, p, q, 'QP')
+        for tag, N in (('big_N8192', 8192), ('big_N16384', 16384)):
+            if want(tag):
+                gen_big_sweep(tag, N)

@@ -89,3 +89,99 @@ def test_lauum(ctx):
     X = np.tril(rng.standard_normal((384, 384)))
     out = ctx.test_lauum(X)
     np.testing.assert_allclose(np.tril(out), np.tril(X.T @ X), rtol=0, atol=1e-11)
+
+
+def _check_factor_by_probes(A, L, X, rng, tol):
+    """O(n^2) checks of a factor + inverse: L L^T v = A v and X (L v) = v for random v."""
+    n = A.shape[0]
+    v = rng.standard_normal((n, 3))
+    Lt = np.tril(L)
+    np.testing.assert_allclose(Lt @ (Lt.T @ v), A @ v, rtol=0, atol=tol * np.abs(A @ v).max())
+    np.testing.assert_allclose(np.tril(X) @ (Lt @ v), v, rtol=0, atol=tol * np.abs(v).max())
+
+
+@pytest.mark.parametrize('flags', [0, 1])
+def test_factor_invert_schedules_at_size(ctx, flags):
+    # ADVICE r1 (high): the HIP-event schedule lost a dependency that only shows with many tile steps
+    # and a batch that keeps stream3 behind the chain: N = 4096 (32 tile steps), 8 matrices.
+    can_flags = ctx.option('flags')
+    if flags and not can_flags:
+        pytest.skip('device-side flags are off for this context (serialising tool or no stream memory ops)')
+    old = ctx.option('flags', flags)
+    try:
+        rng = np.random.RandomState(77)
+        n, batch = 4096, 8
+        A = np.array([_spd(n, rng, 1.0 + 0.25 * b) for b in range(batch)])
+        L, X, info = ctx.test_factor_invert(A)
+        assert info == 0
+        for b in range(batch):
+            Lref = np.linalg.cholesky(A[b])
+            np.testing.assert_allclose(np.tril(L[b]), Lref, rtol=0, atol=2e-11)
+            _check_factor_by_probes(A[b], L[b], X[b], rng, 1e-10)
+    finally:
+        ctx.option('flags', old)
+
+
+def test_factor_invert_event_schedule_n16384(ctx):
+    # once, at BASELINE config 5's matrix size (128 tile steps), on the event schedule
+    old = ctx.option('flags', 0)
+    try:
+        rng = np.random.RandomState(78)
+        n = 16384
+        A = _spd(n, rng, 1.5)
+        L, X, info = ctx.test_factor_invert(A)
+        assert info == 0
+        _check_factor_by_probes(A, L[0], X[0], rng, 1e-9)
+        d = np.diag(L[0])
+        assert np.all(d > 0) and np.isfinite(d).all()
+    finally:
+        ctx.option('flags', old)
+
+
+def test_wait_timeout_falls_back_to_events(ctx, capfd):
+    # A producer flag that never goes up (test hook) makes an in-kernel wait give up after the budget;
+    # the call is then re-run on HIP events: correct numbers, one warning, flags latched off.
+    if not ctx.option('flags'):
+        pytest.skip('device-side flags are off for this context')
+    rng = np.random.RandomState(79)
+    n = 1024
+    A = np.array([_spd(n, rng, 1.0), _spd(n, rng, 2.0)])
+    before = ctx.option('fallbacks')
+    ctx.option('wait_budget_ms', 20)
+    ctx.option('withhold_inner', 2)
+    try:
+        L, X, info = ctx.test_factor_invert(A)
+    finally:
+        ctx.option('withhold_inner', 0)
+        ctx.option('wait_budget_ms', 2000)
+    assert info == 0
+    for b in range(2):
+        np.testing.assert_allclose(np.tril(L[b]), np.linalg.cholesky(A[b]), rtol=0, atol=1e-11)
+        _check_factor_by_probes(A[b], L[b], X[b], rng, 1e-10)
+    assert ctx.option('fallbacks') == before + 1
+    assert ctx.option('flags') == 0                      # latched for the context
+    assert 'timed out' in capfd.readouterr().err
+    # the next call runs on events straight away, no new fallback
+    L2, X2, info = ctx.test_factor_invert(A)
+    assert info == 0 and ctx.option('fallbacks') == before + 1
+    np.testing.assert_array_equal(L2, L)
+    ctx.option('flags', 1)                               # the module fixture goes on with flags
+
+
+def test_two_live_contexts_on_one_device():
+    # six high/low-priority streams over the device's hardware queues: both factorisations must finish
+    # (on flags or after the event fallback) with the right numbers
+    rng = np.random.RandomState(80)
+    n = 1024
+    A = _spd(n, rng, 1.0)
+    c1, c2 = _hip.Context(0), _hip.Context(0)
+    try:
+        for _ in range(3):
+            L1, X1, i1 = c1.test_factor_invert(A)
+            L2, X2, i2 = c2.test_factor_invert(A)
+            assert i1 == 0 and i2 == 0
+            np.testing.assert_array_equal(L1, L2)
+        np.testing.assert_allclose(np.tril(L1[0]), np.linalg.cholesky(A), rtol=0, atol=1e-11)
+    finally:
+        c1.close()
+        c2.close()
