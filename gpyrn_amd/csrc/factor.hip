@@ -435,7 +435,7 @@ static inline int64_t toff(int ti, int tj, int ld) {
 static int sched_mode()
 {
     static int mode = 0;
-    if (!mode) { const char* e = getenv("GPRN_SCHED"); mode = e && atoi(e) >= 1 && atoi(e) <= 3 ? atoi(e) : 3; }
+    if (!mode) { const char* e = getenv("GPRN_SCHED"); mode = e && atoi(e) == 1 ? 1 : 2; }
     return mode;
 }
 static bool split_sched() { return sched_mode() >= 2; }
@@ -470,8 +470,11 @@ int ensure_tasks(gprn_ctx* c)
                                      BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)});
             s.npanel = v.size() - s.panel0;
             s.upd0 = v.size();
-            for (int j = k + 1; j < k1; ++j)
-                for (int i = j; i < T; ++i)
+            // columns of the panel right of step k; and of the NEXT panel's first column the two tiles the
+            // chain starts that panel with, (k1,k1) and (k1+1,k1): kept up to date step by step so that no
+            // K = 512 update of them stands between the last step of this panel and the first of the next
+            for (int j = k + 1; j <= k1 && j < T; ++j)
+                for (int i = j; i < (j < k1 ? T : std::min(T, k1 + 2)); ++i)
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
                                          BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
             for (int i = k + 1; i < k1; ++i)
@@ -487,17 +490,20 @@ int ensure_tasks(gprn_ctx* c)
         // pass 0 ("first"): the next panel's first column of B / first row of R -- what its first
         // tile step needs -- and, in the split schedule, the next panel's diagonal and sub-diagonal
         // tiles (the chain stream owns those); pass 1 ("next"): the rest of the next panel's
-        // columns / rows; pass 2 ("rest"): everything beyond
-        // GPRN_SCHED=3 cuts "first" once more: pass -1 ("c1") = B tiles (k1,k1) and (k1+1,k1), all the
-        // chain needs before the next diagonal block; the rest of "first" then runs on stream3
-        const bool split = split_sched(), lean = sched_mode() == 3;
+        // columns / rows; pass 2 ("rest"): everything beyond.
+        // Tiles (k1,k1) and (k1+1,k1) are not touched here at all: the steps of this panel have brought
+        // them up to date already (see the in-panel lists).  The same two tiles of the panel after next,
+        // (n1,n1) and (n1+1,n1), belong to "next" rather than "rest": the next panel's steps start
+        // updating them as soon as "next" is done, while "rest" may still be running.
+        const bool split = split_sched();
         auto clsB = [&](int i, int j) {
-            if (lean && j == k1 && i <= k1 + 1) return -1;
+            if (j == k1 && i <= k1 + 1) return -2;
             if (j == k1 || (split && j < n1 && i <= j + 1)) return 0;
-            return j < n1 ? 1 : 2;
+            if (j < n1 || (j == n1 && i <= n1 + 1)) return 1;
+            return 2;
         };
         auto clsR = [&](int i) { return i == k1 ? 0 : (i < n1 ? 1 : 2); };
-        for (int pass = -1; pass < 3; ++pass) {
+        for (int pass = 0; pass < 3; ++pass) {
             const size_t begin = v.size();
             for (int i = k1; i < T; ++i) {
                 for (int j = k1; j <= i; ++j) {
@@ -514,8 +520,7 @@ int ensure_tasks(gprn_ctx* c)
                                          (k1 - cc) * GPRN_TILE, BUF_X, BUF_B, BUF_X,
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
-            if (pass == -1) { o.c1_0 = begin; o.nc1 = v.size() - begin; }
-            else if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
+            if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
             else if (pass == 1) { o.next0 = begin; o.nnext = v.size() - begin; }
             else {
                 // Workgroups are dispatched in task order and are not preempted: with the short
@@ -602,10 +607,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // a second code object for one small launch per step).  GPRN_TRI=0 switches it off.
     static int tri = -1;
     if (tri < 0) { const char* e = getenv("GPRN_TRI"); tri = e ? atoi(e) : 1; }
+    // tag: TG_PANEL for the panel products (the only users of the 64x128 / 128x64 shapes), else as given
     auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL,
-                     Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr}) {
+                     Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr}, int tag = TG_INNER) {
+        if (shape == TS_64x128 || shape == TS_128x64) tag = TG_PANEL;
         if (tri) shape = shape == TS_64x128 ? TS_64x128_BTRI : (shape == TS_128x64 ? TS_128x64_ATRI : shape);
-        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, aw);
+        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, aw, tag);
     };
     // Cross-stream dependencies travel through 32-bit flags in device memory instead of events:
     // hipStreamWriteValue32 / hipStreamWaitValue32 cost less than an event record / wait pair
@@ -615,7 +622,6 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     const int use_flags = factor_use_flags(c);
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
-    const bool lean = sched_mode() == 3;           // panel boundaries: only two tiles stay on the chain
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
         c->d_sig = nullptr;
@@ -684,43 +690,31 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         return use_flags ? Signal{slot(k, F_XW), 0, slot(k, F_MINIL) + 1, epoch, timed_out}
                          : Signal{nullptr, 0, nullptr, 0, nullptr};
     };
+    const Await noaw{nullptr, 0, nullptr};
+    const Signal nosig{nullptr, 0, nullptr, 0, nullptr};
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
             const gprn_ctx::StepRange& s = c->steps[set][k];
-            const bool last = (k == o.k1 - 1);     // no in-panel columns right of the last step
-            const bool outer_follows = o.nc1 + o.nfirst + o.nnext + o.nrest > 0;
-            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0,
-                                  last && !(lean && outer_follows) ? Signal{nullptr, 0} : in_kernel(k, F_DIAG)))) return rc;
-            const bool spin = use_flags && k > o.k0 && (!last || (lean && outer_follows));
-            const Await inner_done = spin ? in_kernel_wait(k - 1, F_INNER) : Await{nullptr, 0, nullptr};
-            if (k > o.k0 && !spin) HIP_TRY(c, await(s0, k - 1, F_INNER));
-            if (last && lean && outer_follows) {
-                // chain: the two panel rows the c1 update reads; stream3: the rest of the panel
-                const size_t nmini = std::min<size_t>(2, s.npanel_l);
-                if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
-                if ((rc = tiles(s.panel0, nmini, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), inner_done))) return rc;
-                if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
-                if ((rc = side_sync(k))) return rc;
-                if ((rc = tiles(s.panel0 + nmini, s.npanel_l - nmini, s1, TS_64x128))) return rc;
-                if (s.npanel > s.npanel_l && use_flags) {
-                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
-                                    x_part_then(k)))) return rc;
-                } else {
-                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
-                    HIP_TRY(c, await(s1, k, F_MINIL));
-                }
-                continue;
-            }
-            if (last) {
-                if ((rc = flush_inner())) return rc;
-                if ((rc = tiles(s.panel0, s.npanel_l, s0, TS_64x128))) return rc;
-                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s0, TS_128x64))) return rc;
-                continue;
-            }
+            // Every tile step looks the same to the chain, panel boundaries included (the two tiles the
+            // next panel starts with are updated step by step, see ensure_tasks):
+            //   chain  : diag(k)  ->  L_{k+1,k}  ->  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T
+            //   stream3: the other panel tiles, then the other in-panel updates of the step
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG)))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
-            // chain: L_{k+1,k}, then B_{k+1,k+1}
-            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), inner_done))) return rc;
+            if (s.npanel_l == 0) {
+                // last tile step of the matrix: row k of the inverse is all that is left
+                if ((rc = flush_inner())) return rc;
+                if (k > 0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+                if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64))) return rc;
+                continue;
+            }
+            // L_{k+1,k} reads what stream3's in-panel update of step k-1 wrote: in the flag schedule its
+            // two workgroups per matrix poll that flag themselves (a stream wait is a 5 us kernel of its own)
+            const bool spin = use_flags && k > 0;
+            if (k > 0 && !spin) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL),
+                            spin ? in_kernel_wait(k - 1, F_INNER) : noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
             if (first_J >= 0) {                        // B_{k+1,k+1} carries the previous panel's update
                 HIP_TRY(c, await(s0, first_J, F_FIRST));
@@ -748,56 +742,28 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
                                                        // chain's wait for step k is enqueued at step k + 1
         }
-        if ((rc = flush_inner())) return rc;
-        if (next_J >= 0) {                             // one-step panel: nothing consumed it yet
-            HIP_TRY(c, await(s0, next_J, F_NEXT));
-            next_J = -1;
-        }
-        if (first_J >= 0) {                            // (a one-step panel)
-            HIP_TRY(c, await(s0, first_J, F_FIRST));
-            first_J = -1;
-        }
-        if (o.nc1 + o.nfirst + o.nnext + o.nrest == 0) continue;
-        // Outer update of panel J.  On the chain stream what the chain touches in the next panel
-        // (its first column of B and first row of R, its diagonal and sub-diagonal tiles); the
-        // rest of the next panel and everything beyond go to the bulk stream.
-        if (lean) {
-            // chain: the two tiles the next diagonal block and L_{k1+1,k1} need; stream3 (which has
-            // the whole panel once it has seen the chain's two rows): everything else of "first"
-            if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
-            // The bulk stream is released when these two tiles are done, not before: the next diagonal
-            // block is dispatched at that moment too and, from the higher-priority stream, takes its CUs
-            // before the bulk's workgroups flood them (+0.5 % sweeps/s).  GPRN_HOLD_BULK=0 switches it off.
-            static int hold = -1;
-            if (hold < 0) { const char* e = getenv("GPRN_HOLD_BULK"); hold = e ? atoi(e) : 1; }
-            const bool hold_bulk = use_flags && hold && o.nc1 > 0;
-            if ((rc = tiles(o.c1_0, o.nc1, s0, TS_64x64, GPRN_T_PANEL,
-                            hold_bulk ? in_kernel((int)J, F_XW) : Signal{nullptr, 0}))) return rc;
-            if (hold_bulk) HIP_TRY(c, await(s2, (int)J, F_XW));
-            HIP_TRY(c, raise(s1, (int)J, F_PANEL));
-            if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, F_REST));
-            if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
-            if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst)))) return rc;
-            HIP_TRY(c, raise(s1, (int)J, F_FIRST));
-            if (o.nfirst > 0) first_J = (int)J;
-        } else {
-            HIP_TRY(c, raise(s0, (int)J, F_PANEL));
-            if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
-            if ((rc = tiles(o.first0, o.nfirst, s0, shape_upd(o.nfirst)))) return rc;
-        }
+        if ((rc = flush_inner())) return rc;           // the chain's next step must not queue behind the outer update
+        if (o.nfirst + o.nnext + o.nrest == 0) continue;
+        // Outer update of panel J (K = its width).  stream3, which has seen every tile of the panel: what
+        // the chain touches first in the next panel (its first column of B and first row of R, its diagonal
+        // and sub-diagonal tiles); bulk stream: the rest of the next panel, then everything beyond.  The
+        // chain itself goes straight on with the next diagonal block.
+        HIP_TRY(c, raise(s1, (int)J, F_PANEL));
+        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, F_REST));      // same tiles as the previous panel's rest / next
+        if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+        if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        HIP_TRY(c, raise(s1, (int)J, F_FIRST));
+        if (o.nfirst > 0) first_J = (int)J;
         HIP_TRY(c, await(s2, (int)J, F_PANEL));
-        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext)))) return rc;
+        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, raise(s2, (int)J, F_NEXT));
         if (o.nnext > 0) next_J = (int)J;
         if (o.nrest) {
-            // 64x64 workgroups for the bulk as well: a quarter of the work per workgroup, so CUs come
-            // free four times as often for the chain's kernels (the diagonal block needs a SIMD without
-            // a 128x128 wave: 372 + 225 registers do not fit), and its waves can share a SIMD with
-            // them; stand-alone the two shapes are within 3 % at K = 512.  +1.6 % sweeps/s at config 3.
-            // GPRN_BULK_SHAPE=0 brings the 128x128 workgroups back.
+            // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
+            // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
             static int bulk_shape = -1;
             if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
-            if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE))) return rc;
+            if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
             HIP_TRY(c, raise(s2, (int)J, F_REST));
             rest_J = (int)J;
         }
@@ -830,6 +796,8 @@ int factor_invert(gprn_ctx* c, int nbatch)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
     if (split_sched()) return factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
     bool rest_pending = false, next_pending = false;
+    const Signal nosig{nullptr, 0, nullptr, 0, nullptr};
+    const Await noaw{nullptr, 0, nullptr};
     // Launches with few tasks are latency-bound (one workgroup per 128x128 task, K = 128 or 512 of
     // serial MFMA work each): cut their tasks into 64-row / 64-column pieces to use the idle CUs.
     // In-place panel tasks may only be cut along the dimension they do not read across.
@@ -845,17 +813,17 @@ int factor_invert(gprn_ctx* c, int nbatch)
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur))) return rc;
             if (few(s.npanel)) {
                 if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel_l, c->d_ptrs, nbatch, c->ld,
-                                       GPRN_T_PANEL, nullptr, TS_64x128))) return rc;
+                                       GPRN_T_PANEL, nullptr, TS_64x128, nosig, noaw, TG_PANEL))) return rc;
                 if ((rc = launch_tiles(c, c->d_tasks + s.panel0 + s.npanel_l, s.npanel - s.npanel_l,
-                                       c->d_ptrs, nbatch, c->ld, GPRN_T_PANEL, nullptr, TS_128x64))) return rc;
+                                       c->d_ptrs, nbatch, c->ld, GPRN_T_PANEL, nullptr, TS_128x64, nosig, noaw, TG_PANEL))) return rc;
             } else if ((rc = launch_tiles(c, c->d_tasks + s.panel0, s.npanel, c->d_ptrs, nbatch, c->ld,
-                                          GPRN_T_PANEL))) return rc;
+                                          GPRN_T_PANEL, nullptr, TS_128x128, nosig, noaw, TG_PANEL))) return rc;
             if (next_pending) {                        // the other columns / rows of this panel
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_next, 0));
                 next_pending = false;
             }
             if ((rc = launch_tiles(c, c->d_tasks + s.upd0, s.nupd, c->d_ptrs, nbatch, c->ld,
-                                   GPRN_T_PANEL, nullptr, few(s.nupd) ? TS_64x64 : TS_128x128))) return rc;
+                                   GPRN_T_PANEL, nullptr, few(s.nupd) ? TS_64x64 : TS_128x128, nosig, noaw, TG_INNER))) return rc;
         }
         if (o.nfirst + o.nnext + o.nrest == 0) continue;
         // Outer update of panel J.  On the chain stream only what the next panel's first tile step
@@ -866,15 +834,15 @@ int factor_invert(gprn_ctx* c, int nbatch)
         if (rest_pending)                              // same tiles as the previous panel's rest
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_rest, 0));
         if ((rc = launch_tiles(c, c->d_tasks + o.first0, o.nfirst, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_PANEL, nullptr, few(o.nfirst) ? TS_64x64 : TS_128x128))) return rc;
+                               GPRN_T_PANEL, nullptr, few(o.nfirst) ? TS_64x64 : TS_128x128, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_panel, 0));
         if ((rc = launch_tiles(c, c->d_tasks + o.next0, o.nnext, c->d_ptrs, nbatch, c->ld,
-                               GPRN_T_PANEL, c->stream2, few(o.nnext) ? TS_64x64 : TS_128x128))) return rc;
+                               GPRN_T_PANEL, c->stream2, few(o.nnext) ? TS_64x64 : TS_128x128, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, hipEventRecord(c->ev_next, c->stream2));
         next_pending = o.nnext > 0;
         if (o.nrest) {
             if ((rc = launch_tiles(c, c->d_tasks + o.rest0, o.nrest, c->d_ptrs, nbatch, c->ld,
-                                   GPRN_T_UPDATE, c->stream2))) return rc;
+                                   GPRN_T_UPDATE, c->stream2, TS_128x128, nosig, noaw, TG_BULK))) return rc;
             HIP_TRY(c, hipEventRecord(c->ev_rest, c->stream2));
             rest_pending = true;
         }

@@ -5,31 +5,68 @@
 // the panel solves (as products with the inverted diagonal block) and the
 // X^T X product behind quirk Q1 (see factor.hip for the task lists).
 //
-// Work decomposition: one 256-thread workgroup (4 waves, 2x2) per 128x128
-// output tile, each wave a 64x64 sub-tile = 4x4 MFMA tiles of 16x16, i.e. 16
-// independent accumulators (128 VGPRs) -- enough to issue the 64-cycle f64 MFMA
-// back to back.  K is streamed in chunks of 16 through a double-buffered LDS
-// image (global -> registers -> LDS, one barrier per chunk); global loads of
-// chunk c+1 are in flight while chunk c is multiplied.
+// Work decomposition: one 256-thread workgroup (4 waves, 2x2) per output tile of
+// BM x BN in {64,128}^2; each wave a (BM/2)x(BN/2) sub-tile of 16x16 MFMA tiles
+// (128x128: 16 independent accumulators = 128 VGPRs).  K is streamed in chunks of
+// 16 through a double-buffered LDS image (global -> registers -> LDS, one barrier
+// per chunk); global loads of chunk c+2 are in flight while chunk c is multiplied.
 //
-// LDS images (conflict-free for the one-f64-per-lane MFMA operand fetch,
-// ds_read_b64, banks = (addr/4)%64):
-//   operand stored k-contiguous in memory  -> image [row][k],  pitch 18 doubles
-//   operand stored row-contiguous in memory-> image [k][row],  pitch 144 doubles
-// both 2304 doubles per operand per stage; 4 x 18 KiB = 72 KiB per workgroup,
-// two workgroups per CU.
+// LDS image: BOTH operands are kept [k][row] (pitch rows+16 doubles, rows XOR-swizzled
+// by 4*((k>>1)&3)), whatever their layout in memory -- a k-contiguous operand is
+// transposed on its way in (two ds_write_b64 per 16-byte load either way).  With one
+// layout the fragment addresses of the inner loop are lane bases plus immediates:
+// the loop body has no address arithmetic, only MFMA, ds_read, ds_write, global_load.
+//   operand fetch (one f64 per lane, ds_read_b64): lanes (fr, fk) of a 32-lane half
+//     hit 16*fk + (fr ^ s) mod 32 -- conflict-free (pitch = 16 mod 32);
+//   k-contiguous staging: a 16-lane group writes rows 4a+rr (rr<4), pairs kp<4 to
+//     (row ^ 4kp) -- 16 distinct; row-contiguous staging: 16 consecutive row pairs (2-way on
+//     ds_write_b64's 32 banks, no more LDS cycles than the instruction takes to issue).
+// 2 stages x 2 operands x 16 x (128+16) x 8 B = 72 KiB for 128x128: two workgroups per CU.
+//
+// C -= A.B runs as acc = -C, acc += A.B, C = -acc: the tile is read once, up front, with
+// all loads back to back, the epilogue is stores only, and the operands need no sign.
 #include "gprn_internal.h"
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef const GPRN_GLOBAL v2d* gv2d_t;
+typedef const GPRN_GLOBAL char* gcbytes_t;
 
-// Output tile of one workgroup: BM x BN in {64,128}^2.  A 128x128 task is cut into
-// (128/BM) x (128/BN) workgroups (sub-tile index = blockIdx.x % that).  128x128 is the
-// throughput shape (bulk updates); the smaller shapes put a latency-bound launch -- a few
-// dozen tasks with K = 128 on the factorisation's critical path -- on 2-4x as many CUs:
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Staging geometry.  A thread moves R*8/NT 16-byte pieces of an operand chunk (R rows x 16 k); piece `it`
+// differs from piece 0 by +64 rows (only when the lanes cover 64 of 128 rows) and/or +8 k in BOTH memory
+// layouts, so one lane offset serves all pieces: memory address = base + lane offset + a uniform per-piece
+// offset (the buffer load's scalar offset), LDS address = lane base + an immediate.
+//   mode 0, element (row, k) at row*ld + k: piece = (row, 2kp), (row, 2kp+1); lane = (kp & 3, row)
+//   mode 1, element (row, k) at k*ld + row: piece = (2rp, k), (2rp+1, k);     lane = (rp, k & 7)
+template <int R, int NT>
+__device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigned& goff, int& l0)
+{
+    constexpr int P = R + 16;
+    constexpr int RL = (R < NT / 4) ? R : NT / 4;          // rows the lane index spans (64 or 128)
+    static_assert(R * 8 >= NT && (RL == 64 || RL == 128), "unsupported tile / workgroup combination");
+    if (mode == 0) {
+        const int kp = tid & 3, row = (tid >> 2) & (RL - 1);
+        goff = ((unsigned)row * (unsigned)ld + 2u * kp) * 8u;
+        l0 = (2 * kp) * P + (row ^ (4 * kp));
+    } else {
+        const int rp = tid & (RL / 2 - 1), k = tid / (RL / 2);      // k < 8
+        goff = ((unsigned)k * (unsigned)ld + 2u * rp) * 8u;
+        l0 = k * P + ((2 * rp) ^ (4 * ((k >> 1) & 3)));
+    }
+}
+
+// Output tile of one workgroup: BM x BN in {64,128}^2, computed by NW = 4 waves (2 x 2) or 8 waves (2 x 4).
+// A 128x128 task is cut into (128/BM) x (128/BN) workgroups (sub-tile index = blockIdx.x % that).
+// 128x128 on 8 waves is the throughput shape: 64x32 per wave = 8 accumulators, under 128 VGPRs, so two
+// workgroups = four waves per SIMD share a CU and cover each other's barriers and memory waits.  The
+// smaller 4-wave shapes put a latency-bound launch -- a few dozen tasks with K = 128 on the factorisation's
+// critical path -- on 2-4x as many CUs:
 //   64x128 (rows split)  is safe for in-place panel tasks whose C tile is their A operand,
 //   128x64 (cols split)  for in-place tasks whose C tile is their B operand,
 //   64x64                for everything that is not in place.
@@ -37,98 +74,123 @@ typedef const GPRN_GLOBAL v2d* gv2d_t;
 // explicit zeros above): 1 = it is B, transposed (panel product L_ik = B_ik X_kk^T: k <= n),
 // 2 = it is A (X_kc = X_kk R_kc: k <= m).  K-chunks that only meet the zero half of a 16-wide
 // block are skipped -- 28 of 64 block products.
-template <int BM, int BN, int TRI = 0>
-__global__ __launch_bounds__(256, 2)
+// TAG only names the launch family in profiles (rocprofv3 reports one row per instantiation):
+// TG_PANEL panel products, TG_INNER in-panel K=128 updates, TG_NEXT next-panel K=512 updates,
+// TG_BULK bulk K=512 updates, TG_MISC the rest.
+template <int BM, int BN, int NW, int TRI, int TAG>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out)
 {
     await_flag(wait_flag, wait_value, wait_timed_out);
+    constexpr int NT = 64 * NW, WM = 2, WN = NW / 2;            // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
-    constexpr int MI = BM / 32, NI = BN / 32;                   // 16x16 MFMA tiles per wave (2x2 waves)
-    constexpr int A_DOUBLES = 16 * BM + 256, B_DOUBLES = 16 * BN + 256;   // >= BM*18 and 16*(BM+16)
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;               // 16-byte loads per thread per chunk
-    __shared__ __attribute__((aligned(16))) double lds[2 * (A_DOUBLES + B_DOUBLES)];
+    constexpr int TM = BM / WM, TN = BN / WN;                   // a wave's part of the tile
+    constexpr int MI = TM / 16, NI = TN / 16;                   // 16x16 MFMA tiles per wave
+    constexpr int PA = BM + 16, PB = BN + 16;                   // LDS pitches, doubles
+    constexpr int A_DOUBLES = 16 * PA, B_DOUBLES = 16 * PB;
+    constexpr int STAGE = A_DOUBLES + B_DOUBLES;
+    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte loads per thread per chunk
+    constexpr bool A_ROWS2 = BM * 4 > NT, B_ROWS2 = BN * 4 > NT;   // the pieces of a thread span 2 x 64 rows
+    static_assert(A_IT >= 1 && B_IT >= 1 && NI >= 1 && (MI % 2 == 0) && (NI % 2 == 0), "tile too small for the workgroup");
+    __shared__ __attribute__((aligned(16))) double lds[2 * STAGE];
 
     const TileTask t = tasks[blockIdx.x / (SM * SN)];
     const int sub = blockIdx.x % (SM * SN), sr = sub / SN, sc = sub % SN;
+    // the slot's four buffer pointers in one scalar load, side by side with the task (no load depends on it)
     double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
+    auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
     const int c_mode = t.modes & 3;
     const int a_mode = (t.modes >> 2) & 1;
     const int b_mode = (t.modes >> 3) & 1;
-    gcptr_t A = (gcptr_t)(gp[t.a_buf] + t.a_off) + (a_mode ? (size_t)sr * BM : (size_t)sr * BM * ld);
-    gcptr_t B = (gcptr_t)(gp[t.b_buf] + t.b_off) + (b_mode ? (size_t)sc * BN : (size_t)sc * BN * ld);
-    gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off) + (size_t)sr * BM * ld + sc * BN;
+    const double* A = pick(t.a_buf) + t.a_off + (a_mode ? (size_t)sr * BM : (size_t)sr * BM * ld);
+    const double* B = pick(t.b_buf) + t.b_off + (b_mode ? (size_t)sc * BN : (size_t)sc * BN * ld);
+    gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sr * BM * ld + sc * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WN, wc = wave % WN;
 
-    // ---- global -> LDS staging geometry (pairs of doubles along the contiguous dim)
-    // k-contiguous operand: image [row][k], pitch 18;  row-contiguous: image [k][row], pitch rows+16
-    const int a_shift = a_mode ? (BM == 128 ? 6 : 5) : 3, b_shift = b_mode ? (BN == 128 ? 6 : 5) : 3;
-    const int a_pitch = a_mode ? BM + 16 : 18, b_pitch = b_mode ? BN + 16 : 18;
-    const size_t a_step = a_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
+    // ---- global -> LDS staging (lane_geometry): buffer loads = uniform base (advanced per chunk) + lane
+    // offset + uniform piece offset; the two doubles of a piece go to lane base (+ dl) + immediate
+    const size_t a_step = a_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;       // doubles per chunk
     const size_t b_step = b_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
-    size_t a_g[A_IT], b_g[B_IT];
-    int a_l[A_IT], b_l[B_IT];
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int pi = tid + 256 * it;
-        const int as = pi >> a_shift, af = pi & ((1 << a_shift) - 1);
-        a_g[it] = (size_t)as * ld + 2 * af;
-        a_l[it] = as * a_pitch + 2 * af;
-    }
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int pi = tid + 256 * it;
-        const int bs = pi >> b_shift, bf = pi & ((1 << b_shift) - 1);
-        b_g[it] = (size_t)bs * ld + 2 * bf;
-        b_l[it] = bs * b_pitch + 2 * bf;
-    }
-    // ---- MFMA operand fetch geometry: lane holds A[row = l&15][k = l>>4], B[k = l>>4][col = l&15]
+    unsigned a_g, b_g;
+    int a_l, b_l;
+    lane_geometry<BM, NT>(tid, a_mode, ld, a_g, a_l);
+    lane_geometry<BN, NT>(tid, b_mode, ld, b_g, b_l);
+    const int a_l0 = a_l * 8, a_l1 = a_l0 + (a_mode ? 1 : PA) * 8;              // LDS byte addresses, stage 0
+    const int b_l0 = (A_DOUBLES + b_l) * 8, b_l1 = b_l0 + (b_mode ? 1 : PB) * 8;
+    // uniform piece offsets in memory, bytes: +64 rows, +8 k
+    const unsigned a_row64 = (a_mode ? 64u : 64u * (unsigned)ld) * 8u, a_k8 = (a_mode ? 8u * (unsigned)ld : 8u) * 8u;
+    const unsigned b_row64 = (b_mode ? 64u : 64u * (unsigned)ld) * 8u, b_k8 = (b_mode ? 8u * (unsigned)ld : 8u) * 8u;
+    // ---- MFMA operand fetch: lane holds A[row = fr][k = fk], B[k = fk][col = fr]; LDS byte address of
+    // k4-step ks = lane base[ks] + immediate (16-row block, stage)
     const int fr = lane & 15, fk = lane >> 4;
-    const int a_rs = a_mode ? 1 : 18, a_ks = a_mode ? BM + 16 : 1;
-    const int b_rs = b_mode ? 1 : 18, b_ks = b_mode ? BN + 16 : 1;
-    const int mb16 = (sr * BM + wr * (BM / 2)) >> 4, nb16 = (sc * BN + wc * (BN / 2)) >> 4;   // wave's first 16-blocks
-    const int a_frag = (wr * (BM / 2) + fr) * a_rs + fk * a_ks;
-    const int b_frag = (wc * (BN / 2) + fr) * b_rs + fk * b_ks;
+    const int mb16 = (sr * BM + wr * TM) >> 4, nb16 = (sc * BN + wc * TN) >> 4;   // wave's first 16-blocks
+    int a_fb[4], b_fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int k = 4 * ks + fk, sw = fr ^ (4 * ((k >> 1) & 3));
+        a_fb[ks] = (k * PA + wr * TM + sw) * 8;
+        b_fb[ks] = (A_DOUBLES + k * PB + wc * TN + sw) * 8;
+    }
+    const char* const lds_b = reinterpret_cast<const char*>(lds);
+    char* const lds_w = reinterpret_cast<char*>(lds);
+    auto frag = [&](int byte_addr) { return *reinterpret_cast<const double*>(lds_b + byte_addr); };
 
-    // C -= A.B runs as D = (-A).B + C with the accumulators preloaded from C: the tile is read
-    // once, up front and all loads back to back (a read-modify-write epilogue serialises into
-    // dependent load->store round trips), and the epilogue is stores only.
-    const double a_sign = (c_mode == CM_SET) ? 1.0 : -1.0;
-    gptr_t Cw = C + (size_t)(wr * (BM / 2) + fk) * ld + wc * (BN / 2) + fr;
+    const bool neg = c_mode != CM_SET;                       // acc holds -(result)
+    gptr_t Cw = C + (size_t)(wr * TM + fk) * ld + wc * TN + fr;
     v4d acc[MI][NI];
 
     const int nchunks = t.klen / GPRN_KC;
-    // (de-phasing co-resident workgroups by half a chunk and s_setprio around the MFMA clusters
-    // measured no gain; PMC: MFMA pipe busy 78 %
-    // of the cycles at an effective 2.13 GHz, no LDS bank conflicts -- DESIGN.md section 8)
-    // Software pipeline over K-chunks, one barrier per chunk:
-    //   registers hold chunk c+1 (requested during chunk c-1 ... c), LDS stage c&1 holds chunk c.
-    //   While chunk c is multiplied, chunk c+1 is written to the other LDS stage after the second
-    //   of the four k4-steps (its global loads have had >2000 cycles), and chunk c+2 is requested.
-    //   The barrier at the end of the chunk publishes stage (c+1)&1 and retires the reads of c&1.
-    // The LDS staging therefore overlaps the MFMA stream instead of sitting between two chunks.
     v2d ra[A_IT], rb[B_IT];
+    auto load_chunk = [&]() {
+        // raw buffer resources over the chunk's base: 48-bit address, no stride, no bounds (num_records max)
+        const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
+        for (int it = 0; it < A_IT; ++it) {
+            const unsigned so = A_ROWS2 ? (it & 1) * a_row64 + (it >> 1) * a_k8 : it * a_k8;
+            ra[it] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, a_g, so, 0));
+        }
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
+        for (int it = 0; it < B_IT; ++it) {
+            const unsigned so = B_ROWS2 ? (it & 1) * b_row64 + (it >> 1) * b_k8 : it * b_k8;
+            rb[it] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, b_g, so, 0));
+        }
+    };
+    auto write_chunk = [&](int stage_bytes) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int imm = stage_bytes + (A_ROWS2 ? (it & 1) * 64 * 8 + (it >> 1) * 8 * PA * 8 : it * 8 * PA * 8);
+            *reinterpret_cast<double*>(lds_w + a_l0 + imm) = ra[it][0];
+            *reinterpret_cast<double*>(lds_w + a_l1 + imm) = ra[it][1];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int imm = stage_bytes + (B_ROWS2 ? (it & 1) * 64 * 8 + (it >> 1) * 8 * PB * 8 : it * 8 * PB * 8);
+            *reinterpret_cast<double*>(lds_w + b_l0 + imm) = rb[it][0];
+            *reinterpret_cast<double*>(lds_w + b_l1 + imm) = rb[it][1];
+        }
+    };
+
+    load_chunk();
     // The C tile is requested AFTER the first operand chunk: memory returns in order, so the
     // LDS staging below waits only for the chunk, and the first MFMA of each accumulator only for
-    // its own four values -- most of the 128 KiB tile streams in behind the first MFMAs.
+    // its own four values -- most of the tile streams in behind the first MFMAs.
     __builtin_amdgcn_sched_barrier(0);
-    if (c_mode == CM_SUB) {                      // one uniform branch around all 16*MI*NI/4 loads
+    if (c_mode == CM_SUB) {                      // one uniform branch around all the loads
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16];
+                    acc[i][j][r] = -Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16];
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -136,77 +198,86 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
             for (int j = 0; j < NI; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
     }
     __builtin_amdgcn_sched_barrier(0);
-    {
-        double* sA = lds;
-        double* sB = sA + A_DOUBLES;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) *reinterpret_cast<v2d*>(sA + a_l[it]) = ra[it] * a_sign;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v2d*>(sB + b_l[it]) = rb[it];
-    }
-    if (nchunks > 1) {
-        A += a_step;
-        B += b_step;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
-    }
+    write_chunk(0);
+    if (nchunks > 1) { A += a_step; B += b_step; }
+    load_chunk();                                // chunk 1 (chunk 0 again when there is only one)
     __syncthreads();
 
-    for (int c = 0; c < nchunks; ++c) {
-        const double* sA = lds + (c & 1) * (A_DOUBLES + B_DOUBLES);
-        const double* sB = sA + A_DOUBLES;
-        double* nA = lds + ((c + 1) & 1) * (A_DOUBLES + B_DOUBLES);
-        double* nB = nA + A_DOUBLES;
-        // Operand fragments of k4-step ks+1 are fetched from LDS before the MFMAs of step ks are
-        // issued: a lone wave per SIMD (bulk launches run at one workgroup per CU) then does not
-        // drain the matrix pipe at every step waiting for its own ds_reads (44 -> 46 TF at K = 512
-        // and one workgroup per CU).  Carrying the fetch-ahead across the chunk boundary as well
-        // (barrier after the third step, first fragments of the next chunk read during the fourth)
-        // measured no further gain.
-        double af[2][MI], bf[2][NI];
+    // fragments of the k4-step about to be multiplied: B's are fetched a whole step ahead (every
+    // MFMA of a step reads them), A's row block by row block as the previous step lets go of them
+    double af[MI], bf[2][NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[0][i] = sA[a_frag + i * 16 * a_rs];
+    for (int i = 0; i < MI; ++i) af[i] = frag(a_fb[0] + i * 128);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bf[0][j] = sB[b_frag + j * 16 * b_rs];
+    for (int j = 0; j < NI; ++j) bf[0][j] = frag(b_fb[0] + j * 128);
+
+    // One K-chunk: four k4-steps of MI*NI MFMAs.  Beside them: the fragments of the next step, the
+    // staging of chunk c+1 into the other LDS stage (second step; its global loads were issued a
+    // chunk ago), the request of chunk c+2, and -- before the last step -- the one barrier that
+    // publishes stage c+1 and retires the reads of stage c, so that the last step can already fetch
+    // the first fragments of the next chunk.  The sched_group_barrier sequences spread the memory
+    // instructions between the MFMAs (each holds the matrix pipe for 64 cycles: whatever issues in
+    // its shadow is free, whatever is clustered between two of them is not).
+    auto chunk = [&](auto last_c, int sb, int c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const int nb = sb ^ (STAGE * 8);                       // byte offsets of this chunk's and the next one's stage
 #pragma unroll
-        for (int ks = 0; ks < GPRN_KC / 4; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {
             const int cur = ks & 1, nxt = cur ^ 1;
-            if (ks + 1 < GPRN_KC / 4) {
+            const bool fetch = ks < 3 || !LAST;                // there is a next step
+            const int fb_off = ks < 3 ? sb : nb, fb_ks = ks < 3 ? ks + 1 : 0;
+            if (fetch) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) af[nxt][i] = sA[a_frag + i * 16 * a_rs + (ks + 1) * 4 * a_ks];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[nxt][j] = sB[b_frag + j * 16 * b_rs + (ks + 1) * 4 * b_ks];
+                for (int j = 0; j < NI; ++j) bf[nxt][j] = frag(fb_off + b_fb[fb_ks] + j * 128);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 1 && !LAST) {
+                write_chunk(nb);
+                // chunk c+2, or once more the last one (its registers are not read again)
+                const bool more = c + 2 < nchunks;
+                A += more ? a_step : 0;
+                B += more ? b_step : 0;
+                load_chunk();
+            }
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) {
                     if (TRI == 1 && c > nb16 + j) continue;     // wave-uniform
                     if (TRI == 2 && c > mb16 + i) continue;
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
-            if (ks == 1 && c + 1 < nchunks) {
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int it = 0; it < A_IT; ++it) *reinterpret_cast<v2d*>(nA + a_l[it]) = ra[it] * a_sign;
-#pragma unroll
-                for (int it = 0; it < B_IT; ++it) *reinterpret_cast<v2d*>(nB + b_l[it]) = rb[it];
-                if (c + 2 < nchunks) {
-                    A += a_step;
-                    B += b_step;
-#pragma unroll
-                    for (int it = 0; it < A_IT; ++it) ra[it] = *(gv2d_t)(A + a_g[it]);
-#pragma unroll
-                    for (int it = 0; it < B_IT; ++it) rb[it] = *(gv2d_t)(B + b_g[it]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                if (fetch) af[i] = frag(fb_off + a_fb[fb_ks] + i * 128);
             }
+            if (TRI == 0) {
+                // issue order of this step: MFMAs and memory instructions in turn (adjacent fragment
+                // reads pair up into ds_read2_b64: (MI + NI) / 2 read instructions per step)
+                constexpr int NMF = MI * NI, NRD = (MI + NI) / 2;
+                constexpr int NWR = 2 * (A_IT + B_IT), NLD = A_IT + B_IT;
+                if (ks == 1 && !LAST) {
+#pragma unroll
+                    for (int g = 0; g < NLD; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF / NLD, 0);
+                        if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, NWR / NLD, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                } else if (fetch) {
+#pragma unroll
+                    for (int g = 0; g < NRD; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+            }
+            if (ks == 2 && !LAST) __syncthreads();
         }
-        __syncthreads();
+    };
+    int sb = 0;
+    for (int c = 0; c < nchunks - 1; ++c) {
+        chunk(std::false_type{}, sb, c);
+        sb ^= STAGE * 8;
     }
+    chunk(std::true_type{}, sb, nchunks - 1);
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
@@ -215,12 +286,23 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = acc[i][j][r];
+                Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = neg ? -acc[i][j][r] : acc[i][j][r];
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
+template <int BM, int BN, int TRI, int TAG>
+static void launch_one(const TileTask* d_tasks, size_t ntasks, double* const* tab, int nbatch, int ld,
+                       size_t dyn, hipStream_t stream, const Signal& sig, const Await& aw)
+{
+    constexpr int per_task = (GPRN_TILE / BM) * (GPRN_TILE / BN);
+    constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
+    hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
+                       dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
+                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+}
+
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
-                 int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig, Await aw)
+                 int nbatch, int ld, int fam, hipStream_t stream, int shape, Signal sig, Await aw, int tag)
 {
     if (!stream) stream = c->stream;
     if (ntasks == 0 || nbatch == 0) {
@@ -258,38 +340,34 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     const int kb = nbatch <= pad_small_batch ? pad_small_kb : pad_kb;
     const size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
     double* const* tab = (double* const*)d_ptrs;
-    switch (shape) {
-    case TS_64x64:
-        hipLaunchKernelGGL((k_tile_gemm<64, 64>), dim3((unsigned)ntasks * 4, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-        break;
-    case TS_64x128:
-        hipLaunchKernelGGL((k_tile_gemm<64, 128>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-        break;
-    case TS_128x64:
-        hipLaunchKernelGGL((k_tile_gemm<128, 64>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-        break;
-    case TS_64x128_BTRI:
-        hipLaunchKernelGGL((k_tile_gemm<64, 128, 1>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-        break;
-    case TS_128x64_ATRI:
-        hipLaunchKernelGGL((k_tile_gemm<128, 64, 2>), dim3((unsigned)ntasks * 2, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-        break;
-    default:
-        hipLaunchKernelGGL((k_tile_gemm<128, 128>), dim3((unsigned)ntasks, (unsigned)nbatch), dim3(256),
-                           dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                           aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+#define GO(BM, BN, TRI, TAG) launch_one<BM, BN, TRI, TAG>(d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw)
+    bool known = true;
+    switch (shape * 8 + tag) {
+    // panel products (K = 128 against the triangular X_kk; the plain forms when GPRN_TRI=0)
+    case TS_64x128_BTRI * 8 + TG_PANEL: GO(64, 128, 1, TG_PANEL); break;
+    case TS_128x64_ATRI * 8 + TG_PANEL: GO(128, 64, 2, TG_PANEL); break;
+    case TS_64x128 * 8 + TG_PANEL: GO(64, 128, 0, TG_PANEL); break;
+    case TS_128x64 * 8 + TG_PANEL: GO(128, 64, 0, TG_PANEL); break;
+    case TS_128x128 * 8 + TG_PANEL: GO(128, 128, 0, TG_PANEL); break;
+    // in-panel updates, K = 128
+    case TS_64x64 * 8 + TG_INNER: GO(64, 64, 0, TG_INNER); break;
+    case TS_128x128 * 8 + TG_INNER: GO(128, 128, 0, TG_INNER); break;
+    // next-panel part of an outer update, K = 512
+    case TS_64x64 * 8 + TG_NEXT: GO(64, 64, 0, TG_NEXT); break;
+    case TS_128x128 * 8 + TG_NEXT: GO(128, 128, 0, TG_NEXT); break;
+    // bulk of an outer update, K = 512
+    case TS_64x64 * 8 + TG_BULK: GO(64, 64, 0, TG_BULK); break;
+    case TS_128x128 * 8 + TG_BULK: GO(128, 128, 0, TG_BULK); break;
+    // X^T X, prediction products, diagnostics
+    case TS_128x128 * 8 + TG_MISC: GO(128, 128, 0, TG_MISC); break;
+    case TS_64x64 * 8 + TG_MISC: GO(64, 64, 0, TG_MISC); break;
+    case TS_64x128 * 8 + TG_MISC: GO(64, 128, 0, TG_MISC); break;
+    case TS_128x64 * 8 + TG_MISC: GO(128, 64, 0, TG_MISC); break;
+    default: known = false;
     }
+#undef GO
     prof_end(c);
+    if (!known) { c->err = "launch_tiles: no kernel for this shape/tag"; return GPRN_E_ARG; }
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
 }
@@ -336,6 +414,6 @@ extern "C" int gprn_test_mfma_peak(gprn_ctx* c, int wg_per_cu, int iters, double
     float ms = 0.f;
     HIP_TRY(c, hipEventElapsedTime(&ms, e0, e1));
     *tflops = (double)nwg * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
     return GPRN_OK;
 }

@@ -171,6 +171,10 @@ int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
 enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
        TS_64x128_BTRI = 4, TS_128x64_ATRI = 5 };   // panel products with the triangular X_kk (gemm_tile.hip TRI)
+// launch family of a tile launch: a template tag of k_tile_gemm, so that a kernel trace reports every
+// family under its own kernel name (panel products, in-panel K=128 updates, next-panel K=512 updates,
+// bulk K=512 updates, everything else)
+enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4 };
 // Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
@@ -187,7 +191,8 @@ struct Signal {
 struct Await { const unsigned* flag; unsigned value; unsigned* timed_out; };
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
-                 Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr});
+                 Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},
+                 int tag = TG_MISC);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr});
 
