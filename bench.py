@@ -5,15 +5,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config 3] [--no-cpu]
 
 One "step" = one ELBOaux-equivalent sweep (meanfield.py:651-710) with the
-priors already factored, inputs resident in HBM.  With --gpus N > 1 (launched
-by torch.distributed.run, one rank per GPU) the same problem's latent GPs are
-sharded over the ranks (gpyrn_amd/sharding.py) -- strong scaling.  Rank 0
-prints one JSON line.  No torch import: the launcher only provides RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_*.
+priors already factored, inputs resident in HBM.  With --gpus N > 1 the same
+problem's latent GPs are sharded over N ranks, one per GPU
+(gpyrn_amd/sharding.py) -- strong scaling.  The ranks come either from a
+launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (e.g.
+`python -m torch.distributed.run`), or, when WORLD_SIZE is not set, from this
+script itself: before anything touches the GPU it starts N copies of itself as
+child processes, waits for them and relays rank 0's line.  Rank 0 prints one
+JSON line.  No torch import anywhere.
+
+The timed region is `--blocks` (default 5) blocks of exactly K steps, each
+bracketed by a barrier + device synchronisation and reduced with a MAX over the
+ranks; `value` is K / the median block, the spread is reported beside it.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -73,25 +81,73 @@ def sweep_flops(N, p, q):
     return (2 * G / 3 + (q - 1) / 3) * float(N)**3
 
 
+def _blas_build():
+    try:
+        from threadpoolctl import threadpool_info
+        libs = [i for i in threadpool_info() if i.get('user_api') == 'blas']
+        return '; '.join('%s %s (%s threads)' % (i.get('internal_api'), i.get('version'), i.get('num_threads'))
+                         for i in libs) or 'unknown'
+    except Exception:                      # noqa: BLE001 -- informational only
+        return 'unknown'
+
+
 def cpu_baseline(N, p, q, kind):
-    """The reference's formulation (oracle/cpu_ref.sweep_ref, 7 N^3 per latent GP)
-    on the host cores, on a bounded sample: the same N with p=1, q=1 (2 of the
-    G latent GPs), scaled by G/2 -- every GP costs the same in that formulation."""
+    """The reference's formulation (oracle/cpu_ref.sweep_ref, 7 N^3 per latent GP) on this box's
+    host cores, on the configuration itself: one full sweep of all G latent GPs with the BLAS
+    threads the library picks (all cores), and -- bounded, because 7 G N^3 on one core takes
+    minutes -- one sweep of the p = q = 1 problem of the same N (2 of the G GPs) on ONE BLAS thread,
+    scaled by G / 2 (every GP costs the same in that formulation)."""
     from oracle import cpu_ref
-    t, ys, es = synth.rv_series(N, 1)
-    spec = synth.component_spec(1, 1, kind)
-    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
-    y = np.array(ys)
-    Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, y)
-    mu, var = cpu_ref.init_mu_var(y, [n.pars[0] for n in nodes], [w.pars[0] for w in weights], jit)
-    t0 = time.time()
-    cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu, var)
-    dt = time.time() - t0
     G = q * (p + 1)
-    return {'value': 1.0 / (dt * G / 2), 'unit': 'sweeps/s', 'cores': os.cpu_count(),
-            'kind': 'port',
-            'sample': f'one reference-formulation sweep at N={N}, p=1, q=1 (2 of {G} latent GPs, '
-                      f'{dt:.1f} s, NumPy/SciPy LAPACK, all host cores), scaled by {G}/2'}
+
+    def one_sweep(pp, qq):
+        t, ys, es = synth.rv_series(N, pp)
+        spec = synth.component_spec(pp, qq, kind)
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        y = np.array(ys)
+        Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, y)
+        mu, var = cpu_ref.init_mu_var(y, [n.pars[0] for n in nodes], [w.pars[0] for w in weights], jit)
+        t0 = time.time()
+        cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu, var)
+        return time.time() - t0
+
+    dt_all = one_sweep(p, q)
+    out = {'value': 1.0 / dt_all, 'unit': 'sweeps/s', 'cores': os.cpu_count(), 'kind': 'port',
+           'sample': f'one full reference-formulation sweep of the configuration (N={N}, p={p}, q={q}: all {G} '
+                     f'latent GPs, {dt_all:.1f} s) with NumPy/SciPy LAPACK on all host cores',
+           'blas': _blas_build()}
+    try:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            dt_1 = one_sweep(1, 1)
+        out['one_thread'] = {'value': 1.0 / (dt_1 * G / 2), 'unit': 'sweeps/s', 'cores': 1,
+                             'sample': f'one sweep at N={N}, p=1, q=1 (2 of {G} latent GPs, {dt_1:.1f} s) on one '
+                                       f'BLAS thread, scaled by {G}/2'}
+    except ImportError:
+        out['one_thread'] = None
+    return out
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: N child processes, one per rank, started BEFORE this
+    process makes any HIP call (a process that has initialised the GPU must not exec or fork
+    GPU work).  Rank r uses GPU r % (devices on the box); on a one-GPU box that only works with the
+    rehearsal transport (GPRN_COMM_TRANSPORT=shm)."""
+    port = os.environ.get('MASTER_PORT') or str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, GPRN_LAUNCH_TAG=str(os.getpid()))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.exit('bench.py: rank(s) failed: %s' % ', '.join('%d (exit %d)' % rc for rc in bad))
 
 
 def main():
@@ -104,15 +160,14 @@ def main():
     ap.add_argument('--no-calc', action='store_true')
     ap.add_argument('--shape', default=None,
                     help='N,p,q of an ad-hoc problem (experiments; not a BASELINE config)')
+    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps sweeps each')
     a = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        return self_launch(a)
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
-    if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit('bench.py --gpus N>1 must be launched with torch.distributed.run '
-                     '(one rank per GPU)')
-        a.gpus = world
+    a.gpus = world
     N, p, q, kind = synth.CONFIGS[a.config]
     if a.shape:
         N, p, q = (int(x) for x in a.shape.split(','))
@@ -135,11 +190,14 @@ def main():
     if a.warmup > 0:
         ctx.sweep(a.warmup, commit=True)
     ctx.profile_enable(['update'])
-    ctx.barrier_max(0.0)                                   # barrier + device sync
-    t0 = time.perf_counter()
-    elbo, parts, info = ctx.sweep(a.steps, commit=True)    # K sweeps, one host sync at the end
-    dt_local = time.perf_counter() - t0
-    dt = ctx.barrier_max(dt_local)                         # MAX over ranks
+    block_s = []
+    for _ in range(max(1, a.blocks)):
+        ctx.barrier_max(0.0)                               # barrier + device sync
+        t0 = time.perf_counter()
+        elbo, parts, info = ctx.sweep(a.steps, commit=True)    # K sweeps, one host sync at the end
+        dt_local = time.perf_counter() - t0
+        block_s.append(ctx.barrier_max(dt_local))          # MAX over ranks
+    dt = float(np.median(block_s))
     prof = ctx.profile_read()
     ctx.profile_enable([])
 
@@ -198,7 +256,7 @@ def main():
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
         ms_upd, n_upd = prof['update']
         T = (N + TILE - 1) // TILE
-        fl = update_flops(T, len(nodes_l) + len(weights_l)) * a.steps
+        fl = update_flops(T, len(nodes_l) + len(weights_l)) * a.steps * len(block_s)
         achieved = fl / (ms_upd * 1e-3) / 1e12 if ms_upd > 0 else None
         out = {
             'metric': 'ELBO iterations/sec (N=%d, P=%d, Q=%d)' % (N, p, q),
@@ -206,6 +264,9 @@ def main():
             'unit': 'sweeps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * dt / a.steps,
+            'blocks': {'n': len(block_s), 'steps_each': a.steps,
+                       'sweeps_per_s': {'median': a.steps / dt, 'min': a.steps / max(block_s),
+                                        'max': a.steps / min(block_s)}},
             'higher_is_better': True,
             'scaling': 'strong',
             'vs_baseline': None,
@@ -215,7 +276,8 @@ def main():
                                    'weights, synthetic RV series (seed 0)'
                                    % ('ad-hoc shape' if a.shape else 'BASELINE config %d' % a.config,
                                       N, p, q, kind),
-                       'latent_gps': q * (p + 1), 'sharding': 'latent GPs over %d rank(s)' % world},
+                       'latent_gps': q * (p + 1), 'sharding': 'latent GPs over %d rank(s)' % world,
+                       'comm_ranks': ctx.world, 'transport': os.environ.get('GPRN_COMM_TRANSPORT', 'rccl') if world > 1 else None},
             'sweep_tflops': sweep_flops(N, p, q) * a.steps / dt / 1e12,
             # BASELINE metric, second half: fp64 rate of the Cholesky work.  The sweep's N^3 work IS
             # the G fused Cholesky + triangular-inverse factorisations (+ q-1 X^T X products); this is
@@ -232,7 +294,7 @@ def main():
             'independent_evaluations': pool,
             'elbo_last': float(elbo[-1]), 'info': int(info),
             'roofline': {
-                'kernel': 'k_tile_gemm<64,64> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
+                'kernel': 'k_tile_gemm<..., TG_BULK> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,
                 'unit': 'TFLOP/s',
                 'frac': (achieved / FP64_MFMA_PEAK_TFLOPS) if achieved else None,

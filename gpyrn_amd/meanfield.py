@@ -292,6 +292,7 @@ class inference:
             forced = bool(os.environ.get('GPRN_FORCE_RCCL'))      # one-rank communicator, for tests
             if comm is not None and (comm.world > 1 or forced):
                 ctx.comm_init(comm.world, comm.rank, comm.unique_id())
+                comm.done()
             ctx.set_data(np.asarray(self.time, dtype=float), self.y, self.yerr, self.q)
             if comm is not None and comm.world > 1:
                 ctx.set_owners(sharding.owners(self.p, self.q, comm.world))

@@ -22,6 +22,7 @@ import os
 import time
 
 _generation = 0
+_START = time.time()
 
 
 def owners(p, q, world):
@@ -51,8 +52,29 @@ def helper_inverses(p, q, world, rank):
     return list(range(nodes[0] + 1, q))
 
 
+def _rendezvous_dir():
+    """A directory only this user can write to: $XDG_RUNTIME_DIR when it exists, else /tmp/gprn-<uid> (0700)."""
+    base = os.environ.get('XDG_RUNTIME_DIR')
+    if base and os.path.isdir(base) and os.access(base, os.W_OK):
+        d = os.path.join(base, 'gprn')
+    else:
+        d = os.path.join('/tmp', 'gprn-%d' % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise PermissionError(f'{d} is not a private directory of this user')
+    return d
+
+
 class Comm:
-    """World description + ncclUniqueId rendezvous for one communicator."""
+    """World description + ncclUniqueId rendezvous for one communicator.
+
+    The id travels through a file in a private per-user directory, named after the launch (the
+    launcher's pid, or GPRN_LAUNCH_TAG when the launcher sets it), the rendezvous port, the world size
+    and a per-process generation count.  Rank 0 removes anything stale under that name, creates the file
+    with O_EXCL and mode 0600 and renames it into place; the other ranks accept only a 128-byte file
+    of their own user written after they started.  ``done()`` removes it once the communicator exists.
+    """
 
     def __init__(self, world=None, rank=None, local_rank=None, tag=None):
         env = os.environ
@@ -63,43 +85,63 @@ class Comm:
         global _generation
         _generation += 1
         port = env.get('MASTER_PORT', '0')
-        self._path = '/tmp/gprn_uid_%s_%s_%s_%d' % (
-            tag if tag is not None else os.getppid(), port, self.world, _generation)
+        if tag is None:
+            tag = env.get('GPRN_LAUNCH_TAG') or os.getppid()
+        self._path = None
+        self._name = 'uid_%s_%s_%s_%d' % (tag, port, self.world, _generation)
         self._id = None
+
+    def _file(self):
+        if self._path is None:
+            self._path = os.path.join(_rendezvous_dir(), self._name)
+        return self._path
 
     def unique_id(self, timeout=300.0):
         """Rank 0 creates the id and publishes it atomically; the others wait."""
         if self._id is not None or self.world == 1:
             return self._id
+        path = self._file()
         if self.rank == 0:
             from . import _hip
             self._id = _hip.comm_unique_id()
-            tmp = self._path + '.tmp%d' % os.getpid()
-            with open(tmp, 'wb') as f:
+            tmp = path + '.tmp%d' % os.getpid()
+            for stale in (path, tmp):
+                try:
+                    os.unlink(stale)
+                except FileNotFoundError:
+                    pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, 'wb') as f:
                 f.write(self._id)
-            os.replace(tmp, self._path)
+            os.replace(tmp, path)
         else:
             t0 = time.time()
             while True:
                 try:
-                    with open(self._path, 'rb') as f:
-                        data = f.read()
-                    if len(data) == 128:
-                        self._id = data
-                        break
+                    st = os.stat(path)
+                    fresh = st.st_mtime >= _START - 2.0
+                    if st.st_uid == os.getuid() and not (st.st_mode & 0o077) and st.st_size == 128 and fresh:
+                        with open(path, 'rb') as f:
+                            data = f.read()
+                        if len(data) == 128:
+                            self._id = data
+                            break
                 except FileNotFoundError:
                     pass
                 if time.time() - t0 > timeout:
-                    raise TimeoutError(f'no ncclUniqueId at {self._path} after {timeout}s')
+                    raise TimeoutError(f'no ncclUniqueId at {path} after {timeout}s')
                 time.sleep(0.01)
         return self._id
 
-    def cleanup(self):
-        if self.rank == 0:
+    def done(self):
+        """The communicator is up on this rank (its creation is collective: every rank has read the id)."""
+        if self.rank == 0 and self._path is not None:
             try:
                 os.unlink(self._path)
             except OSError:
                 pass
+
+    cleanup = done
 
 
 class EvalPool:
@@ -126,6 +168,7 @@ class EvalPool:
         self._ctx = _hip.Context(self.device)
         if self.world > 1:
             self._ctx.comm_init(self.world, self.rank, self.comm.unique_id())
+            self.comm.done()
 
     def map(self, func, items):
         items = list(items)

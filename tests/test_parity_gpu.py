@@ -252,7 +252,8 @@ def _run_ranks(module, tag, world, tmp_path, extra_env=None):
     procs, outs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29534', GPRN_COMM_TRANSPORT='shm')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(20000 + os.getpid() % 20000),
+                   GPRN_COMM_TRANSPORT='shm')
         env.update(extra_env or {})
         out = str(tmp_path / f'rank{r}.npz')
         outs.append(out)
