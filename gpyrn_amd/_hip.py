@@ -62,6 +62,9 @@ SIGNATURES = {
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
+    'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
+    'gprn_eval_kernel': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, _dp]),
+    'gprn_sample_prior': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, c_int, _dp, _dp]),
 }
 
 _lib = None
@@ -235,6 +238,34 @@ class Context:
         info = self._check(self._lib.gprn_predict(self._h, ts.size, _ptr(ts), _ptr(mean), _ptr(var)),
                            'predict')
         return mean, var, info
+
+    def eval_kernel(self, ops, params, nugget):
+        """K = expr(t_i, t_j) + nugget I at the data times, filled on the device."""
+        flat = np.ascontiguousarray(np.asarray(ops, dtype=np.int32).reshape(-1, 3))
+        par = _f64(np.atleast_1d(params))
+        K = np.empty((self.N, self.N))
+        self._check(self._lib.gprn_eval_kernel(self._h, flat.ctypes.data_as(POINTER(c_int32)), flat.shape[0],
+                                               _ptr(par), par.size, float(nugget), _ptr(K)), 'eval_kernel')
+        return K
+
+    def sample_prior(self, ops, params, nugget, z):
+        """L z for every row z of standard normals, K + nugget I = L L^T; returns (samples, info)."""
+        flat = np.ascontiguousarray(np.asarray(ops, dtype=np.int32).reshape(-1, 3))
+        par = _f64(np.atleast_1d(params))
+        z = _f64(np.atleast_2d(z))
+        if z.shape[1] != self.N:
+            raise ValueError('z must have N columns')
+        out = np.empty_like(z)
+        info = self._check(self._lib.gprn_sample_prior(
+            self._h, flat.ctypes.data_as(POINTER(c_int32)), flat.shape[0], _ptr(par), par.size, float(nugget),
+            z.shape[0], _ptr(z), _ptr(out)), 'sample_prior')
+        return out, info
+
+    def grad_matrices(self, gp):
+        """(K^-1, K^-1 S K^-1) of latent GP `gp` after a sweep with keep_sigma: the N^3 part of the ELBO gradient."""
+        Kinv, P = np.empty((self.N, self.N)), np.empty((self.N, self.N))
+        self._check(self._lib.gprn_grad_matrices(self._h, int(gp), _ptr(Kinv), _ptr(P)), 'grad_matrices')
+        return Kinv, P
 
     def keep_sigma(self, on=True):
         self._check(self._lib.gprn_keep_sigma(self._h, int(bool(on))), 'keep_sigma')

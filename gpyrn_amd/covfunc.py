@@ -82,6 +82,25 @@ class covFunction:
     def set_parameters(self, p):
         return _take_leading(self, p, 'kernel')
 
+    # -- derivatives in the hyper-parameters (not in the reference: SURVEY.md 8f-3) ----------
+    def _dk_dpars(self, r):
+        """``[dK/dpars[0], dK/dpars[1], ...]`` on the array of time differences `r`.  The base version
+        differentiates ``self(r)`` numerically (central differences, relative step 1e-6), which serves
+        every kernel, user subclasses included; built-ins with a closed form override it."""
+        out = []
+        keep = self.pars.copy()
+        try:
+            for i, v in enumerate(keep):
+                h = 1e-6 * max(1.0, abs(v))
+                self.pars = keep.copy(); self.pars[i] = v + h
+                up = np.asarray(self(r), dtype=float)
+                self.pars = keep.copy(); self.pars[i] = v - h
+                dn = np.asarray(self(r), dtype=float)
+                out.append((up - dn) / (2 * h))
+        finally:
+            self.pars = keep
+        return out
+
     # -- algebra -------------------------------------------------------------
     def __add__(self, other):
         return Sum(self, other)
@@ -231,6 +250,11 @@ class SquaredExponential(covFunction):
     def __call__(self, r):
         return self.pars[0]**2 * np.exp(-0.5 * r**2 / self.pars[1]**2)
 
+    def _dk_dpars(self, r):
+        theta, ell = self.pars
+        K = self(r)
+        return [2 * K / theta, K * r**2 / ell**3]
+
     def _dkdxi(self, r):
         theta, ell = self.pars
         return theta**2 * (-r) * np.exp(-0.5 * (-r)**2 / ell**2) / ell**2
@@ -259,6 +283,12 @@ class Periodic(covFunction):
         theta, P, ell = self.pars
         return theta**2 * np.exp(-2 * np.sin(np.pi * np.abs(r) / P)**2 / ell**2)
 
+    def _dk_dpars(self, r):
+        theta, P, ell = self.pars
+        K = self(r)
+        x = np.pi * np.abs(r) / P
+        return [2 * K / theta, K * 2 * x * np.sin(2 * x) / (P * ell**2), K * 4 * np.sin(x)**2 / ell**3]
+
     def _dkdxidj(self, r):
         theta, P, ell = self.pars
         x = np.pi * r / P
@@ -283,6 +313,13 @@ class QuasiPeriodic(covFunction):
         periodic = -2 * np.sin(np.pi * np.abs(r) / P)**2 / lp**2
         decay = r**2 / (2 * le**2)
         return theta**2 * np.exp(periodic - decay)
+
+    def _dk_dpars(self, r):
+        theta, le, P, lp = self.pars
+        K = self(r)
+        x = np.pi * np.abs(r) / P
+        return [2 * K / theta, K * r**2 / le**3, K * 2 * x * np.sin(2 * x) / (P * lp**2),
+                K * 4 * np.sin(x)**2 / lp**3]
 
     def _dkdxidj(self, r):
         theta, le, P, lp = self.pars

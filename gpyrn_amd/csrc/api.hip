@@ -891,27 +891,48 @@ static int run_phase(gprn_ctx* c, bool weights)
             const size_t nn = (size_t)c->ld * c->ld;
             TRY(lauum_lower(c, ns));
             for (int s = 0; s < ns; ++s) {
-                if (!c->Sig[gps[s]]) TRY(dev_alloc(c, &c->Sig[gps[s]], nn));
+                if (!c->Sig[gps[s]]) {
+                    TRY(dev_alloc(c, &c->Sig[gps[s]], nn));
+                    HIP_TRY(c, hipMemsetAsync(c->Sig[gps[s]], 0, nn * sizeof(double), c->stream));   // padding stays zero
+                }
                 TRY(vec_sigma(c, c->wsB[c->slot0 + s], c->d_s + o + (size_t)s * c->ld, c->Sig[gps[s]]));
             }
         }
         if (!weights && c->q > 1) {
             // quirk Q1: <K_j^-1, Sigma_k> for k < j needs the explicit B_k^-1 = X^T X of every node
-            // but the last.  Nothing in the weight phase reads it, so it runs behind that phase on
-            // the second stream and is joined before the ELBO assembly.
+            // but the last.  Nothing in the weight phase reads it, so it runs beside that phase on
+            // the second stream and is joined before the ELBO assembly.  It is handed to the weight
+            // phase's factorisation, which enqueues it once its chain kernel holds its CUs (a launch of
+            // 528 long-running workgroups just before would keep the chain waiting for a free CU).
             const int n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
             HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
-            if (n_inv && !c->keep_sigma) TRY(lauum_lower(c, n_inv, c->stream2));
-            for (int s = 0; s < ns; ++s) {
-                const int k = gps[s];
-                for (int j = k + 1; j < c->q; ++j)
-                    TRY(vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld, c->d_u,
-                               c->d_q1 + (size_t)j * c->q + k, c->stream2));
-            }
-            HIP_TRY(c, hipEventRecord(c->ev_q1, c->stream2));
+            const std::vector<int> node_gps = gps;
+            double** const node_tab = c->d_ptrs;
+            c->chain_started = [c, n_inv, ns, node_gps, node_tab]() -> int {
+                double** const cur = c->d_ptrs;
+                c->d_ptrs = node_tab;
+                HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
+                int rc = GPRN_OK;
+                if (n_inv && !c->keep_sigma) rc = lauum_lower(c, n_inv, c->stream2);
+                for (int s = 0; s < ns && !rc; ++s) {
+                    const int k = node_gps[s];
+                    for (int j = k + 1; j < c->q && !rc; ++j)
+                        rc = vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld, c->d_u,
+                                    c->d_q1 + (size_t)j * c->q + k, c->stream2);
+                }
+                c->d_ptrs = cur;
+                if (rc) return rc;
+                HIP_TRY(c, hipEventRecord(c->ev_q1, c->stream2));
+                return GPRN_OK;
+            };
             c->q1_pending = true;
         }
+    }
+    if (weights && c->chain_started) {
+        // no factorisation took it along (no weight GP on this rank, or the launch schedule): now
+        std::function<int()> f;
+        f.swap(c->chain_started);
+        TRY(f());
     }
     return exchange_rows(c, weights);
 }
@@ -1147,6 +1168,185 @@ done:
     dev_free(d_ts); dev_free(d_kss); dev_free(d_mean); dev_free(d_pvar); dev_free(d_t);
     c->factored = c->factored;      // the priors' factors live in K/KLinv, not in the workspaces
     return rc;
+}
+
+// ------------------------------------------------------------------ kernel matrices, prior samples
+static int spec_from_args(gprn_ctx* c, KernelSpec& ks, const int32_t* ops, int n_ops, const double* params,
+                          int n_params, int add_nugget)
+{
+    if (!ops || n_ops <= 0 || n_ops > GPRN_MAX_OPS || n_params < 0 || n_params > GPRN_MAX_KPARAMS || (n_params && !params))
+        return bad(c, "kernel expression: bad argument");
+    int depth = 0;
+    for (int o = 0; o < n_ops; ++o) {
+        const int op = ops[3 * o], kid = ops[3 * o + 1], off = ops[3 * o + 2];
+        if (op == GPRN_OP_PUSH) {
+            if (kid < 0 || kid >= GPRN_K_COUNT || off < 0 || off > n_params || ++depth > 8) return bad(c, "kernel expression: bad push");
+        } else if (op == GPRN_OP_ADD || op == GPRN_OP_MUL) {
+            if (--depth < 1) return bad(c, "kernel expression: malformed");
+        } else return bad(c, "kernel expression: unknown opcode");
+    }
+    if (depth != 1) return bad(c, "kernel expression: malformed");
+    ks.set = true; ks.uploaded = false;
+    ks.n_ops = n_ops; ks.n_params = n_params; ks.nugget = add_nugget ? 1 : 0;
+    memcpy(ks.ops, ops, 3 * n_ops * sizeof(int32_t));
+    if (n_params) memcpy(ks.params, params, n_params * sizeof(double));
+    return GPRN_OK;
+}
+
+static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch);
+
+// K = expr(t_i, t_j) + nugget I at the data times, evaluated by the fused fill kernel: inference._KMatrix
+// (meanfield.py:413-434, nugget 1e-6) and _tinyNuggetKMatrix (:436-452, 1.25e-12); nugget = 0 for the
+// two-argument kernels.  K_out: (N, N) host.
+extern "C" int gprn_eval_kernel(gprn_ctx* c, const int32_t* ops, int n_ops, const double* params, int n_params,
+                                double nugget, double* K_out)
+{
+    if (!c || !c->N || !K_out) return bad(c, "eval_kernel: call set_data first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    KernelSpec ks;
+    TRY(spec_from_args(c, ks, ops, n_ops, params, n_params, nugget != 0.0));
+    TRY(test_setup(c, c->ld, 1, 1));
+    TRY(launch_fill(c, ks, c->d_test[0], nugget));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy2D(K_out, (size_t)c->N * sizeof(double), c->d_test[0], (size_t)c->ld * sizeof(double),
+                           (size_t)c->N * sizeof(double), c->N, hipMemcpyDeviceToHost));
+    return GPRN_OK;
+}
+
+// Draws from the GP prior of a kernel at the data times: out[s] = L z[s] with K + nugget I = L L^T from the
+// blocked factorisation (inference._sample_from_gp, meanfield.py:517-531, which hands K to
+// scipy.stats.multivariate_normal).  z: (n_samples, N) standard normals from the caller's generator; a
+// positive return is the LAPACK-style info of a K that is not positive definite at this nugget.
+static int sample_prior_impl(gprn_ctx* c, const KernelSpec& ks, double nugget, int n_samples, const double* z,
+                             double* out)
+{
+    const int ld = c->ld, N = c->N;
+    TRY(test_setup(c, ld, 2, 1));
+    double **d_p = nullptr, *d_z = nullptr, *d_o = nullptr;
+    int* d_i = nullptr;
+    int rc = dev_alloc(c, &d_p, GPRN_NBUF);
+    if (!rc) rc = dev_alloc(c, &d_i, 1);
+    if (!rc) rc = dev_alloc(c, &d_z, (size_t)n_samples * ld);
+    if (!rc) rc = dev_alloc(c, &d_o, (size_t)n_samples * ld);
+    double** const sptrs = c->d_ptrs;
+    int* const sinfo = c->d_info_cur;
+    int info0 = 0;
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], nullptr, nullptr};
+        e = hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_i, 0, sizeof(int));
+        if (e == hipSuccess) e = hipMemset(d_z, 0, (size_t)n_samples * ld * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy2D(d_z, (size_t)ld * sizeof(double), z, (size_t)N * sizeof(double),
+                                             (size_t)N * sizeof(double), n_samples, hipMemcpyHostToDevice);
+        if (e == hipSuccess) rc = launch_fill(c, ks, c->d_test[0], nugget);
+        c->d_ptrs = d_p; c->d_info_cur = d_i;
+        if (e == hipSuccess && !rc) rc = factor_invert(c, 1);
+        for (int s = 0; s < n_samples && e == hipSuccess && !rc; ++s)     // L z: row i of lower(B) . z
+            rc = vec_lower_matvec(c, BUF_B, d_z + (size_t)s * ld, 0, 0, nullptr, 1, d_o + (size_t)s * ld);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && !rc) rc = factor_check_waits(c);
+        if (e == hipSuccess && !rc) e = hipMemcpy(&info0, d_i, sizeof(int), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && !rc)
+            e = hipMemcpy2D(out, (size_t)N * sizeof(double), d_o, (size_t)ld * sizeof(double),
+                            (size_t)N * sizeof(double), n_samples, hipMemcpyDeviceToHost);
+    }
+    c->d_ptrs = sptrs; c->d_info_cur = sinfo;
+    if (d_p) hipFree(d_p);
+    if (d_i) hipFree(d_i);
+    if (d_z) hipFree(d_z);
+    if (d_o) hipFree(d_o);
+    if (rc) return rc;
+    HIP_TRY(c, e);
+    return info0;
+}
+
+extern "C" int gprn_sample_prior(gprn_ctx* c, const int32_t* ops, int n_ops, const double* params, int n_params,
+                                 double nugget, int n_samples, const double* z, double* out)
+{
+    if (!c || !c->N || n_samples <= 0 || !z || !out) return bad(c, "sample_prior: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    KernelSpec ks;
+    TRY(spec_from_args(c, ks, ops, n_ops, params, n_params, nugget != 0.0));
+    TRY(ensure_tasks(c));
+    return with_event_fallback(c, "sample_prior", [&](bool) { return sample_prior_impl(c, ks, nugget, n_samples, z, out); });
+}
+
+// ------------------------------------------------------------------ gradient pieces
+// At fixed variational state only the expected log prior depends on the hyper-parameters of latent GP g's
+// kernel (meanfield.py:992-1067):  -1/2 log det K - 1/2 (m^T K^-1 m + tr(K^-1 S)),  S = the covariance the
+// reference pairs with K_g (node j: Sigma_f0 + ... + Sigma_fj, quirk Q1; weight: its own Sigma_w), so
+//     d/dtheta = 1/2 < K^-1 S K^-1 + a a^T - K^-1 , dK/dtheta >,   a = K^-1 m.
+// The N^3 part is done here, on the tile kernel: K^-1 = L_K^-T L_K^-1 and P = K^-1 S K^-1 for one latent GP,
+// from the factors of gprn_factor_priors and the explicit Sigma of the last sweep (gprn_keep_sigma).  The
+// O(N^2) contraction with dK/dtheta stays with the caller, who owns the kernel classes.
+// Kinv_out, P_out: (N, N), both symmetric (full).  One rank only (the node sum needs every node's Sigma).
+extern "C" int gprn_grad_matrices(gprn_ctx* c, int gp, double* Kinv_out, double* P_out)
+{
+    if (!c || !c->N || gp < 0 || gp >= c->G || !Kinv_out || !P_out) return bad(c, "grad_matrices: bad argument");
+    if (c->world != 1) return bad(c, "grad_matrices: not available on a sharded context");
+    if (!c->factored || !c->keep_sigma) return bad(c, "grad_matrices: needs factor_priors and a sweep with keep_sigma");
+    const int nsum = gp < c->q ? gp + 1 : 1;
+    for (int k = 0; k < nsum; ++k)
+        if (!c->Sig[gp < c->q ? k : gp]) return bad(c, "grad_matrices: no Sigma yet (run a sweep with keep_sigma on)");
+    if (c->nslot < 2) return bad(c, "grad_matrices: needs two workspace slots");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    const int ld = c->ld, N = c->N, T = c->T;
+    const size_t nn = (size_t)ld * ld;
+    // workspaces of the sweep are free between calls: slot 0's B holds K^-1, its X the sum S, slot 1's B the
+    // product -K^-1 S, and P lands in slot 0's X once S has been read
+    double* const dKinv = c->wsB[0];
+    double* const dS = c->wsX[0];
+    double* const dC1 = c->wsB[1];
+    // S (full, ld x ld, padding zero)
+    HIP_TRY(c, hipMemsetAsync(dS, 0, nn * sizeof(double), c->stream));
+    for (int k = 0; k < nsum; ++k)
+        TRY(vec_axpy_matrix(c, c->Sig[gp < c->q ? k : gp], dS, N));
+    TileTask* d_t = nullptr;
+    double** d_p = nullptr;
+    std::vector<TileTask> tasks;
+    auto toff = [&](int ti, int tj) { return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE; };
+    // buffer slots of these launches: 0 = K^-1 (BUF_B), 1 = L_K^-1 (BUF_X, for the X^T X list), 2 = S then P, 3 = C1
+    double* hp[GPRN_NBUF] = {dKinv, c->KLinv[gp], dS, dC1};
+    int rc = dev_alloc(c, &d_p, GPRN_NBUF);
+    hipError_t e = hipSuccess;
+    if (!rc) e = hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice);
+    // (1) K^-1 = lower(X^T X), X = L_K^-1: the X^T X task list (BUF_X -> BUF_B); then mirror it to the upper
+    // triangle so that the two products below read plain full tiles
+    if (!rc && e == hipSuccess) rc = ensure_tasks(c);
+    double** const sptrs = c->d_ptrs;
+    c->d_ptrs = d_p;
+    if (!rc && e == hipSuccess) rc = lauum_lower(c, 1);
+    if (!rc && e == hipSuccess) rc = vec_symmetrize(c, dKinv);
+    // (2) C1 = -K^-1 S, all T x T tiles, K = ld
+    for (int i = 0; i < T; ++i)
+        for (int j = 0; j < T; ++j)
+            tasks.push_back(TileTask{toff(i, j), toff(i, 0), toff(0, j), ld, 3, 0, 2, tile_modes(CM_SETNEG, 0, 1)});
+    const size_t n1 = tasks.size();
+    // (3) P = -C1 K^-1 = K^-1 S K^-1, into slot 2 (S is dead by then)
+    for (int i = 0; i < T; ++i)
+        for (int j = 0; j < T; ++j)
+            tasks.push_back(TileTask{toff(i, j), toff(i, 0), toff(0, j), ld, 2, 3, 0, tile_modes(CM_SETNEG, 0, 1)});
+    if (!rc && e == hipSuccess) rc = dev_alloc(c, &d_t, tasks.size());
+    if (!rc && e == hipSuccess)
+        e = hipMemcpyAsync(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, c->stream);
+    if (!rc && e == hipSuccess) rc = launch_tiles(c, d_t, n1, d_p, 1, ld, GPRN_T_UPDATE);
+    if (!rc && e == hipSuccess) rc = launch_tiles(c, d_t + n1, tasks.size() - n1, d_p, 1, ld, GPRN_T_UPDATE);
+    c->d_ptrs = sptrs;
+    if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (!rc && e == hipSuccess)
+        e = hipMemcpy2D(Kinv_out, (size_t)N * sizeof(double), dKinv, (size_t)ld * sizeof(double),
+                        (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
+    if (!rc && e == hipSuccess)
+        e = hipMemcpy2D(P_out, (size_t)N * sizeof(double), dS, (size_t)ld * sizeof(double),
+                        (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
+    if (d_t) hipFree(d_t);
+    if (d_p) hipFree(d_p);
+    if (rc) return rc;
+    HIP_TRY(c, e);
+    return GPRN_OK;
 }
 
 // ------------------------------------------------------------------ diagnostics

@@ -17,13 +17,13 @@
 // update touches (T-1-k)(T-k)/2 + (T-1-k)(k+1) tiles -- roughly constant until
 // the tail, unlike POTRF alone.  Flops: N^3/3 + N^3/3.
 #include "gprn_internal.h"
+#include "tile_mma.h"
 
 #include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
-
-typedef double v4d __attribute__((ext_vector_type(4)));
+#include <functional>
 
 #define PP 18             // LDS pitch (doubles) of a 16-wide column panel: conflict-free operand fetch
 #define NSB 8             // 16x16 sub-blocks per tile edge
@@ -253,20 +253,19 @@ __device__ __forceinline__ v4d get16(const double* __restrict__ T)
 // The pivot wave runs one step ahead of the compute waves: it needs only the column panel and
 // the diagonal sub-tile as they stood after update(kb-1), both published to LDS in phase kb-1,
 // so the 16-pivot chains (the serial part) never wait for the bulk of the update.
-__global__ __launch_bounds__(256)
-void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info,
-                  unsigned* sig_slot, unsigned sig_value)
+#define DIAG_LDS_DOUBLES (2 * 128 * PP + 128 * PP + 2 * 16 * PP + 2 * 16 * PP + 16 * PP + 64)
+
+// potrf + inverse of the 128x128 tile at Bt (-> L, lower) with X = L^-1 -> Xt; `lds`: DIAG_LDS_DOUBLES doubles.
+// All 256 threads of the workgroup call it.
+__device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
+                                          int* __restrict__ info, int slot, int pivot0)
 {
-    __shared__ __attribute__((aligned(16))) double PA[2 * 128 * PP];   // published column panels (by parity)
-    __shared__ __attribute__((aligned(16))) double PB[128 * PP];       // current column after scaling by X_kb^T
-    __shared__ __attribute__((aligned(16))) double DG[2 * 16 * PP];    // diagonal sub-tiles for / from the pivot wave
-    __shared__ __attribute__((aligned(16))) double XD[2 * 16 * PP];    // X_kb by parity
-    __shared__ __attribute__((aligned(16))) double SC[16 * PP];        // pivot wave scratch
-    __shared__ __attribute__((aligned(16))) double LINE[64];
-    const int slot = blockIdx.x;
-    const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-    gptr_t Bt = (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off);
-    gptr_t Xt = (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off);
+    double* const PA = lds;                         // published column panels (by parity)     2 x 128 x PP
+    double* const PB = PA + 2 * 128 * PP;           // current column after scaling by X_kb^T  128 x PP
+    double* const DG = PB + 128 * PP;               // diagonal sub-tiles for / from the pivot wave
+    double* const XD = DG + 2 * 16 * PP;            // X_kb by parity
+    double* const SC = XD + 2 * 16 * PP;            // pivot wave scratch
+    double* const LINE = SC + 16 * PP;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int fr = lane & 15, fk = lane >> 4;
     const bool compute = wave < 3;
@@ -297,7 +296,7 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
         }
     }
     __syncthreads();
-    if (!compute) base16(DG, XD, Xt, ld, info, slot, kblk * GPRN_TILE, LINE);
+    if (!compute) base16(DG, XD, Xt, ld, info, slot, pivot0, LINE);
     __syncthreads();
 
     for (int kb = 0; kb < NSB; ++kb) {
@@ -358,7 +357,7 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
                 const int n = kb + 1;
                 base16(DG + (n & 1) * 16 * PP, XD + (n & 1) * 16 * PP,
                        Xt + (size_t)(16 * n) * ld + 16 * n, ld, info, slot,
-                       kblk * GPRN_TILE + 16 * n, LINE);
+                       pivot0 + 16 * n, LINE);
             }
         }
         __syncthreads();                                       // E
@@ -396,7 +395,95 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256)
+void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info,
+                  unsigned* sig_slot, unsigned sig_value)
+{
+    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    const int slot = blockIdx.x;
+    const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
+    diag_tile(lds, (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off),
+              (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off), ld, info, slot, kblk * GPRN_TILE);
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
+}
+
+// ------------------------------------------------------------------ chain
+// The latency chain of one factorisation as ONE persistent workgroup per matrix: for every tile step k
+//     diag(k)  ->  L_{k+1,k} = B_{k+1,k} X_kk^T  ->  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T
+// back to back on a CU of its own (it asks for so much LDS that nothing else fits beside it), instead of three
+// dependent launches per step that share their CUs with the bulk updates: no launch, dispatch or flag latency
+// inside the chain, no co-resident MFMA waves holding the SIMD's FP64 units while the pivot chain runs.
+// It talks to the other streams through the same flags as the launch schedule (factor_invert_split):
+//   raises  F_DIAG(k)   when L_kk, X_kk are in memory   (stream3 starts the panel of step k)
+//           F_MINIL(k)  when L_{k+1,k} is                (stream3's in-panel updates of step k)
+//   waits   F_INNER(k-1) before it reads B_{k+1,k}, B_{k+1,k+1}  (stream3's in-panel update of step k-1)
+//           F_FIRST(J)  before B_{k+1,k+1} at the first step of panel J+1 (its K = width-of-panel update)
+// flags: (step or panel) * kinds * 2 + kind * 2 + 1 words into `sig`; a flag is up when it holds >= epoch.
+#define CHAIN_MMA_DOUBLES (2 * 16 * (128 + 128 + 32))
+#define CHAIN_LDS_DOUBLES (CHAIN_MMA_DOUBLES > DIAG_LDS_DOUBLES ? CHAIN_MMA_DOUBLES : DIAG_LDS_DOUBLES)
+
+// One flag per (tile step, kind) serves the whole batch: the chain workgroups of all matrices count in on the
+// word in front of it and the last one raises it (as the workgroups of one launch do in signal_done).
+__device__ __forceinline__ void chain_publish(unsigned* flag, unsigned epoch)
+{
+    // every wave's stores have left the CU, then one release for the workgroup, then the count / the flag
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* const count = flag - 1;
+        if (atomicAdd(count, 1u) + 1 == gridDim.x) {
+            atomicExch(count, 0u);
+            __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __restrict__ info,
+             unsigned* sig, int kinds, int f_diag, int f_minil, int f_inner, int f_first, unsigned epoch,
+             unsigned* timed_out, unsigned long long* stamps /* development aid: 8 per tile step, or null */)
+{
+#define STAMP(i) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(size_t)k * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS_DOUBLES];
+    const int slot = blockIdx.x;
+    double* const Bm = ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    double* const Xm = ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    auto flag = [&](int idx, int kind) { return sig + ((size_t)idx * kinds + kind) * 2 + 1; };
+    for (int k = 0; k < T; ++k) {
+        const size_t dk = ((size_t)k * GPRN_TILE) * ld + (size_t)k * GPRN_TILE;
+        STAMP(0);
+        diag_tile(lds, (gptr_t)(Bm + dk), (gptr_t)(Xm + dk), ld, info, slot, k * GPRN_TILE);
+        STAMP(1);
+        chain_publish(flag(k, f_diag), epoch);
+        STAMP(2);
+        if (k + 1 == T) break;
+        // L_{k+1,k} = B_{k+1,k} X_kk^T, in place; rows split over the four waves (each meets the same share
+        // of X_kk's zero half)
+        if (k > 0) await_flag(flag(k - 1, f_inner), epoch, timed_out);
+        else __syncthreads();
+        STAMP(3);
+        const size_t sub = dk + (size_t)GPRN_TILE * ld;          // tile (k+1, k)
+        tile_mma<128, 128, 4, 1, 1, false>(lds, Bm + sub, Xm + dk, (gptr_t)(Bm + sub), ld, 0, 0, CM_SET,
+                                            GPRN_TILE, 0, 0);
+        STAMP(4);
+        chain_publish(flag(k, f_minil), epoch);
+        STAMP(5);
+        // B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T (lower blocks); at a panel boundary it first takes the
+        // previous panel's outer update
+        if ((k + 1) % outer == 0) await_flag(flag((k + 1) / outer - 1, f_first), epoch, timed_out);
+        tile_mma<128, 128, 4, 1, 0, true>(lds, Bm + sub, Bm + sub, (gptr_t)(Bm + sub + GPRN_TILE), ld, 0, 0,
+                                           CM_SUB, GPRN_TILE, 0, 0);
+        STAMP(6);
+        // the next diagonal block reads this tile back: own stores, same CU -- drained, then one barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        STAMP(7);
+    }
+#undef STAMP
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
@@ -692,10 +779,68 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     };
     const Await noaw{nullptr, 0, nullptr};
     const Signal nosig{nullptr, 0, nullptr, 0, nullptr};
+    // GPRN_CHAIN=1: the chain as one persistent workgroup per matrix (k_chain; flag schedule only, it waits
+    // in-kernel) instead of three launches per tile step on the chain stream.  Off by default: one CU does
+    // L_{k+1,k} and the B_{k+1,k+1} update in 12 + 22 us where the launches spread them over six CUs, and the
+    // step is no shorter (measured 86 vs 97 sweeps/s at config 3, 365 vs 423 at config 2).
+    static int chain_env = -1;
+    if (chain_env < 0) { const char* e = getenv("GPRN_CHAIN"); chain_env = e ? atoi(e) : 0; }
+    const bool use_chain = use_flags && chain_env && c->T > 1;
+    static int stamps_env = -1;                    // GPRN_CHAIN_STAMPS=1: clock stamps of matrix 0's chain (probes)
+    if (stamps_env < 0) { const char* e = getenv("GPRN_CHAIN_STAMPS"); stamps_env = e ? atoi(e) : 0; }
+    if (use_chain && stamps_env && c->stamps_T < c->T) {
+        if (c->d_stamps) hipFree(c->d_stamps);
+        HIP_TRY(c, hipMalloc(&c->d_stamps, (size_t)c->T * 8 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_stamps, 0, (size_t)c->T * 8 * sizeof(unsigned long long)));
+        c->stamps_T = c->T;
+    }
+    if (use_chain) {
+        const int outer_w = c->outers[set][0].k1 - c->outers[set][0].k0;
+        prof_begin(c, GPRN_T_DIAG, s0);
+        // 48 KiB of dynamic LDS on top of the 72 KiB it uses: nothing else fits on its CU
+        hipLaunchKernelGGL(k_chain, dim3(nbatch), dim3(256), 48 * 1024, s0, (double* const*)c->d_ptrs, c->ld, c->T,
+                           outer_w, c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_MINIL, (int)F_INNER,
+                           (int)F_FIRST, epoch, timed_out, c->d_stamps);
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+        if (c->chain_started) {
+            // work that must not take the chain's CUs before it is resident (run_phase: the X^T X product of
+            // the node phase, which fills the head of the weight phase): behind the first diagonal block
+            HIP_TRY(c, await(s2, 0, F_DIAG));
+            std::function<int()> f;
+            f.swap(c->chain_started);
+            if ((rc = f())) return rc;
+        }
+    }
+    if (!use_chain && c->chain_started) {              // launch schedule: nothing to wait for
+        std::function<int()> f;
+        f.swap(c->chain_started);
+        if ((rc = f())) return rc;
+    }
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
             const gprn_ctx::StepRange& s = c->steps[set][k];
+            if (use_chain && s.npanel_l > 0) {
+                // stream3's half of the step; diag(k), L_{k+1,k} and B_{k+1,k+1} are k_chain's
+                if (first_J >= 0) first_J = -1;        // (k_chain waits for F_FIRST itself)
+                if ((rc = side_sync(k))) return rc;
+                if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
+                if (s.npanel > s.npanel_l) {
+                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
+                                    x_part_then(k)))) return rc;
+                } else HIP_TRY(c, await(s1, k, F_MINIL));
+                if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+                if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
+                inner_k = k;
+                continue;
+            }
+            if (use_chain) {                           // last tile step: diag(k) was k_chain's last act
+                if ((rc = flush_inner())) return rc;
+                if (k > 0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+                if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64))) return rc;
+                continue;
+            }
             // Every tile step looks the same to the chain, panel boundaries included (the two tiles the
             // next panel starts with are updated step by step, see ensure_tasks):
             //   chain  : diag(k)  ->  L_{k+1,k}  ->  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T
@@ -777,6 +922,22 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
 // a dependency wait inside a chain kernel gave up (see Await): the results of that call are void
 int factor_check_waits(gprn_ctx* c)
 {
+    if (c->d_stamps && c->stamps_T >= c->T && c->T > 1) {     // development aid: print the last chain's timeline
+        std::vector<unsigned long long> h((size_t)c->T * 8);
+        if (hipMemcpy(h.data(), c->d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
+            double sum[8] = {0};
+            int n = 0;
+            for (int k = 1; k + 2 < c->T; ++k, ++n)
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned long long a = h[(size_t)k * 8 + i], b = i < 7 ? h[(size_t)k * 8 + i + 1] : h[(size_t)(k + 1) * 8];
+                    sum[i] += (double)(b - a) * 0.01;        // 100 MHz ticks -> us
+                }
+            if (n > 0)
+                fprintf(stderr, "[gprn] chain us/step over %d steps: diag %.1f publish %.1f -> %.1f wait %.1f L %.1f publish %.1f "
+                                "U %.1f drain %.1f\n", n, sum[0] / n, sum[1] / n, sum[2] / n, 0.0, sum[3] / n, sum[4] / n,
+                        sum[5] / n, sum[6] / n + sum[7] / n);
+        }
+    }
     if (!c->d_sig) return GPRN_OK;
     unsigned flag = 0;
     HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -806,6 +967,11 @@ int factor_invert(gprn_ctx* c, int nbatch)
     auto few = [&](size_t ntasks) { return ntasks * (size_t)nbatch <= few_max; };
     const int set = nbatch * c->T <= 32 ? 1 : 0;   // latency schedule: little work in total (measured:
                                                    // +11 % at N=2048 x 1 matrix, -3 % at N=4096 x 2)
+    if (c->chain_started) {
+        std::function<int()> f;
+        f.swap(c->chain_started);
+        if ((rc = f())) return rc;
+    }
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {            // the latency chain of this panel

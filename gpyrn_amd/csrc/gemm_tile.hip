@@ -31,35 +31,7 @@
 
 #include <type_traits>
 
-typedef double v4d __attribute__((ext_vector_type(4)));
-typedef double v2d __attribute__((ext_vector_type(2)));
-typedef const GPRN_GLOBAL v2d* gv2d_t;
-typedef const GPRN_GLOBAL char* gcbytes_t;
-
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-
-// Staging geometry.  A thread moves R*8/NT 16-byte pieces of an operand chunk (R rows x 16 k); piece `it`
-// differs from piece 0 by +64 rows (only when the lanes cover 64 of 128 rows) and/or +8 k in BOTH memory
-// layouts, so one lane offset serves all pieces: memory address = base + lane offset + a uniform per-piece
-// offset (the buffer load's scalar offset), LDS address = lane base + an immediate.
-//   mode 0, element (row, k) at row*ld + k: piece = (row, 2kp), (row, 2kp+1); lane = (kp & 3, row)
-//   mode 1, element (row, k) at k*ld + row: piece = (2rp, k), (2rp+1, k);     lane = (rp, k & 7)
-template <int R, int NT>
-__device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigned& goff, int& l0)
-{
-    constexpr int P = R + 16;
-    constexpr int RL = (R < NT / 4) ? R : NT / 4;          // rows the lane index spans (64 or 128)
-    static_assert(R * 8 >= NT && (RL == 64 || RL == 128), "unsupported tile / workgroup combination");
-    if (mode == 0) {
-        const int kp = tid & 3, row = (tid >> 2) & (RL - 1);
-        goff = ((unsigned)row * (unsigned)ld + 2u * kp) * 8u;
-        l0 = (2 * kp) * P + (row ^ (4 * kp));
-    } else {
-        const int rp = tid & (RL / 2 - 1), k = tid / (RL / 2);      // k < 8
-        goff = ((unsigned)k * (unsigned)ld + 2u * rp) * 8u;
-        l0 = k * P + ((2 * rp) ^ (4 * ((k >> 1) & 3)));
-    }
-}
+#include "tile_mma.h"
 
 // Output tile of one workgroup: BM x BN in {64,128}^2, computed by NW = 4 waves (2 x 2) or 8 waves (2 x 4).
 // A 128x128 task is cut into (128/BM) x (128/BN) workgroups (sub-tile index = blockIdx.x % that).
@@ -84,17 +56,9 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out)
 {
     await_flag(wait_flag, wait_value, wait_timed_out);
-    constexpr int NT = 64 * NW, WM = 2, WN = NW / 2;            // waves: WM x WN
+    constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
-    constexpr int TM = BM / WM, TN = BN / WN;                   // a wave's part of the tile
-    constexpr int MI = TM / 16, NI = TN / 16;                   // 16x16 MFMA tiles per wave
-    constexpr int PA = BM + 16, PB = BN + 16;                   // LDS pitches, doubles
-    constexpr int A_DOUBLES = 16 * PA, B_DOUBLES = 16 * PB;
-    constexpr int STAGE = A_DOUBLES + B_DOUBLES;
-    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte loads per thread per chunk
-    constexpr bool A_ROWS2 = BM * 4 > NT, B_ROWS2 = BN * 4 > NT;   // the pieces of a thread span 2 x 64 rows
-    static_assert(A_IT >= 1 && B_IT >= 1 && NI >= 1 && (MI % 2 == 0) && (NI % 2 == 0), "tile too small for the workgroup");
-    __shared__ __attribute__((aligned(16))) double lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
 
     const TileTask t = tasks[blockIdx.x / (SM * SN)];
     const int sub = blockIdx.x % (SM * SN), sr = sub / SN, sc = sub % SN;
@@ -109,184 +73,8 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const double* B = pick(t.b_buf) + t.b_off + (b_mode ? (size_t)sc * BN : (size_t)sc * BN * ld);
     gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sr * BM * ld + sc * BN;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave / WN, wc = wave % WN;
-
-    // ---- global -> LDS staging (lane_geometry): buffer loads = uniform base (advanced per chunk) + lane
-    // offset + uniform piece offset; the two doubles of a piece go to lane base (+ dl) + immediate
-    const size_t a_step = a_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;       // doubles per chunk
-    const size_t b_step = b_mode ? (size_t)GPRN_KC * ld : (size_t)GPRN_KC;
-    unsigned a_g, b_g;
-    int a_l, b_l;
-    lane_geometry<BM, NT>(tid, a_mode, ld, a_g, a_l);
-    lane_geometry<BN, NT>(tid, b_mode, ld, b_g, b_l);
-    const int a_l0 = a_l * 8, a_l1 = a_l0 + (a_mode ? 1 : PA) * 8;              // LDS byte addresses, stage 0
-    const int b_l0 = (A_DOUBLES + b_l) * 8, b_l1 = b_l0 + (b_mode ? 1 : PB) * 8;
-    // uniform piece offsets in memory, bytes: +64 rows, +8 k
-    const unsigned a_row64 = (a_mode ? 64u : 64u * (unsigned)ld) * 8u, a_k8 = (a_mode ? 8u * (unsigned)ld : 8u) * 8u;
-    const unsigned b_row64 = (b_mode ? 64u : 64u * (unsigned)ld) * 8u, b_k8 = (b_mode ? 8u * (unsigned)ld : 8u) * 8u;
-    // ---- MFMA operand fetch: lane holds A[row = fr][k = fk], B[k = fk][col = fr]; LDS byte address of
-    // k4-step ks = lane base[ks] + immediate (16-row block, stage)
-    const int fr = lane & 15, fk = lane >> 4;
-    const int mb16 = (sr * BM + wr * TM) >> 4, nb16 = (sc * BN + wc * TN) >> 4;   // wave's first 16-blocks
-    int a_fb[4], b_fb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int k = 4 * ks + fk, sw = fr ^ (4 * ((k >> 1) & 3));
-        a_fb[ks] = (k * PA + wr * TM + sw) * 8;
-        b_fb[ks] = (A_DOUBLES + k * PB + wc * TN + sw) * 8;
-    }
-    const char* const lds_b = reinterpret_cast<const char*>(lds);
-    char* const lds_w = reinterpret_cast<char*>(lds);
-    auto frag = [&](int byte_addr) { return *reinterpret_cast<const double*>(lds_b + byte_addr); };
-
-    const bool neg = c_mode != CM_SET;                       // acc holds -(result)
-    gptr_t Cw = C + (size_t)(wr * TM + fk) * ld + wc * TN + fr;
-    v4d acc[MI][NI];
-
-    const int nchunks = t.klen / GPRN_KC;
-    v2d ra[A_IT], rb[B_IT];
-    auto load_chunk = [&]() {
-        // raw buffer resources over the chunk's base: 48-bit address, no stride, no bounds (num_records max)
-        const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const unsigned so = A_ROWS2 ? (it & 1) * a_row64 + (it >> 1) * a_k8 : it * a_k8;
-            ra[it] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, a_g, so, 0));
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const unsigned so = B_ROWS2 ? (it & 1) * b_row64 + (it >> 1) * b_k8 : it * b_k8;
-            rb[it] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, b_g, so, 0));
-        }
-    };
-    auto write_chunk = [&](int stage_bytes) {
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int imm = stage_bytes + (A_ROWS2 ? (it & 1) * 64 * 8 + (it >> 1) * 8 * PA * 8 : it * 8 * PA * 8);
-            *reinterpret_cast<double*>(lds_w + a_l0 + imm) = ra[it][0];
-            *reinterpret_cast<double*>(lds_w + a_l1 + imm) = ra[it][1];
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int imm = stage_bytes + (B_ROWS2 ? (it & 1) * 64 * 8 + (it >> 1) * 8 * PB * 8 : it * 8 * PB * 8);
-            *reinterpret_cast<double*>(lds_w + b_l0 + imm) = rb[it][0];
-            *reinterpret_cast<double*>(lds_w + b_l1 + imm) = rb[it][1];
-        }
-    };
-
-    load_chunk();
-    // The C tile is requested AFTER the first operand chunk: memory returns in order, so the
-    // LDS staging below waits only for the chunk, and the first MFMA of each accumulator only for
-    // its own four values -- most of the tile streams in behind the first MFMAs.
-    __builtin_amdgcn_sched_barrier(0);
-    if (c_mode == CM_SUB) {                      // one uniform branch around all the loads
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = -Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16];
-    } else {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    write_chunk(0);
-    if (nchunks > 1) { A += a_step; B += b_step; }
-    load_chunk();                                // chunk 1 (chunk 0 again when there is only one)
-    __syncthreads();
-
-    // fragments of the k4-step about to be multiplied: B's are fetched a whole step ahead (every
-    // MFMA of a step reads them), A's row block by row block as the previous step lets go of them
-    double af[MI], bf[2][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[i] = frag(a_fb[0] + i * 128);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bf[0][j] = frag(b_fb[0] + j * 128);
-
-    // One K-chunk: four k4-steps of MI*NI MFMAs.  Beside them: the fragments of the next step, the
-    // staging of chunk c+1 into the other LDS stage (second step; its global loads were issued a
-    // chunk ago), the request of chunk c+2, and -- before the last step -- the one barrier that
-    // publishes stage c+1 and retires the reads of stage c, so that the last step can already fetch
-    // the first fragments of the next chunk.  The sched_group_barrier sequences spread the memory
-    // instructions between the MFMAs (each holds the matrix pipe for 64 cycles: whatever issues in
-    // its shadow is free, whatever is clustered between two of them is not).
-    auto chunk = [&](auto last_c, int sb, int c) {
-        constexpr bool LAST = decltype(last_c)::value;
-        const int nb = sb ^ (STAGE * 8);                       // byte offsets of this chunk's and the next one's stage
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-            const bool fetch = ks < 3 || !LAST;                // there is a next step
-            const int fb_off = ks < 3 ? sb : nb, fb_ks = ks < 3 ? ks + 1 : 0;
-            if (fetch) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) bf[nxt][j] = frag(fb_off + b_fb[fb_ks] + j * 128);
-            }
-            if (ks == 1 && !LAST) {
-                write_chunk(nb);
-                // chunk c+2, or once more the last one (its registers are not read again)
-                const bool more = c + 2 < nchunks;
-                A += more ? a_step : 0;
-                B += more ? b_step : 0;
-                load_chunk();
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if (TRI == 1 && c > nb16 + j) continue;     // wave-uniform
-                    if (TRI == 2 && c > mb16 + i) continue;
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[cur][j], acc[i][j], 0, 0, 0);
-                }
-                if (fetch) af[i] = frag(fb_off + a_fb[fb_ks] + i * 128);
-            }
-            if (TRI == 0) {
-                // issue order of this step: MFMAs and memory instructions in turn (adjacent fragment
-                // reads pair up into ds_read2_b64: (MI + NI) / 2 read instructions per step)
-                constexpr int NMF = MI * NI, NRD = (MI + NI) / 2;
-                constexpr int NWR = 2 * (A_IT + B_IT), NLD = A_IT + B_IT;
-                if (ks == 1 && !LAST) {
-#pragma unroll
-                    for (int g = 0; g < NLD; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, NMF / NLD, 0);
-                        if (g < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x200, NWR / NLD, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    }
-                } else if (fetch) {
-#pragma unroll
-                    for (int g = 0; g < NRD; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    }
-                }
-            }
-            if (ks == 2 && !LAST) __syncthreads();
-        }
-    };
-    int sb = 0;
-    for (int c = 0; c < nchunks - 1; ++c) {
-        chunk(std::false_type{}, sb, c);
-        sb ^= STAGE * 8;
-    }
-    chunk(std::true_type{}, sb, nchunks - 1);
-
-    // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cw[(size_t)(i * 16 + 4 * r) * ld + j * 16] = neg ? -acc[i][j][r] : acc[i][j][r];
+    tile_mma<BM, BN, WM, WN, TRI, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+                                         (sr * BM) >> 4, (sc * BN) >> 4);
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -148,6 +149,10 @@ struct gprn_ctx {
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
     int sig_budget_ms = -1;          // budget the device word holds
+    // enqueued by the next factor_invert right behind the start of its persistent chain kernel (factor.hip)
+    std::function<int()> chain_started;
+    unsigned long long* d_stamps = nullptr;   // GPRN_CHAIN_STAMPS: clock stamps of the chain kernel (probes)
+    int stamps_T = 0;
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update

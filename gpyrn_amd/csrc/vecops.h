@@ -16,3 +16,5 @@ int vec_elbo(gprn_ctx* c, double* out4);
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);
 int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,
                   double* mean, double* var);
+int vec_axpy_matrix(gprn_ctx* c, const double* src, double* dst, int N);   // dst += src on the N x N block (pitch ld)
+int vec_symmetrize(gprn_ctx* c, double* M);                                 // upper := lower^T on the ld x ld matrix

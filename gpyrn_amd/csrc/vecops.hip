@@ -484,6 +484,36 @@ int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out)
     LAUNCH_END(c);
 }
 
+// dst += src on the N x N block of two ld-pitched matrices (the node sum of quirk Q1 for the gradient)
+__global__ __launch_bounds__(256)
+void k_axpy_matrix(const double* __restrict__ src, double* __restrict__ dst, int N, int ld)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n < N && m < N) dst[(size_t)m * ld + n] += src[(size_t)m * ld + n];
+}
+
+int vec_axpy_matrix(gprn_ctx* c, const double* src, double* dst, int N)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_axpy_matrix, dim3((N + 255) / 256, N), dim3(256), 0, c->stream, src, dst, N, c->ld);
+    LAUNCH_END(c);
+}
+
+// upper triangle := transpose of the lower one (ld x ld)
+__global__ __launch_bounds__(256)
+void k_symmetrize(double* __restrict__ M, int ld)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n < ld && n > m) M[(size_t)m * ld + n] = M[(size_t)n * ld + m];
+}
+
+int vec_symmetrize(gprn_ctx* c, double* M)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_symmetrize, dim3((c->ld + 255) / 256, c->ld), dim3(256), 0, c->stream, M, c->ld);
+    LAUNCH_END(c);
+}
+
 // ---- prediction (gprn_predict): mean[i] = sum_n Ks[i][n] sol[n];  q[i] = sum_a WT[i][a]^2
 __global__ __launch_bounds__(256)
 void k_pred_rows(double* const* __restrict__ ptrs, int ns, int N, int ld, int ns_pad,

@@ -32,6 +32,7 @@ from ._utils import Array, _array_input  # noqa: F401
 __all__ = ['inference']
 
 _NUGGET = 1e-6          # meanfield.py:433
+_TINY_NUGGET = 1.25e-12 # meanfield.py:450
 _TWO_ARGUMENT = (covfunc.HarmonicPeriodic, covfunc.QuasiHarmonicPeriodic,
                  covfunc.Polynomial)          # meanfield.py:426-428
 _NOT_SET = 'GPRN components not set, use set_components'
@@ -330,6 +331,19 @@ class inference:
         else:
             ctx.set_kernel(gp, spec[1], spec[2], spec[3])
 
+    def _device_K(self, kernel, time, nugget):
+        """K = kernel at the data times + nugget on the diagonal through the fused HIP fill (built-in kernels
+        and their sums / products at the data's own time stamps), else None."""
+        if not (time is self.time or (np.shape(time) == np.shape(self.time)
+                                      and np.array_equal(time, self.time))):
+            return None
+        program = kernel._device_program() if isinstance(kernel, covfunc.covFunction) else None
+        if program is None:
+            return None
+        ops, params = program
+        two = isinstance(kernel, _TWO_ARGUMENT)        # evaluated without a nugget (meanfield.py:426-431)
+        return self._backend().eval_kernel(ops, params, 0.0 if two else nugget)
+
     def _KMatrix(self, kernel, time=None):
         """
         Covariance matrix of `kernel` at the data times, with the reference's
@@ -337,20 +351,61 @@ class inference:
         for built-in kernels when `time` is the data's own time vector.
         """
         time = self.time if time is None else time
-        if time is self.time or (np.shape(time) == np.shape(self.time)
-                                 and np.array_equal(time, self.time)):
-            ctx = self._backend()
-            if isinstance(kernel, covfunc.covFunction) and kernel._device_program() is not None:
-                scratch = _hip.Context(ctx_device(ctx))
+        K = self._device_K(kernel, time, _NUGGET)
+        return self._host_K(kernel, np.asarray(time, dtype=float)) if K is None else K
+
+    def _tinyNuggetKMatrix(self, kernel, time=None):
+        """Covariance matrix with the tiniest stability nugget, 1.25e-12 (meanfield.py:436-452)."""
+        time = self.time if time is None else time
+        K = self._device_K(kernel, time, _TINY_NUGGET)
+        if K is not None:
+            return K
+        time = np.asarray(time, dtype=float)
+        if isinstance(kernel, _TWO_ARGUMENT):
+            return kernel(time[:, None], time[None, :])
+        r = time[:, None] - time[None, :]
+        return kernel(r) + _TINY_NUGGET * np.eye(time.size)
+
+    def _sample_from_gp(self, kernel, time=None):
+        """
+        One draw from the GP prior of `kernel` at `time` (meanfield.py:517-531).  The reference hands the
+        tiny-nugget matrix to scipy's ``multivariate_normal(..., allow_singular=True)``; here the draw is
+        ``L z`` with ``z`` from NumPy's global generator and ``K + nugget I = L L^T`` factored on the GPU,
+        the nugget growing from 1.25e-12 by factors of 100 (to 1.25e-6 at most) while fp64 finds the matrix
+        not positive definite -- what ``allow_singular`` papers over on the CPU.  Same distribution, not
+        the same stream of numbers.  Kernels without a device program are factored on the host.
+        """
+        time = self.time if time is None else time
+        n = np.size(time)
+        z = np.random.standard_normal(n)
+        program = kernel._device_program() if isinstance(kernel, covfunc.covFunction) else None
+        same_t = time is self.time or (np.shape(time) == np.shape(self.time) and np.array_equal(time, self.time))
+        nugget = _TINY_NUGGET
+        while True:
+            if program is not None and same_t and not isinstance(kernel, _TWO_ARGUMENT):
+                out, info = self._backend().sample_prior(program[0], program[1], nugget, z[None])
+                if info == 0:
+                    return out[0]
+            else:
+                K = self._tinyNuggetKMatrix(kernel, np.asarray(time, dtype=float))
+                K = K + (nugget - _TINY_NUGGET) * np.eye(n)
                 try:
-                    scratch.set_data(np.asarray(self.time, dtype=float), self.y[:1], self.yerr[:1], 1)
-                    self._send_spec(scratch, 0, self._kernel_spec(kernel))
-                    self._send_spec(scratch, 1, self._kernel_spec(covfunc.Constant(1.0)))
-                    scratch.factor_priors()
-                    return scratch.get_matrix(_hip.M_K, 0)
-                finally:
-                    scratch.close()
-        return self._host_K(kernel, np.asarray(time, dtype=float))
+                    return np.linalg.cholesky(K) @ z
+                except np.linalg.LinAlgError:
+                    pass
+            if nugget >= 1e-6:
+                raise np.linalg.LinAlgError('prior covariance is not positive definite even with a 1e-6 nugget')
+            nugget *= 100.0
+
+    def sample(self, time=None):
+        """Draws of every node and weight GP from its prior (meanfield.py:533-539; it prints the two
+        shapes, so does this).  Returns (node_samples (q, N), weight_samples (q*p, N))."""
+        nodes, weights, means, jitters = self._get_components()
+        node_samples = np.array([self._sample_from_gp(node) for node in nodes])
+        weight_samples = np.array([self._sample_from_gp(weight) for weight in weights])
+        print(node_samples.shape)
+        print(weight_samples.shape)
+        return node_samples, weight_samples
 
     def _setup_device(self, nodes, weights, means, jitters):
         """The setup block of ELBOcalc (meanfield.py:618-624) on the GPU."""
@@ -482,11 +537,15 @@ class inference:
         Maximise the ELBO over the free parameters with scipy.optimize.minimize
         (Nelder-Mead unless `method` is given).  `vars`: 'name' optimises only
         that parameter, '-name' all but it, a list optimises those named.
+        ``jac=True`` hands scipy the analytic gradient (``nELBO_and_grad``).
         """
         from scipy.optimize import minimize
         self._select_vars(vars)
         kwargs.setdefault('method', 'Nelder-Mead')
-        res = minimize(self.nELBO, self.get_parameters(), **kwargs)
+        # jac=True (not in the reference, which is derivative-free): the analytic gradient of grad_ELBO,
+        # e.g. optimize(method='L-BFGS-B', jac=True)
+        fun = self.nELBO_and_grad if kwargs.get('jac') is True else self.nELBO
+        res = minimize(fun, self.get_parameters(), **kwargs)
         self.set_parameters(res.x)
         return res
 
@@ -575,18 +634,113 @@ class inference:
         f = lambda x: float(self.nELBO(x, max_iter=max_iter))
         return list(map(f, sets)) if pool is None else pool.map(f, sets)
 
+    # ------------------------------------------------------------ gradients
+    def grad_ELBO(self):
+        """
+        Gradient of the ELBO with respect to ALL parameters (the order of ``get_parameters(
+        include_frozen=True)``: nodes, weights, means, jitters) at the current variational state.
+
+        Not in the reference, whose optimiser is derivative-free (meanfield.py:1149-1150).
+        One more committed sweep is run from the stored state with the explicit covariances kept; the
+        gradient is the partial derivative of THAT sweep's ELBO (returned with it) at fixed variational
+        means and covariances -- what the envelope theorem makes the total derivative at a converged state:
+
+        * kernel hyper-parameters enter through the expected log prior only (meanfield.py:992-1067):
+          ``dELBO/dtheta = 1/(2q) < K^-1 S K^-1 + a a^T - K^-1 , dK/dtheta >`` with ``a = K^-1 m`` and the
+          (S, m) the reference pairs with that kernel -- quirks included: node j meets the cumulative
+          ``Sigma_f0 + ... + Sigma_fj`` (Q1), weight (j, i) the raw-reshape row of ``mu_w`` (Q2).  The
+          N^3 work (K^-1, K^-1 S K^-1) runs on the GPU (``gprn_grad_matrices``); ``dK/dtheta`` comes from
+          ``covFunction._dk_dpars`` (closed forms for SquaredExponential, Periodic, QuasiPeriodic; central
+          differences of ``kernel(r)`` otherwise, user kernels included).
+        * jitters enter through the expected log likelihood (meanfield.py:895-990), in closed form.
+        * mean-function parameters: zero.  The reference's likelihood term reads the RAW data (quirk Q3),
+          so at a fixed variational state the ELBO does not depend on them.
+
+        Returns ``(ELBO, gradient)``.  Unsharded problems only.
+        """
+        assert self._components_set, _NOT_SET
+        if self._mu is None:
+            self.ELBOcalc()
+        nodes, weights, means, jitters = self._get_components()
+        ctx = self._setup_device(nodes, weights, means, jitters)
+        ctx.set_muvar(self._mu, self._var)
+        ctx.keep_sigma(True)
+        try:
+            elbo, _, info = ctx.sweep(1, commit=True)
+            mu, var = ctx.get_muvar()
+            grads = self._grad_from_state(nodes, weights, means, jitters, mu, var, ctx.grad_matrices)
+        finally:
+            ctx.keep_sigma(False)
+        self._mu, self._var = mu, var
+        self.last_info = info
+        return float(elbo[0]), np.array(grads)
+
+    def _grad_from_state(self, nodes, weights, means, jitters, mu, var, matrices):
+        """The O(N^2) and O(pqN) part of grad_ELBO: `matrices(gp)` returns ``(K^-1, K^-1 S K^-1)`` of latent GP
+        `gp` (the GPU's ``gprn_grad_matrices``; a NumPy stand-in in the CPU tests)."""
+        t = np.asarray(self.time, dtype=float)
+        r = t[:, None] - t[None, :]
+        q, p, N = self.q, self.p, self.N
+        m_scr = mu[1:].reshape(q, p, N)                      # quirk Q2 (meanfield.py:1021)
+        grads = []
+        for gp, kernel in enumerate(chain(nodes, weights)):
+            Kinv, P = matrices(gp)
+            if gp < q:
+                m = mu[0, gp]
+            else:
+                jj, ii = divmod(gp - q, p)
+                m = m_scr[jj, ii]
+            a = Kinv @ m
+            G = 0.5 * (P - Kinv + np.outer(a, a)) / q        # ELBO = (...) / q, meanfield.py:709
+            if isinstance(kernel, _TWO_ARGUMENT):
+                keep = kernel.pars.copy()
+                dks = []
+                for i, v in enumerate(keep):                  # kernel(t_i, t_j): differences only
+                    h = 1e-6 * max(1.0, abs(v))
+                    kernel.pars = keep.copy(); kernel.pars[i] = v + h
+                    up = kernel(t[:, None], t[None, :])
+                    kernel.pars = keep.copy(); kernel.pars[i] = v - h
+                    dks.append((up - kernel(t[:, None], t[None, :])) / (2 * h))
+                kernel.pars = keep
+            else:
+                dks = kernel._dk_dpars(r)
+            grads += [float(np.sum(G * dk)) for dk in dks]
+        grads += [0.0] * sum(0 if m_ is None else int(m_._parsize) for m_ in means)
+        # jitters: LogL = -1/2 sum [log(2 pi v) + ((Y - fit)^2 + A) / v],  v = jitter^2 + yerr^2
+        variance = np.asarray(jitters, dtype=float)[:, None]**2 + self.yerr2
+        fit = np.einsum('iqn,qn->in', mu[1:], mu[0])
+        A = np.zeros((p, N))
+        for i in range(p):
+            for j in range(q):
+                A[i] += var[0, j] * mu[1 + i, j]**2 + var[1 + i, j] * mu[0, j]**2 + var[0, j] * var[1 + i, j]
+        dv = -0.5 * (1.0 / variance - ((self.y - fit)**2 + A) / variance**2)
+        grads += [float(np.sum(dv[i]) * 2 * jitters[i]) / q for i in range(p)]
+        return grads
+
+    def nELBO_and_grad(self, parameters, max_iter=None):
+        """``(-ELBO, -dELBO/dparameters)`` over the FREE parameters, for gradient-based optimisers:
+        ``nELBO(parameters)`` (warm-started ELBOcalc, as the reference's objective), then ``grad_ELBO``."""
+        self.nELBO(parameters, max_iter=max_iter)
+        elbo, grad = self.grad_ELBO()
+        return -elbo, -grad[~self.frozen_mask]
+
     def mcmc(self, priors, p0=None, vars=None, niter=500, **kwargs):
         """
         Sample the posterior of the free parameters with emcee, the ELBO (100
         sweeps at most, warm-started) standing in for the marginal likelihood
         (meanfield.py:1154-1286).  `priors`: dict name -> frozen scipy.stats
         distribution.  emcee is imported here, not at package import; without it
-        this raises ImportError.  Returns the sampler.  ``pool=sharding.EvalPool()``
-        (forwarded to emcee with the other keyword arguments) spreads the walkers
-        over the GPUs of the node.
+        this raises ImportError.  Returns the sampler.
+
+        Same sequence as the reference: walkers from the priors (or an ellipsoid around `p0`), one
+        evaluation of every initial walker (it also moves the warm-start state), a sampler over an HDF
+        backend file ``gprn.h5`` that is reset on every call, convergence from the autocorrelation time
+        every ten steps.  Beyond the reference: keyword arguments go on to ``emcee.EnsembleSampler`` (the
+        reference accepts and drops them), so ``pool=sharding.EvalPool()`` spreads the walkers over the
+        GPUs of a node; ``backend=`` replaces the HDF file, and without h5py emcee's in-memory backend is used.
         """
         assert self._components_set, _NOT_SET
-        from emcee import EnsembleSampler
+        from emcee import EnsembleSampler, backends
         self._select_vars(vars)
         names = np.array(list(self.parameters_dict.keys()))[~self.frozen_mask]
 
@@ -605,23 +759,47 @@ class inference:
 
         ndim = len(names)
         nwalkers = 2 * ndim
+        print(f'Setting up sampler (parameters: {ndim}, walkers: {nwalkers})')
         if p0 is None:
             p0 = np.array([draw() for _ in range(nwalkers)])
         else:
             from emcee.utils import sample_ellipsoid
-            sigma = [priors[n].std() if callable(priors[n].std) else priors[n].std for n in names]
+            sigma = []
+            for n in names:
+                try:
+                    sigma.append(priors[n].std())
+                except TypeError:
+                    sigma.append(priors[n].std)
             p0 = sample_ellipsoid(p0, np.diag(sigma) / 100, size=nwalkers)
             for i, x in enumerate(p0):
                 if np.isneginf(logprior(x)):
                     p0[i] = draw()
+        print('initial values for parameters are set')
+        start = time_module.time()
+        _ = [logposterior(x) for x in p0]
+        print()
+        print(f'evaluation for initial values took {time_module.time() - start:.0f} sec')
+        print('- adjust your expectations accordingly')
+
+        if 'backend' not in kwargs:
+            try:
+                be = backends.HDFBackend('gprn.h5')
+                be.reset(nwalkers, ndim)
+                kwargs['backend'] = be
+            except ImportError:                # h5py missing: emcee's default in-memory backend
+                pass
         sampler = EnsembleSampler(nwalkers, ndim, logposterior, **kwargs)
         old_tau = np.inf
-        for _ in sampler.sample(p0, iterations=niter, progress=False):
+        for sample in sampler.sample(p0, iterations=niter, progress=True):
+            if sampler.iteration % 10 == 0:
+                print(sample.log_prob.max())
             if sampler.iteration % 10:
                 continue
             tau = sampler.get_autocorr_time(tol=0)
-            if np.all(tau * 100 < sampler.iteration) and \
-                    np.all(np.abs(old_tau - tau) / tau < 0.01):
+            converged = np.all(tau * 100 < sampler.iteration)
+            converged &= np.all(np.abs(old_tau - tau) / tau < 0.01)
+            if converged:
+                print('MCMC converged!')
                 break
             old_tau = tau
         return sampler
@@ -645,7 +823,3 @@ class inference:
         else:
             raise ValueError(f'`vars` should be str or list, got {type(vars)}')
 
-
-def ctx_device(ctx):
-    """GPU ordinal a context lives on (contexts do not expose it in the C ABI)."""
-    return getattr(ctx, 'device', 0)

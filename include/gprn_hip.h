@@ -135,6 +135,29 @@ int gprn_sweep(gprn_ctx* ctx, int n_sweeps, int commit,
  * ranks are left untouched.  Needs device-evaluable kernels (gprn_set_kernel). */
 int gprn_predict(gprn_ctx* ctx, int ns, const double* tstar, double* mean_out, double* var_out);
 
+/* ---- kernel matrices and prior draws outside the ELBO loop ----
+ * eval_kernel: K = expr(t_i, t_j) + nugget I at the data times through the fused fill kernel: replaces
+ * inference._KMatrix (meanfield.py:413-434; nugget 1e-6) and _tinyNuggetKMatrix (:436-452; 1.25e-12) when
+ * they are called on their own.  K_out (N, N).
+ * sample_prior: out[s] = L z[s], K + nugget I = L L^T by the blocked factorisation: replaces
+ * inference._sample_from_gp / sample (:517-539), which draw from scipy's multivariate_normal.  z, out:
+ * (n_samples, N); z = standard normals of the caller's generator.  Returns info > 0 when K + nugget I is
+ * not positive definite in fp64. */
+int gprn_eval_kernel(gprn_ctx* ctx, const int32_t* ops, int n_ops, const double* params, int n_params,
+                     double nugget, double* K_out);
+int gprn_sample_prior(gprn_ctx* ctx, const int32_t* ops, int n_ops, const double* params, int n_params,
+                      double nugget, int n_samples, const double* z, double* out);
+
+/* ---- analytic gradient of the ELBO in the kernel hyper-parameters (not in the reference,
+ * whose optimiser is derivative-free, meanfield.py:1149-1150; the derivative hooks it carries are
+ * covfunc.py:172-185, 215-221, 257-266).  At fixed variational state only the expected log prior
+ * (meanfield.py:992-1067) depends on K_gp:  d/dtheta = 1/2 < K^-1 S K^-1 + a a^T - K^-1, dK/dtheta >, with S the
+ * covariance the reference pairs with K_gp (node j: Sigma_f0 + ... + Sigma_fj; weight: its Sigma_w) and
+ * a = K^-1 m.  This entry does the O(N^3) part on the device and returns K^-1 and P = K^-1 S K^-1, both
+ * (N, N) symmetric; needs gprn_factor_priors and a committed sweep with gprn_keep_sigma(1).  Unsharded
+ * contexts only. */
+int gprn_grad_matrices(gprn_ctx* ctx, int gp, double* Kinv_out, double* P_out);
+
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */
 enum {
     GPRN_M_K = 0,        /* prior covariance K_gp (N,N) */

@@ -96,7 +96,7 @@ def expected_loglike(y_raw, variance, mu_f, mu_w, dsf, dsw):
 
 
 # --------------------------------------------------------- form "ref"
-def sweep_ref(Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var):
+def sweep_ref(Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var, return_sigma=False):
     """One ELBOaux in the reference's formulation.
 
     Kf (q,N,N), Kw (q*p,N,N) flat index j*p+i, Lf/Lw their lower Cholesky
@@ -156,7 +156,36 @@ def sweep_ref(Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var):
     logl = expected_loglike(y_raw, variance, mu_f, mu_w, dsf, dsw)
     new_mu = np.concatenate((mu_f[None], mu_w))
     new_var = np.concatenate((dsf[None], np.transpose(dsw, (1, 0, 2))))
+    if return_sigma:
+        return (logl + logp + ent) / q, new_mu, new_var, (logl, logp, ent), sig_f, sig_w
     return (logl + logp + ent) / q, new_mu, new_var, (logl, logp, ent)
+
+
+def fixed_state_elbo(Kf, Kw, y_raw, yerr2, jitt2, mu_f, mu_w, sig_f, sig_w):
+    """(LogL + LogP)/q of meanfield.py:895-1067 as a function of the prior matrices and the jitters, with the
+    variational means (mu_f (q,N), mu_w (p,q,N)) and covariances (sig_f (q,N,N), sig_w (q,p,N,N)) held fixed --
+    the entropy does not depend on either.  Finite differences of this are what the analytic gradient of
+    gpyrn_amd.inference.grad_ELBO is checked against."""
+    q, N = Kf.shape[0], Kf.shape[-1]
+    p = Kw.shape[0] // q
+    Kw4 = Kw.reshape(q, p, N, N)
+    variance = jitt2[:, None] + yerr2
+    m_scr = mu_w.reshape(q, p, N)
+    logp = 0.0
+    cum = np.zeros((N, N))
+    for j in range(q):
+        cum = cum + sig_f[j]
+        L = np.linalg.cholesky(Kf[j])
+        logp += -np.sum(np.log(np.diag(L))) - 0.5 * (mu_f[j] @ cho_solve((L, True), mu_f[j])
+                                                     + np.trace(cho_solve((L, True), cum)))
+        for i in range(p):
+            L = np.linalg.cholesky(Kw4[j, i])
+            logp += -np.sum(np.log(np.diag(L))) - 0.5 * (m_scr[j, i] @ cho_solve((L, True), m_scr[j, i])
+                                                         + np.trace(cho_solve((L, True), sig_w[j, i])))
+    dsf = np.einsum('jnn->jn', sig_f)
+    dsw = np.einsum('jinn->jin', sig_w)
+    logl = expected_loglike(y_raw, variance, mu_f, mu_w, dsf, dsw)
+    return (logl + logp) / q
 
 
 # ----------------------------------------------------------- form "B"

@@ -396,6 +396,47 @@ def gen_multiconstant(tag='multiconstant'):
     print('%s: names=%s ELBO=%.12g iter=%d' % (tag, names, float(E), it))
 
 
+def gen_mcmc(tag='mcmc_N48_p1q1'):
+    """inference.mcmc (meanfield.py:1154-1286) under the deterministic emcee stand-in of tests/fake_emcee
+    (emcee itself is not installed anywhere here): the reference's chain, log-probabilities and ELBO blobs
+    for a seeded run.  Run as `python oracle/gen_golden.py mcmc` -- it needs the stand-in in front of
+    oracle/standins, which this function arranges by re-importing."""
+    import importlib
+    import scipy.stats as st
+    fake = os.path.join(REPO, 'tests', 'fake_emcee')
+    for name in [m for m in sys.modules if m == 'emcee' or m.startswith('emcee.')]:
+        del sys.modules[name]
+    sys.path.insert(0, fake)
+    import emcee
+    assert emcee.__version__.endswith('fake')
+    import gpyrn.meanfield as rm
+    rm.EnsembleSampler = emcee.EnsembleSampler          # the names meanfield.py imported at load time
+    rm.backends = emcee.backends
+    rm.sample_ellipsoid = emcee.utils.sample_ellipsoid
+    N, p, q = 48, 1, 1
+    spec = ([('QuasiPeriodic', [1.1, 40.0, 23.0, 0.8])], [('SquaredExponential', [0.9, 55.0])],
+            [('Constant', [0.2])], [0.45])
+    out = {'N': N, 'p': p, 'q': q, 'nodes': spec[0], 'weights': spec[1], 'means': spec[2], 'jitters': spec[3],
+           'seed': 2024, 'niter': 12, 'vars': ['node1.P', 'weight1.ell', 'jitter1']}
+
+    def priors():
+        return {'node1.P': st.uniform(15.0, 20.0), 'weight1.ell': st.uniform(30.0, 60.0),
+                'jitter1': st.uniform(0.05, 1.5)}
+    for label, p0 in (('prior_start', None), ('ellipsoid_start', [23.0, 55.0, 0.45])):
+        g, *_ = make_ref(N, p, q, spec)
+        np.random.seed(out['seed'])
+        sampler = g.mcmc(priors(), p0=p0, vars=list(out['vars']), niter=out['niter'])
+        out[label] = {'chain': sampler.get_chain().tolist(), 'log_prob': sampler.get_log_prob().tolist(),
+                      'blobs': sampler.get_blobs().tolist(), 'iteration': int(sampler.iteration),
+                      'tau': sampler.get_autocorr_time(tol=0).tolist(),
+                      'final_parameters': g.get_parameters(include_frozen=True).tolist(),
+                      'mask': g.frozen_mask.tolist()}
+    with open(os.path.join(OUT, tag + '.json'), 'w') as f:
+        json.dump(out, f, indent=1)
+    print('%s: %d iterations, last log-prob max %.10g' % (tag, out['prior_start']['iteration'],
+                                                        max(out['prior_start']['log_prob'][-1])))
+
+
 def gen_solar(tag='solar'):
     """The reference's data file gpyrn/datasets/Solar_observations.txt (header line 1, 13 columns): per-column
     sums and the first/last rows, for the loader test.  The values are data, read with numpy alone."""
@@ -452,6 +493,8 @@ if __name__ == '__main__':
         gen_multiconstant()
     if want('solar'):
         gen_solar()
+    if 'mcmc' in only:                  # swaps the emcee stand-in: only on request, and last
+        gen_mcmc()
     if big:
         # trajectories at the BASELINE configs (cfg 3: ~21 reference sweeps of ~35 s) and one reference-form
         # sweep each at N = 8192 and N = 16384 (7.2.N^3 flop: minutes to tens of minutes, ~30 GB)

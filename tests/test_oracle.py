@@ -76,3 +76,71 @@ def test_prediction(tag):
     np.testing.assert_allclose(wP, g['weight_means'], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(mean, g['mean'], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(var, g['var'], rtol=1e-6, atol=1e-9)
+
+
+def test_elbo_calc_trajectory_at_config_2():
+    """BASELINE config 2 (N = 2048, p = q = 1): the B-form oracle against the reference's own ELBOcalc
+    (every ELBOaux value, the stop rule's trip count, the converged means) -- the same fixture pins the HIP
+    path on the GPU (tests/test_parity_gpu.py); config 3's takes minutes per sweep on a CPU and is pinned there only."""
+    from gpyrn_amd import synth
+    meta, d = _cases.load('traj_cfg2_N2048')
+    t, ys, es = synth.rv_series(meta['N'], meta['p'], meta['seed'])
+    nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+    y = np.array(ys)
+    Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, y)
+    mu0, var0 = cpu_ref.init_mu_var(y, [n.pars[0] for n in nodes], [w.pars[0] for w in weights], jit)
+    E, mu, var, it, hist = cpu_ref.elbo_calc(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu0, var0, form='B')
+    assert it == int(d['calc_iter'])
+    np.testing.assert_allclose(hist, d['calc_elbo_array'], rtol=1e-8)
+    np.testing.assert_allclose(mu, d['calc_mu'], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('tag', ['step_p3q2', 'step_p2q3'])
+def test_gradient_formula_against_finite_differences(tag):
+    """The closed form behind inference.grad_ELBO (1/(2q) <K^-1 S K^-1 + a a^T - K^-1, dK/dtheta> per kernel,
+    the jitter derivative of the likelihood term, zero for the means) with NumPy in place of the GPU's
+    gprn_grad_matrices, against central differences of the oracle's ELBO at a fixed variational state."""
+    import gpyrn_amd as gpyrn
+    meta, d, nodes, weights, jit, args = _problem(tag)
+    means = _cases.components(meta, covfunc, meanfunc)[2]
+    g = gpyrn.inference.__new__(gpyrn.inference)          # the container only: no device is touched
+    gpyrn.inference.__init__(g, meta['q'], np.array(d['time']), *_cases.data_args(d))
+    g.set_components(nodes, weights, means, jit)
+    jit = list(g.jitters)
+    E, mu_n, var_n, parts, sig_f, sig_w = cpu_ref.sweep_ref(*args, d['mu_init'], d['var_init'], return_sigma=True)
+    q, p, N = meta['q'], meta['p'], meta['N']
+    Kf, Kw = args[0], args[1]
+
+    def matrices(gp):
+        if gp < q:
+            K, S = Kf[gp], sig_f[:gp + 1].sum(axis=0)
+        else:
+            jj, ii = divmod(gp - q, p)
+            K, S = Kw[gp - q], sig_w[jj, ii]
+        Kinv = np.linalg.inv(K)
+        return Kinv, Kinv @ S @ Kinv
+    grad = np.array(g._grad_from_state(nodes, weights, means, jit, mu_n, var_n, matrices))
+    t = np.asarray(d['time'], dtype=float)
+
+    def F():
+        Kf_, Kw_, _, _, _, j2_ = cpu_ref.setup(t, nodes, weights, means, jit, d['y'])
+        return cpu_ref.fixed_state_elbo(Kf_, Kw_, d['y'], d['yerr']**2, j2_, mu_n[0], mu_n[1:], sig_f, sig_w)
+    fd = []
+    for k in list(nodes) + list(weights):
+        for i in range(k.pars.size):
+            v = k.pars[i]
+            h = 1e-5 * max(1.0, abs(v))
+            k.pars[i] = v + h; up = F()
+            k.pars[i] = v - h; dn = F()
+            k.pars[i] = v
+            fd.append((up - dn) / (2 * h))
+    fd += [0.0] * sum(0 if m is None else int(m._parsize) for m in means)
+    for i in range(len(jit)):
+        v = jit[i]
+        h = 1e-5 * max(1.0, abs(v))
+        jit[i] = v + h; up = F()
+        jit[i] = v - h; dn = F()
+        jit[i] = v
+        fd.append((up - dn) / (2 * h))
+    fd = np.array(fd)
+    np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=1e-6 * np.abs(fd).max())

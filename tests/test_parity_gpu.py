@@ -509,3 +509,139 @@ def test_multiconstant_model_matches_reference():
     np.testing.assert_allclose(E, float(d['calc_elbo']), rtol=RTOL)
     np.testing.assert_allclose(mu, d['calc_mu'], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(var, d['calc_var'], rtol=1e-6, atol=1e-12)
+
+
+def test_mcmc_matches_reference_chain(monkeypatch, tmp_path):
+    """inference.mcmc (meanfield.py:1154-1286) against the reference's own run under the same deterministic
+    emcee stand-in (tests/fake_emcee; emcee is not installed here): walkers drawn from the priors, the
+    evaluation of the initial walkers (which moves the warm-start state), every stretch move with its
+    warm-started, 100-sweep-capped ELBO -- chain, log-probabilities and ELBO blobs number by number."""
+    import sys
+    import scipy.stats as st
+    with open(os.path.join(_cases.GOLDEN, 'mcmc_N48_p1q1.json')) as f:
+        ref = json.load(f)
+    fake = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fake_emcee')
+    for name in [m for m in sys.modules if m == 'emcee' or m.startswith('emcee.')]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.syspath_prepend(fake)
+    monkeypatch.chdir(tmp_path)                      # (a real emcee would write gprn.h5 here)
+    t, ys, es = synth.rv_series(ref['N'], ref['p'])
+
+    def priors():
+        return {'node1.P': st.uniform(15.0, 20.0), 'weight1.ell': st.uniform(30.0, 60.0),
+                'jitter1': st.uniform(0.05, 1.5)}
+    for label, p0 in (('prior_start', None), ('ellipsoid_start', [23.0, 55.0, 0.45])):
+        nodes, weights, means, jit = _cases.components(ref, covfunc, meanfunc)
+        g = gpyrn.inference(ref['q'], t, ys[0], es[0])
+        g.set_components(nodes, weights, means, jit)
+        np.random.seed(ref['seed'])
+        sampler = g.mcmc(priors(), p0=p0, vars=list(ref['vars']), niter=ref['niter'])
+        want = ref[label]
+        assert sampler.iteration == want['iteration'] and g.frozen_mask.tolist() == want['mask']
+        np.testing.assert_allclose(sampler.get_chain(), want['chain'], rtol=1e-9)
+        np.testing.assert_allclose(sampler.get_blobs(), want['blobs'], rtol=RTOL)       # the ELBO of every walker
+        np.testing.assert_allclose(sampler.get_log_prob(), want['log_prob'], rtol=RTOL)
+        np.testing.assert_allclose(g.get_parameters(include_frozen=True), want['final_parameters'], rtol=1e-9)
+
+
+def test_kmatrix_and_tiny_nugget_on_device():
+    """inference._KMatrix / _tinyNuggetKMatrix (meanfield.py:413-452) called on their own: one fused fill,
+    no factorisation, no second context."""
+    meta, d, g = _model('step_p3q2')
+    t = np.asarray(g.time)
+    r = t[:, None] - t[None, :]
+    for k in (covfunc.QuasiPeriodic(1.1, 30.0, 12.5, 0.6), covfunc.SquaredExponential(0.9, 7.0) * covfunc.Periodic(1.0, 9.0, 0.8)):
+        np.testing.assert_allclose(g._KMatrix(k), k(r) + 1e-6 * np.eye(t.size), rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(g._tinyNuggetKMatrix(k), k(r) + 1.25e-12 * np.eye(t.size), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(g._KMatrix(g.nodes[0]), d['Kf'][0], rtol=1e-12, atol=1e-13)
+    two = covfunc.Polynomial(1.0, 0.01, 1.5, 2.0)                       # two-argument kernel: no nugget
+    np.testing.assert_allclose(g._KMatrix(two), two(t[:, None], t[None, :]), rtol=1e-12)
+
+
+def test_sample_draws_from_the_prior():
+    """inference.sample (meanfield.py:517-539).  The reference draws through scipy's multivariate_normal, so
+    the numbers cannot be compared; the construction can: with the generator re-seeded, every draw must be
+    L z for the z NumPy hands out and a Cholesky factor L of the kernel matrix the reference would use."""
+    meta, d, g = _model('mid_N300_p3q2')
+    t = np.asarray(g.time)
+    N, q, qp = t.size, g.q, g.q * g.p
+    np.random.seed(11)
+    fs, ws = g.sample()
+    assert fs.shape == (q, N) and ws.shape == (qp, N)
+    np.random.seed(11)
+    zs = [np.random.standard_normal(N) for _ in range(q + qp)]
+    for draw, z, k in zip(list(fs) + list(ws), zs, list(g.nodes) + list(g.weights)):
+        r = t[:, None] - t[None, :]
+        K = k(r)
+        for nug in (1.25e-12, 1.25e-10, 1.25e-8, 1.25e-6):
+            try:
+                L = np.linalg.cholesky(K + nug * np.eye(N))
+            except np.linalg.LinAlgError:
+                continue
+            if np.allclose(L @ z, draw, rtol=1e-6, atol=1e-6 * np.abs(draw).max()):
+                break
+        else:
+            raise AssertionError('draw is not L z for any admissible nugget')
+    # second moment: many draws of one smooth GP have the prior's variance on the diagonal
+    np.random.seed(3)
+    k = covfunc.SquaredExponential(1.3, 20.0)
+    draws = np.array([g._sample_from_gp(k) for _ in range(400)])
+    assert abs(draws.var() / 1.3**2 - 1.0) < 0.15
+
+
+# ------------------------------------------------ analytic gradient (SURVEY 8f-3; an extension, not parity)
+@pytest.mark.parametrize('tag', ['step_p3q2', 'cfg1_N200', 'mid_N300_p3q2'])
+def test_grad_elbo_against_finite_differences(tag):
+    """inference.grad_ELBO: the N^3 part on the GPU, against central differences of the oracle's ELBO at the
+    same FIXED variational state (oracle/cpu_ref.fixed_state_elbo), parameter by parameter: kernel
+    hyper-parameters of every node and weight (quirks Q1/Q2 included), mean parameters (zero, quirk Q3),
+    jitters."""
+    meta, d, g = _model(tag)
+    g.ELBOcalc()
+    mu_prev, var_prev = g._mu.copy(), g._var.copy()
+    E, grad = g.grad_ELBO()
+    assert grad.shape == (len(g.get_parameters(include_frozen=True)),)
+    # the same extra sweep through the oracle, with explicit covariances
+    t = np.asarray(g.time, dtype=float)
+    nodes, weights, means, jit = g.nodes, g.weights, g.means, list(g.jitters)
+    Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, g.y)
+    E_ref, mu_n, var_n, parts, sig_f, sig_w = cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, g.y, g.yerr2, j2,
+                                                               mu_prev, var_prev, return_sigma=True)
+    np.testing.assert_allclose(E, E_ref, rtol=RTOL)
+    mu_f, mu_w = mu_n[0], mu_n[1:]
+
+    def F():
+        Kf_, Kw_, _, _, _, j2_ = cpu_ref.setup(t, nodes, weights, means, jit, g.y)
+        return cpu_ref.fixed_state_elbo(Kf_, Kw_, g.y, g.yerr2, j2_, mu_f, mu_w, sig_f, sig_w)
+
+    fd = []
+    for k in list(nodes) + list(weights):
+        for i in range(k.pars.size):
+            v = k.pars[i]
+            h = 1e-5 * max(1.0, abs(v))
+            k.pars[i] = v + h; up = F()
+            k.pars[i] = v - h; dn = F()
+            k.pars[i] = v
+            fd.append((up - dn) / (2 * h))
+    fd += [0.0] * sum(0 if m is None else int(m._parsize) for m in means)
+    for i in range(len(jit)):
+        v = jit[i]
+        h = 1e-5 * max(1.0, abs(v))
+        jit[i] = v + h; up = F()
+        jit[i] = v - h; dn = F()
+        jit[i] = v
+        fd.append((up - dn) / (2 * h))
+    fd = np.array(fd)
+    scale = np.abs(fd).max()
+    np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=1e-6 * scale)
+
+
+def test_optimize_with_analytic_gradient():
+    """optimize(method='L-BFGS-B', jac=True): runs on the analytic gradient and does not do worse than where
+    it started; the gradient of the frozen parameters never reaches scipy."""
+    meta, d, g = _model('cfg1_N200')
+    before = g.ELBOcalc()[0]
+    g.freeze_parameter(name='mean*')
+    res = g.optimize(method='L-BFGS-B', jac=True, options={'maxiter': 4})
+    assert res.jac.shape == g.get_parameters().shape
+    assert -res.fun >= before - 1e-6 * abs(before)
