@@ -53,17 +53,25 @@ template <int BM, int BN, int NW, int TRI, int TAG>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                 const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out)
+                 const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map)
 {
     await_flag(wait_flag, wait_value, wait_timed_out);
     constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
     __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
 
-    const TileTask t = tasks[blockIdx.x / (SM * SN)];
-    const int sub = blockIdx.x % (SM * SN), sr = sub / SN, sc = sub % SN;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in dispatch order, so
+    // neighbours in the grid never share an L2.  Re-map: XCD x takes one contiguous eighth of the (task,
+    // sub-tile, matrix) list -- tasks that share the operand panel L[i, k0:k1] and the sub-tiles of one
+    // task then meet in one L2 (placement is a speed matter only: any mapping is a bijection).
+    const unsigned gx = gridDim.x, nblk = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    const unsigned n8 = nblk & ~7u;
+    const unsigned lb = (xcd_map && lin < n8) ? (lin & 7u) * (n8 >> 3) + (lin >> 3) : lin;
+    const unsigned bx = lb % gx, by = lb / gx;
+    const TileTask t = tasks[bx / (SM * SN)];
+    const int sub = bx % (SM * SN), sr = sub / SN, sc = sub % SN;
     // the slot's four buffer pointers in one scalar load, side by side with the task (no load depends on it)
-    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    double* const* gp = ptrs + (size_t)by * GPRN_NBUF;
     double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
     auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
     const int c_mode = t.modes & 3;
@@ -78,6 +86,13 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
+static int xcd_map()                               // GPRN_XCD_MAP=0: grid order as dispatched (experiments)
+{
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GPRN_XCD_MAP"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 template <int BM, int BN, int TRI, int TAG>
 static void launch_one(const TileTask* d_tasks, size_t ntasks, double* const* tab, int nbatch, int ld,
                        size_t dyn, hipStream_t stream, const Signal& sig, const Await& aw)
@@ -86,7 +101,7 @@ static void launch_one(const TileTask* d_tasks, size_t ntasks, double* const* ta
     constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
-                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map());
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
