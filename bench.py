@@ -54,12 +54,12 @@ def update_flops(T, n_gp, outer=4):
             per_gp += k0 * 2.0 * TILE * TILE * kw                  # R_ic, c < k0
             for c in range(k0, k1):
                 per_gp += 2.0 * TILE * TILE * (k1 - c) * TILE      # R_ic, first touch
-        # tiles (n1,n1) and (n1+1,n1) are not part of "rest": the next panel's steps start on them early,
-        # so they go with the next-panel launch (csrc/factor.hip, ensure_tasks)
-        if n1 < T:
+        # the diagonal and sub-diagonal tiles of the panel after next are not part of "rest": the next
+        # panel's steps start on them early, so they go with the next-panel launch (csrc/factor.hip, ensure_tasks)
+        for j in range(n1, min(T, n1 + outer)):
             per_gp -= 2.0 * (TILE * (TILE + 1) / 2) * kw
-        if n1 + 1 < T:
-            per_gp -= 2.0 * TILE * TILE * kw
+            if j + 1 < T:
+                per_gp -= 2.0 * TILE * TILE * kw
     return per_gp * n_gp
 
 

@@ -419,7 +419,6 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
 //   raises  F_DIAG(k)   when L_kk, X_kk are in memory   (stream3 starts the panel of step k)
 //           F_MINIL(k)  when L_{k+1,k} is                (stream3's in-panel updates of step k)
 //   waits   F_INNER(k-1) before it reads B_{k+1,k}, B_{k+1,k+1}  (stream3's in-panel update of step k-1)
-//           F_FIRST(J)  before B_{k+1,k+1} at the first step of panel J+1 (its K = width-of-panel update)
 // flags: (step or panel) * kinds * 2 + kind * 2 + 1 words into `sig`; a flag is up when it holds >= epoch.
 #define CHAIN_MMA_DOUBLES (2 * 16 * (128 + 128 + 32))
 #define CHAIN_LDS_DOUBLES (CHAIN_MMA_DOUBLES > DIAG_LDS_DOUBLES ? CHAIN_MMA_DOUBLES : DIAG_LDS_DOUBLES)
@@ -472,9 +471,8 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
         STAMP(4);
         chain_publish(flag(k, f_minil), epoch);
         STAMP(5);
-        // B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T (lower blocks); at a panel boundary it first takes the
-        // previous panel's outer update
-        if ((k + 1) % outer == 0) await_flag(flag((k + 1) / outer - 1, f_first), epoch, timed_out);
+        // B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T (lower blocks); like every tile the chain touches it is kept
+        // up to date by the in-panel updates alone (ensure_tasks), so there is nothing else to wait for
         tile_mma<128, 128, 4, 1, 0, true>(lds, Bm + sub, Bm + sub, (gptr_t)(Bm + sub + GPRN_TILE), ld, 0, 0,
                                            CM_SUB, GPRN_TILE, 0, 0);
         STAMP(6);
@@ -557,11 +555,11 @@ int ensure_tasks(gprn_ctx* c)
                                      BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)});
             s.npanel = v.size() - s.panel0;
             s.upd0 = v.size();
-            // columns of the panel right of step k; and of the NEXT panel's first column the two tiles the
-            // chain starts that panel with, (k1,k1) and (k1+1,k1): kept up to date step by step so that no
-            // K = 512 update of them stands between the last step of this panel and the first of the next
-            for (int j = k + 1; j <= k1 && j < T; ++j)
-                for (int i = j; i < (j < k1 ? T : std::min(T, k1 + 2)); ++i)
+            // columns of the panel right of step k; and of the NEXT panel its diagonal and sub-diagonal tiles
+            // (j,j), (j+1,j), k1 <= j < n1 -- the tiles the chain works on there: kept up to date step by
+            // step (K = 128), so that the chain never waits for a K = 512 update of the outer panel
+            for (int j = k + 1; j < std::min(T, k1 + outer); ++j)
+                for (int i = j; i < (j < k1 ? T : std::min(T, j + 2)); ++i)
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
                                          BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
             for (int i = k + 1; i < k1; ++i)
@@ -574,19 +572,18 @@ int ensure_tasks(gprn_ctx* c)
         gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
-        // pass 0 ("first"): the next panel's first column of B / first row of R -- what its first
-        // tile step needs -- and, in the split schedule, the next panel's diagonal and sub-diagonal
-        // tiles (the chain stream owns those); pass 1 ("next"): the rest of the next panel's
-        // columns / rows; pass 2 ("rest"): everything beyond.
-        // Tiles (k1,k1) and (k1+1,k1) are not touched here at all: the steps of this panel have brought
-        // them up to date already (see the in-panel lists).  The same two tiles of the panel after next,
-        // (n1,n1) and (n1+1,n1), belong to "next" rather than "rest": the next panel's steps start
-        // updating them as soon as "next" is done, while "rest" may still be running.
-        const bool split = split_sched();
+        // pass 0 ("first"): the next panel's first column of B / first row of R -- what stream3's half of
+        // its first tile step needs; pass 1 ("next"): the rest of the next panel's columns / rows;
+        // pass 2 ("rest"): everything beyond.
+        // The next panel's diagonal and sub-diagonal tiles are not touched here at all: the steps of this
+        // panel have brought them up to date already (see the in-panel lists).  The same tiles of the panel
+        // after next belong to "next" rather than "rest": the next panel's steps start updating them as soon
+        // as "next" is done, while "rest" may still be running.
+        const int n2 = std::min(T, n1 + outer);
         auto clsB = [&](int i, int j) {
-            if (j == k1 && i <= k1 + 1) return -2;
-            if (j == k1 || (split && j < n1 && i <= j + 1)) return 0;
-            if (j < n1 || (j == n1 && i <= n1 + 1)) return 1;
+            if (j < n1 && i <= j + 1) return -2;
+            if (j == k1) return 0;
+            if (j < n1 || (j < n2 && i <= j + 1)) return 1;
             return 2;
         };
         auto clsR = [&](int i) { return i == k1 ? 0 : (i < n1 ? 1 : 2); };
@@ -861,10 +858,6 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL),
                             spin ? in_kernel_wait(k - 1, F_INNER) : noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
-            if (first_J >= 0) {                        // B_{k+1,k+1} carries the previous panel's update
-                HIP_TRY(c, await(s0, first_J, F_FIRST));
-                first_J = -1;
-            }
             if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
             if ((rc = side_sync(k))) return rc;

@@ -61,12 +61,15 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
 
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2) in dispatch order, so
-    // neighbours in the grid never share an L2.  Re-map: XCD x takes one contiguous eighth of the (task,
-    // sub-tile, matrix) list -- tasks that share the operand panel L[i, k0:k1] and the sub-tiles of one
-    // task then meet in one L2 (placement is a speed matter only: any mapping is a bijection).
+    // neighbours in the grid never share an L2.  Re-map in chunks of 16: the workgroup an XCD receives as its
+    // c-th takes position c % 16 of chunk (c / 16) * 8 + x of the (task, sub-tile, matrix) list -- 16 consecutive
+    // entries (the sub-tiles of a task, tasks that share the operand panel L[i, k0:k1]) meet in one L2, and the
+    // chunks of the list still go round the XCDs, so its short-to-long ordering loads them evenly (one
+    // contiguous eighth per XCD measured -25 % fabric traffic but +6 % time).  Placement is a speed matter
+    // only: any bijection is correct.
     const unsigned gx = gridDim.x, nblk = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-    const unsigned n8 = nblk & ~7u;
-    const unsigned lb = (xcd_map && lin < n8) ? (lin & 7u) * (n8 >> 3) + (lin >> 3) : lin;
+    const unsigned n128 = nblk & ~127u, cx = lin >> 3;
+    const unsigned lb = (xcd_map && lin < n128) ? ((((cx >> 4) << 3) + (lin & 7u)) << 4) + (cx & 15u) : lin;
     const unsigned bx = lb % gx, by = lb / gx;
     const TileTask t = tasks[bx / (SM * SN)];
     const int sub = bx % (SM * SN), sr = sub / SN, sc = sub % SN;

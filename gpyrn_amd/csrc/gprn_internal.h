@@ -239,9 +239,16 @@ __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value, cons
                                             unsigned then_value, unsigned* timed_out)
 {
     if (!slot) return;                              // uniform
+    // every wave's stores have left the CU (s_barrier waits for no counter), then one release for the
+    // workgroup -- a release only: the consumer does its own acquire, and __threadfence() would add an L1/L2
+    // invalidate (about as long again) to every kernel of the chain
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (value) __threadfence();                 // this workgroup's writes, agent scope
+        if (value) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         const unsigned total = gridDim.x * gridDim.y * gridDim.z;
         if (atomicAdd(slot, 1u) + 1 == total) {
             atomicExch(slot, 0u);
