@@ -619,8 +619,10 @@ int ensure_tasks(gprn_ctx* c)
     }
     }   // set
     // lower(X^T X) -> BUF_B: tile (a,b), a >= b, sums over rows a*128 .. ld of X
+    // (short contractions first: a launch of these runs beside the next phase's factorisation, whose diagonal
+    // block needs a whole free CU -- the CUs that got the short tasks come free within tens of microseconds)
     c->lauum0 = v.size();
-    for (int a = 0; a < T; ++a)
+    for (int a = T - 1; a >= 0; --a)
         for (int b = 0; b <= a; ++b)
             v.push_back(TileTask{toff(a, b, ld), toff(a, a, ld), toff(a, b, ld), ld - a * GPRN_TILE,
                                  BUF_B, BUF_X, BUF_X, tile_modes(CM_SET, 1, 1)});
@@ -809,7 +811,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if ((rc = f())) return rc;
         }
     }
-    if (!use_chain && c->chain_started) {              // launch schedule: nothing to wait for
+    if (!use_chain && !use_flags && c->chain_started) {    // event schedule: nothing to gate it on
         std::function<int()> f;
         f.swap(c->chain_started);
         if ((rc = f())) return rc;
@@ -844,6 +846,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             //   stream3: the other panel tiles, then the other in-panel updates of the step
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG)))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
+            if (use_flags && k == 0 && c->chain_started) {
+                // work handed over by the caller for the bulk stream (run_phase: the previous phase's X^T X
+                // product, 528 long-running workgroups) goes behind the FIRST diagonal block: launched before
+                // it, it holds every CU and the block waits for one to drain (211 us instead of 50 measured)
+                HIP_TRY(c, await(s2, 0, F_DIAG));
+                std::function<int()> f;
+                f.swap(c->chain_started);
+                if ((rc = f())) return rc;
+            }
             if (s.npanel_l == 0) {
                 // last tile step of the matrix: row k of the inverse is all that is left
                 if ((rc = flush_inner())) return rc;
