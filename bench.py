@@ -181,6 +181,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     a.gpus = world
+    if os.environ.get('GPRN_BENCH_LAUNCH_PROBE'):
+        # tests/test_sharding.py: what a rank sees, without touching a GPU
+        if rank == 0:
+            print(json.dumps({'probe': True, 'world': world, 'rank': rank,
+                              'env': {k: os.environ.get(k) for k in ('LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                                     'GPRN_LAUNCH_TAG')}}), flush=True)
+        sys.exit(int(os.environ.get('GPRN_BENCH_PROBE_FAIL_RANK', -1)) == rank)
     N, p, q, kind = synth.CONFIGS[a.config]
     if a.shape:
         N, p, q = (int(x) for x in a.shape.split(','))

@@ -53,6 +53,7 @@ static void prof_collect(gprn_ctx* c)
     hipStreamSynchronize(c->stream);
     hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream3);
+    if (c->stream4) hipStreamSynchronize(c->stream4);
     for (auto& r : c->prof.pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -115,6 +116,7 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body)
     int rc = body(false);
     if (rc != GPRN_E_WAIT_TIMEOUT) return rc;
     hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->stream3);
+    if (c->stream4) hipStreamSynchronize(c->stream4);
     c->use_flags = 0;
     c->fallbacks += 1;
     fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms; re-running the call with "
@@ -137,6 +139,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
+    else if (!strcmp(name, "chain_streams")) { if (old) *old = factor_probe_streams(c); return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
     if (value >= 0) {
@@ -205,6 +208,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_diag, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_first, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_minil, hipEventDisableTiming) != hipSuccess ||
@@ -242,6 +246,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
     hipEventDestroy(c->ev_minil);
     hipEventDestroy(c->ev_inner);
     hipStreamDestroy(c->stream3);
+    if (c->stream4) { hipStreamSynchronize(c->stream4); hipStreamDestroy(c->stream4); }
     hipEventDestroy(c->ev_panel);
     hipEventDestroy(c->ev_rest);
     hipEventDestroy(c->ev_next);

@@ -399,9 +399,11 @@ __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, g
 
 __global__ __launch_bounds__(256)
 void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info,
-                  unsigned* sig_slot, unsigned sig_value)
+                  unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
+                  unsigned* wait_timed_out)
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    await_flag(wait_flag, wait_value, wait_timed_out);
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     diag_tile(lds, (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off),
@@ -485,12 +487,12 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
-                Signal sig)
+                Signal sig, Await aw)
 {
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
     hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, stream,
-                       (double* const*)d_ptrs, ld, kblk, d_info, sig.slot, sig.value);
+                       (double* const*)d_ptrs, ld, kblk, d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -652,13 +654,42 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
     if (wait_flag) spin_until(wait_flag, wait_value, timed_out);
 }
 
-#define GPRN_FLAG_KINDS 8           // flag kinds per tile step / outer panel (factor_invert_split)
+#define GPRN_FLAG_KINDS 9           // flag kinds per tile step / outer panel (factor_invert_split)
 
 // Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
 // beside them: every switch that serialises kernels or starves the hardware queues means events.
 //   rocprofv3 --pmc (ROCPROF_COUNTER_COLLECTION=1), AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING,
 //   GPU_MAX_HW_QUEUES < 4 (three streams of this context + the null stream), no stream memory operations.
 // GPRN_FLAGS=0/1 overrides; gprn_set_option(ctx, "flags", v) sets it per context; a time-out latches 0.
+__global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const unsigned* wait_flag,
+                            unsigned wait_value, unsigned* timed_out);
+
+// Do kernels of the chain stream and of stream4 run side by side?  With too few hardware queues the runtime
+// folds two streams onto one, and a kernel that waits in-kernel for a later launch of the "other" stream would
+// never see it start.  Tried once per context: a kernel on stream4 waits (20 ms at most) for a flag that a
+// kernel launched AFTER it on the chain stream raises.
+int factor_probe_streams(gprn_ctx* c)
+{
+    if (c->chain_streams >= 0) return c->chain_streams;
+    c->chain_streams = 0;
+    if (!c->stream4) return 0;
+    unsigned* w = nullptr;                         // [0] flag, [2] time-out word, [3] budget in 100 MHz ticks
+    if (hipMalloc(&w, 4 * sizeof(unsigned)) != hipSuccess) return 0;
+    const unsigned init[4] = {0u, 0u, 0u, 2000000u};
+    bool ok = hipMemcpy(w, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, c->stream4, (unsigned*)nullptr, 0u,
+                           (const unsigned*)w, 1u, w + 2);
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, c->stream, w, 1u, (const unsigned*)nullptr, 0u, w + 2);
+        ok = hipStreamSynchronize(c->stream4) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+    }
+    unsigned out[4] = {0, 0, 1, 0};
+    if (ok) ok = hipMemcpy(out, w, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess;
+    hipFree(w);
+    c->chain_streams = (ok && out[0] == 1u && out[2] == 0u) ? 1 : 0;
+    return c->chain_streams;
+}
+
 int factor_use_flags(gprn_ctx* c)
 {
     if (c->use_flags >= 0) return c->use_flags;
@@ -706,7 +737,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     const int use_flags = factor_use_flags(c);
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_KINDS };
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
@@ -724,7 +755,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         c->sig_budget_ms = c->wait_budget_ms;
     }
     const unsigned epoch = ++c->epoch;
-    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr};
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr, nullptr};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
@@ -740,7 +771,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // the chain's L_{k+1,k} launch (2 workgroups per matrix) waits for stream3's flag itself: the
     // stream wait is a 5 us kernel of its own on this runtime (__amd_rocclr_streamOpsWait)
     auto in_kernel_wait = [&](int idx, int kind) {
-        return Await{slot(idx, kind) + 1, epoch, c->d_sig + (size_t)c->sig_T * F_KINDS * 2};
+        return Await{slot(idx, kind) + 1, epoch, c->d_sig + (size_t)c->sig_T * F_KINDS * 2, nullptr, 0};
     };
     auto await = [&](hipStream_t st, int idx, int kind) {
         return use_flags ? hipStreamWaitValue32(st, slot(idx, kind) + 1, epoch, hipStreamWaitValueGte, 0xffffffffu)
@@ -811,6 +842,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if ((rc = f())) return rc;
         }
     }
+    // GPRN_CHAIN_STREAMS=1: the chain on two streams when the runtime runs them side by side (measured: no gain,
+    // 96.7 vs 97.3 sweeps/s at config 3 -- what a chain kernel costs beyond its arithmetic is inside it, fences
+    // and operand latency, not its dispatch); default: one stream
+    static int cs_env = -1;
+    if (cs_env < 0) { const char* e = getenv("GPRN_CHAIN_STREAMS"); cs_env = e ? atoi(e) : 0; }
+    const bool two_streams = use_flags && !use_chain && cs_env && factor_probe_streams(c) == 1;
     if (!use_chain && !use_flags && c->chain_started) {    // event schedule: nothing to gate it on
         std::function<int()> f;
         f.swap(c->chain_started);
@@ -844,7 +881,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // next panel starts with are updated step by step, see ensure_tasks):
             //   chain  : diag(k)  ->  L_{k+1,k}  ->  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T
             //   stream3: the other panel tiles, then the other in-panel updates of the step
-            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG)))) return rc;
+            // two_streams: the diagonal blocks on the chain stream, the step's two tile launches on stream4, every
+            // kernel waiting in-kernel for the flag of the one before it in the chain -- so each is dispatched
+            // (arguments, task and pointer loads done, workgroups resident) while its predecessor still runs,
+            // instead of after its completion has travelled through the stream
+            const Await after_u = (two_streams && k > 0) ? in_kernel_wait(k - 1, F_U) : noaw;
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), after_u))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             if (use_flags && k == 0 && c->chain_started) {
                 // work handed over by the caller for the bulk stream (run_phase: the previous phase's X^T X
@@ -866,10 +908,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // two workgroups per matrix poll that flag themselves (a stream wait is a 5 us kernel of its own)
             const bool spin = use_flags && k > 0;
             if (k > 0 && !spin) HIP_TRY(c, await(s0, k - 1, F_INNER));
-            if ((rc = tiles(s.panel0, 1, s0, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL),
-                            spin ? in_kernel_wait(k - 1, F_INNER) : noaw))) return rc;
+            Await l_waits = spin ? in_kernel_wait(k - 1, F_INNER) : noaw;
+            if (two_streams) {
+                if (spin) { l_waits.flag2 = slot(k, F_DIAG) + 1; l_waits.value2 = epoch; }
+                else l_waits = in_kernel_wait(k, F_DIAG);
+            }
+            hipStream_t sc = two_streams ? c->stream4 : s0;
+            if ((rc = tiles(s.panel0, 1, sc, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), l_waits))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
-            if ((rc = tiles(s.upd0, 1, s0, TS_64x64))) return rc;
+            if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
             if ((rc = side_sync(k))) return rc;
             if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;

@@ -53,9 +53,10 @@ template <int BM, int BN, int NW, int TRI, int TAG>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                 const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map)
+                 const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map,
+                 const unsigned* wait_flag2, unsigned wait_value2)
 {
-    await_flag(wait_flag, wait_value, wait_timed_out);
+    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
     constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
     __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
@@ -104,7 +105,8 @@ static void launch_one(const TileTask* d_tasks, size_t ntasks, double* const* ta
     constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
-                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map());
+                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map(),
+                       aw.flag2, aw.value2);
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
@@ -117,6 +119,7 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
         // the workgroups", and flags never go down) is written from the stream.  Signals and waits exist in
         // the flag schedule only, which requires stream memory operations (factor_use_flags).
         if (aw.flag) HIP_TRY(c, hipStreamWaitValue32(stream, (void*)aw.flag, aw.value, hipStreamWaitValueGte, 0xffffffffu));
+        if (aw.flag2) HIP_TRY(c, hipStreamWaitValue32(stream, (void*)aw.flag2, aw.value2, hipStreamWaitValueGte, 0xffffffffu));
         if (sig.slot && sig.value) HIP_TRY(c, hipStreamWriteValue32(stream, sig.slot + 1, sig.value, 0));
         if (sig.slot && sig.then_wait)
             HIP_TRY(c, hipStreamWaitValue32(stream, (void*)sig.then_wait, sig.then_value, hipStreamWaitValueGte, 0xffffffffu));

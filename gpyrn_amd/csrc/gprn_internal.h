@@ -74,6 +74,9 @@ struct gprn_ctx {
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
     hipStream_t stream3 = nullptr;   // in-panel work that is off the chain (panel rest, inner rest)
+    hipStream_t stream4 = nullptr;   // the chain's two tile launches of a step, dispatched ahead of their inputs
+    int chain_streams = -1;          // 1: the chain runs on two streams (diagonal blocks | tile launches) whose
+                                     // kernels wait for each other in-kernel; 0: one stream; -1: not probed yet
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
     hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
     hipStream_t prof_stream = nullptr;
@@ -193,13 +196,15 @@ struct Signal {
 // The other direction, for launches of a FEW workgroups only (a spinning launch that fills the GPU
 // could keep its own producer from being dispatched): every workgroup of the launch waits at its
 // start until *flag >= value; a wait that times out (about a second) sets *timed_out and goes on.
-struct Await { const unsigned* flag; unsigned value; unsigned* timed_out; };
+struct Await { const unsigned* flag; unsigned value; unsigned* timed_out;
+               const unsigned* flag2; unsigned value2; };       // optional second flag, same time-out word
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
                  Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},
                  int tag = TG_MISC);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
-                hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr});
+                hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
+                Await aw = Await{nullptr, 0, nullptr, nullptr, 0});
 
 #ifdef __HIPCC__
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
@@ -227,10 +232,14 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value,
 }
 
 // start of a kernel: every thread of the workgroup calls it
-__device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out)
+__device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out,
+                                           const unsigned* flag2 = nullptr, unsigned value2 = 0)
 {
-    if (!flag) return;                              // uniform
-    if (threadIdx.x == 0) spin_until(flag, value, timed_out);
+    if (!flag && !flag2) return;                    // uniform
+    if (threadIdx.x == 0) {
+        if (flag) spin_until(flag, value, timed_out);
+        if (flag2) spin_until(flag2, value2, timed_out);
+    }
     __syncthreads();
 }
 
@@ -266,3 +275,4 @@ int ensure_tasks(gprn_ctx* c);
 #define GPRN_E_WAIT_TIMEOUT (-100)
 int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel dependency wait timed out since the last check
 int factor_use_flags(gprn_ctx* c);
+int factor_probe_streams(gprn_ctx* c);

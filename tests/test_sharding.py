@@ -205,3 +205,41 @@ def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
         assert np.isneginf(out[1][1]) and np.isnan(out[2][1]) and out[4][1] == 2.0
     one = sharding.EvalPool(NoRendezvous(world=1, rank=0, local_rank=0))
     assert one.map(lambda x: x * 2.0, [1.0, 2.0]) == [2.0, 4.0]
+
+
+# ---------------------------------------------------------------- bench.py --gpus N without a launcher
+def _bench(args, extra_env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, cwd=root,
+                          capture_output=True, text=True, timeout=120)
+
+
+def test_bench_self_launch_starts_one_rank_per_gpu():
+    """`python bench.py --gpus 3` with no launcher around it: three child ranks, before any GPU call, and
+    exactly rank 0's line on stdout (the children answer from a probe hook, no GPU needed)."""
+    import json
+    r = _bench(['--gpus', '3'], {'GPRN_BENCH_LAUNCH_PROBE': '1'})
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['world'] == 3 and d['rank'] == 0 and d['env']['LOCAL_RANK'] == '0'
+    assert d['env']['MASTER_ADDR'] == '127.0.0.1' and d['env']['MASTER_PORT'] and d['env']['GPRN_LAUNCH_TAG']
+
+
+def test_bench_self_launch_reports_a_failed_rank():
+    r = _bench(['--gpus', '2'], {'GPRN_BENCH_LAUNCH_PROBE': '1', 'GPRN_BENCH_PROBE_FAIL_RANK': '1'})
+    assert r.returncode != 0 and 'rank(s) failed: 1' in r.stderr
+
+
+def test_bench_respects_an_outer_launcher():
+    """With WORLD_SIZE set by a launcher (torch.distributed.run), bench.py is one rank and starts nothing."""
+    import json
+    r = _bench(['--gpus', '4'], {'GPRN_BENCH_LAUNCH_PROBE': '1', 'WORLD_SIZE': '4', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip())
+    assert d['world'] == 4 and d['env']['GPRN_LAUNCH_TAG'] is None
