@@ -73,7 +73,7 @@ class Comm:
     launcher's pid, or GPRN_LAUNCH_TAG when the launcher sets it), the rendezvous port, the world size
     and a per-process generation count.  Rank 0 removes anything stale under that name, creates the file
     with O_EXCL and mode 0600 and renames it into place; the other ranks accept only a 128-byte file
-    of their own user written after they started.  ``done()`` removes it once the communicator exists.
+    of their own user that is at most minutes older than their own start.  ``done()`` removes it once the communicator exists.
     """
 
     def __init__(self, world=None, rank=None, local_rank=None, tag=None):
@@ -119,7 +119,9 @@ class Comm:
             while True:
                 try:
                     st = os.stat(path)
-                    fresh = st.st_mtime >= _START - 2.0
+                    # written during this launch: the ranks of one launch start within seconds of each other, a
+                    # left-over of an earlier launch under the same name (same launcher pid, port, world) is far older
+                    fresh = st.st_mtime >= _START - 600.0
                     if st.st_uid == os.getuid() and not (st.st_mode & 0o077) and st.st_size == 128 and fresh:
                         with open(path, 'rb') as f:
                             data = f.read()
