@@ -257,8 +257,11 @@ __device__ __forceinline__ v4d get16(const double* __restrict__ T)
 
 // potrf + inverse of the 128x128 tile at Bt (-> L, lower) with X = L^-1 -> Xt; `lds`: DIAG_LDS_DOUBLES doubles.
 // All 256 threads of the workgroup call it.
+// img: the tile's lower 16 x 16 blocks in LDS instead of at Bt (block (P, Q) at img + (P (P + 1) / 2 + Q) * 256, row-major),
+// or null.
 __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
-                                          int* __restrict__ info, int slot, int pivot0)
+                                          int* __restrict__ info, int slot, int pivot0,
+                                          const double* __restrict__ img = nullptr)
 {
     double* const PA = lds;                         // published column panels (by parity)     2 x 128 x PP
     double* const PB = PA + 2 * 128 * PP;           // current column after scaling by X_kb^T  128 x PP
@@ -282,7 +285,10 @@ __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, g
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int row = 16 * rows[pp] + fk + 4 * t, col = 16 * Q + fr;
-                    acc[pp][Q][t] = (rows[pp] >= 0 && col <= row) ? Bt[(size_t)row * ld + col] : 0.0;
+                    const bool mine = rows[pp] >= 0 && col <= row;
+                    acc[pp][Q][t] = !mine ? 0.0
+                        : (img ? img[(rows[pp] * (rows[pp] + 1) / 2 + Q) * 256 + (fk + 4 * t) * 16 + fr]
+                               : Bt[(size_t)row * ld + col]);
                 }
         // publish column 0 and the diagonal sub-tiles 0 and 1 as they are
 #pragma unroll
@@ -449,7 +455,11 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
              unsigned* timed_out, unsigned long long* stamps /* development aid: 8 per tile step, or null */)
 {
 #define STAMP(i) do { if (stamps && blockIdx.x == 0 && threadIdx.x == 0) stamps[(size_t)k * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS_DOUBLES];
+    // [0, CHAIN_LDS_DOUBLES): the diagonal block's buffers / the tile products' stages; behind them the next
+    // diagonal tile as the update leaves it (36 lower blocks): 144 KiB in all -- nothing else fits on this CU
+    __shared__ __attribute__((aligned(16))) double lds[CHAIN_LDS_DOUBLES + 36 * 256];
+    double* const img = lds + CHAIN_LDS_DOUBLES;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = blockIdx.x;
     double* const Bm = ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     double* const Xm = ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
@@ -457,7 +467,7 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
     for (int k = 0; k < T; ++k) {
         const size_t dk = ((size_t)k * GPRN_TILE) * ld + (size_t)k * GPRN_TILE;
         STAMP(0);
-        diag_tile(lds, (gptr_t)(Bm + dk), (gptr_t)(Xm + dk), ld, info, slot, k * GPRN_TILE);
+        diag_tile(lds, (gptr_t)(Bm + dk), (gptr_t)(Xm + dk), ld, info, slot, k * GPRN_TILE, k > 0 ? img : nullptr);
         STAMP(1);
         chain_publish(flag(k, f_diag), epoch);
         STAMP(2);
@@ -475,11 +485,15 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
         STAMP(5);
         // B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T (lower blocks); like every tile the chain touches it is kept
         // up to date by the in-panel updates alone (ensure_tasks), so there is nothing else to wait for
-        tile_mma<128, 128, 4, 1, 0, true>(lds, Bm + sub, Bm + sub, (gptr_t)(Bm + sub + GPRN_TILE), ld, 0, 0,
-                                           CM_SUB, GPRN_TILE, 0, 0);
+        // every wave its own copy (its blocks are compile-time constants there); the result stays in LDS for
+        // the next diagonal block -- nobody else reads this tile before it is factored
+        switch (wave_id) {
+#define U_OF(W) case W: tile_mma<128, 128, 4, 1, 0, true, W>(lds, Bm + sub, Bm + sub, (gptr_t)(Bm + sub + GPRN_TILE), ld, \
+                                                             0, 0, CM_SUB, GPRN_TILE, 0, 0, img); break;
+        U_OF(0) U_OF(1) U_OF(2) default: U_OF(3)
+#undef U_OF
+        }
         STAMP(6);
-        // the next diagonal block reads this tile back: own stores, same CU -- drained, then one barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         STAMP(7);
     }
@@ -827,8 +841,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (use_chain) {
         const int outer_w = c->outers[set][0].k1 - c->outers[set][0].k0;
         prof_begin(c, GPRN_T_DIAG, s0);
-        // 48 KiB of dynamic LDS on top of the 72 KiB it uses: nothing else fits on its CU
-        hipLaunchKernelGGL(k_chain, dim3(nbatch), dim3(256), 48 * 1024, s0, (double* const*)c->d_ptrs, c->ld, c->T,
+        hipLaunchKernelGGL(k_chain, dim3(nbatch), dim3(256), 0, s0, (double* const*)c->d_ptrs, c->ld, c->T,
                            outer_w, c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_MINIL, (int)F_INNER,
                            (int)F_FIRST, epoch, timed_out, c->d_stamps);
         prof_end(c);

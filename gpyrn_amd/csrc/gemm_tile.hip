@@ -147,7 +147,13 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     if (pad_small_kb < 0) { const char* e = getenv("GPRN_PAD_SMALL_KB"); pad_small_kb = e ? atoi(e) : 64; }
     if (pad_small_batch < 0) { const char* e = getenv("GPRN_PAD_SMALL_BATCH"); pad_small_batch = e ? atoi(e) : 2; }
     const int kb = nbatch <= pad_small_batch ? pad_small_kb : pad_kb;
-    const size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
+    size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
+    // The chain's own tile launches (one task: L_{k+1,k}, the B_{k+1,k+1} update) can ask for unused LDS too: with
+    // enough of it they only land on CUs that run no bulk workgroup and are not slowed by MFMA-saturating
+    // neighbours (GPRN_CHAIN_PAD_KB, experiments).
+    static int chain_pad_kb = -1;
+    if (chain_pad_kb < 0) { const char* e = getenv("GPRN_CHAIN_PAD_KB"); chain_pad_kb = e ? atoi(e) : 0; }
+    if (chain_pad_kb && ntasks == 1 && (stream == c->stream || stream == c->stream4)) dyn = (size_t)chain_pad_kb * 1024;
     double* const* tab = (double* const*)d_ptrs;
 #define GO(BM, BN, TRI, TAG) launch_one<BM, BN, TRI, TAG>(d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw)
     bool known = true;

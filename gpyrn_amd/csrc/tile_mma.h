@@ -38,14 +38,20 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // operands; modes as in TileTask; mb16_0 / nb16_0: index of the part's first 16-row / 16-column block inside
 // its 128 x 128 tile (TRI).  Every thread of the workgroup calls it; the last LDS reads are retired on return
 // only after the caller's next barrier.
-template <int BM, int BN, int WM, int WN, int TRI, bool SYRK>
+// WSEL >= 0 (SYRK only): the calling wave's index as a compile-time constant -- the caller switches on the wave
+// and every wave runs its own copy, in which "which blocks are mine" is resolved at compile time (no per-MFMA
+// branches, no registers for the blocks of other waves).  out_img (SYRK only): instead of storing the lower
+// blocks to C, leave them in LDS for the caller: block (P, Q), P >= Q, at out_img + (P (P + 1) / 2 + Q) * 256,
+// 16 x 16 row-major.
+template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
-                                         int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0)
+                                         int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
+                                         double* out_img = nullptr)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: conditions on it are scalar branches
-    const int wr = wave / WN, wc = wave % WN;
+    const int wr = WSEL >= 0 ? WSEL : wave / WN, wc = WSEL >= 0 ? 0 : wave % WN;
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;                   // a wave's part of the tile
     constexpr int MI = TM / 16, NI = TN / 16;                   // 16x16 MFMA tiles per wave
@@ -79,6 +85,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     const int row0 = SYRK ? 16 * wr : wr * TM;                 // first row of the wave's block i = 0
     const int row1_off = SYRK ? 16 * (7 - 2 * wr) : 16;        // rows from block i = 0 to block i = 1 (SYRK: MI = 2)
     const int blk[2] = {SYRK ? wr : 0, SYRK ? 7 - wr : 0};     // SYRK: 16-block row index of block i
+    static_assert(WSEL < 0 || SYRK, "WSEL is for the SYRK form");
     int a_fb[4], b_fb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -238,6 +245,8 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (SYRK && j > blk[i]) continue;
-                Cw[(crow(i) + 4 * r) * ld + j * 16] = neg ? -acc[i][j][r] : acc[i][j][r];
+                const double v = neg ? -acc[i][j][r] : acc[i][j][r];
+                if (SYRK && out_img) out_img[(blk[i] * (blk[i] + 1) / 2 + j) * 256 + (fk + 4 * r) * 16 + fr] = v;
+                else Cw[(crow(i) + 4 * r) * ld + j * 16] = v;
             }
 }
