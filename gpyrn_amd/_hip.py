@@ -63,6 +63,7 @@ SIGNATURES = {
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
+    'gprn_grad_kernel': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_eval_kernel': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, _dp]),
     'gprn_sample_prior': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, c_int, _dp, _dp]),
 }
@@ -266,6 +267,17 @@ class Context:
         Kinv, P = np.empty((self.N, self.N)), np.empty((self.N, self.N))
         self._check(self._lib.gprn_grad_matrices(self._h, int(gp), _ptr(Kinv), _ptr(P)), 'grad_matrices')
         return Kinv, P
+
+    def grad_kernel(self, gp, m, n_params):
+        """Kernel-parameter gradient of latent GP `gp` contracted on the device (SE / Periodic / QuasiPeriodic
+        only; None for any other kernel -- use grad_matrices then)."""
+        m = _f64(np.ravel(m), (self.N,))
+        out = np.zeros(max(4, int(n_params)))
+        rc = self._lib.gprn_grad_kernel(self._h, int(gp), _ptr(m), _ptr(out))
+        if rc == GPRN_E_ARG:
+            return None
+        self._check(rc, 'grad_kernel')
+        return out[:n_params]
 
     def keep_sigma(self, on=True):
         self._check(self._lib.gprn_keep_sigma(self._h, int(bool(on))), 'keep_sigma')

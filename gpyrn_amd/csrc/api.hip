@@ -68,6 +68,7 @@ static void prof_collect(gprn_ctx* c)
 
 extern "C" int gprn_profile_enable(gprn_ctx* c, int mask)
 {
+    DeviceLock lock_(c);
     if (!c) return GPRN_E_ARG;
     prof_collect(c);
     c->prof.on = mask != 0;
@@ -77,6 +78,7 @@ extern "C" int gprn_profile_enable(gprn_ctx* c, int mask)
 
 extern "C" int gprn_profile_read(gprn_ctx* c, double* ms, int64_t* launches, int reset)
 {
+    DeviceLock lock_(c);
     if (!c) return GPRN_E_ARG;
     prof_collect(c);
     for (int i = 0; i < GPRN_T_COUNT; ++i) {
@@ -133,6 +135,7 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body)
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
+    DeviceLock lock_(c);
     if (!c || !name) return GPRN_E_ARG;
     int* field = nullptr;
     if (!strcmp(name, "flags")) { factor_use_flags(c); field = &c->use_flags; }
@@ -190,6 +193,50 @@ extern "C" int gprn_device_count(void)
     return n;
 }
 
+// ONE set of streams per device and process, shared by every context on it.  Streams are a scarce resource
+// here: the runtime folds a process's streams onto a few hardware queues, and a context whose chain and side
+// streams land on the same queue dead-locks the flag schedule (a kernel polling for a flag whose producer sits
+// behind it in that queue) -- measured on MI355X / ROCm 7.2: the SECOND context of a process, every time, when
+// each context made its own four streams.  Every entry point is synchronous (it returns results to the host), so
+// contexts never have work in flight at the same time anyway; calls from several threads are serialised by the
+// device's lock (DeviceLock at the top of each entry point).
+//   s[0] chain (high priority): everything, incl. the latency chain of the factorisation
+//   s[1] bulk (low priority): trailing updates running behind the chain (look-ahead)
+//   s[2] side: in-panel work that is off the chain        s[3]: second chain stream (GPRN_CHAIN_STREAMS=1)
+static std::mutex g_streams_mu;
+static std::map<int, DeviceStreams*> g_streams;
+
+static DeviceStreams* device_streams_acquire(int device)
+{
+    std::lock_guard<std::mutex> g(g_streams_mu);
+    auto it = g_streams.find(device);
+    if (it != g_streams.end()) { it->second->refs += 1; return it->second; }
+    DeviceStreams* d = new DeviceStreams();
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const int prio[4] = {prio_hi, prio_lo, prio_hi, prio_hi};
+    for (int i = 0; i < 4; ++i)
+        if (hipStreamCreateWithPriority(&d->s[i], hipStreamNonBlocking, prio[i]) != hipSuccess) {
+            for (int j = 0; j < i; ++j) hipStreamDestroy(d->s[j]);
+            delete d;
+            return nullptr;
+        }
+    d->device = device;
+    d->refs = 1;
+    g_streams[device] = d;
+    return d;
+}
+
+static void device_streams_release(DeviceStreams* d)
+{
+    if (!d) return;
+    std::lock_guard<std::mutex> g(g_streams_mu);
+    if (--d->refs > 0) return;
+    for (int i = 0; i < 4; ++i) { hipStreamSynchronize(d->s[i]); hipStreamDestroy(d->s[i]); }
+    g_streams.erase(d->device);
+    delete d;
+}
+
 extern "C" int gprn_create(gprn_ctx** out, int device_id)
 {
     if (!out) return GPRN_E_ARG;
@@ -200,16 +247,13 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
     gprn_ctx* c = new gprn_ctx();
     c->device = device_id;
-    // Three streams: `stream` carries everything incl. the latency chain of the factorisation,
-    // `stream3` the in-panel work that is off that chain, `stream2` the bulk trailing updates
-    // running behind both (look-ahead).
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->stream4, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_diag, hipEventDisableTiming) != hipSuccess ||
+    c->shared = device_streams_acquire(device_id);
+    if (!c->shared) { delete c; return GPRN_E_HIP; }
+    c->stream = c->shared->s[0];
+    c->stream2 = c->shared->s[1];
+    c->stream3 = c->shared->s[2];
+    c->stream4 = c->shared->s[3];
+    if (hipEventCreateWithFlags(&c->ev_diag, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_first, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_minil, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming) != hipSuccess ||
@@ -218,6 +262,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
+        device_streams_release(c->shared);
         delete c;
         return GPRN_E_HIP;
     }
@@ -230,30 +275,31 @@ static void comm_teardown(gprn_ctx* c);
 extern "C" void gprn_destroy(gprn_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    prof_collect(c);
-    for (auto e : c->prof.pool) hipEventDestroy(e);
-    comm_teardown(c);
-    free_problem(c);
-    dev_free(c->d_tasks);
-    if (c->d_sig) hipFree(c->d_sig);
-    dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
-    hipStreamSynchronize(c->stream2);
-    hipStreamSynchronize(c->stream3);
-    hipEventDestroy(c->ev_diag);
-    hipEventDestroy(c->ev_first);
-    hipEventDestroy(c->ev_minil);
-    hipEventDestroy(c->ev_inner);
-    hipStreamDestroy(c->stream3);
-    if (c->stream4) { hipStreamSynchronize(c->stream4); hipStreamDestroy(c->stream4); }
-    hipEventDestroy(c->ev_panel);
-    hipEventDestroy(c->ev_rest);
-    hipEventDestroy(c->ev_next);
-    hipEventDestroy(c->ev_nodes);
-    hipEventDestroy(c->ev_q1);
-    hipStreamDestroy(c->stream2);
-    hipStreamDestroy(c->stream);
+    {
+        DeviceLock lock_(c);
+        hipSetDevice(c->device);
+        hipStreamSynchronize(c->stream);
+        hipStreamSynchronize(c->stream2);
+        hipStreamSynchronize(c->stream3);
+        hipStreamSynchronize(c->stream4);
+        prof_collect(c);
+        for (auto e : c->prof.pool) hipEventDestroy(e);
+        comm_teardown(c);
+        free_problem(c);
+        dev_free(c->d_tasks);
+        if (c->d_sig) hipFree(c->d_sig);
+        dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
+        hipEventDestroy(c->ev_diag);
+        hipEventDestroy(c->ev_first);
+        hipEventDestroy(c->ev_minil);
+        hipEventDestroy(c->ev_inner);
+        hipEventDestroy(c->ev_panel);
+        hipEventDestroy(c->ev_rest);
+        hipEventDestroy(c->ev_next);
+        hipEventDestroy(c->ev_nodes);
+        hipEventDestroy(c->ev_q1);
+    }
+    device_streams_release(c->shared);
     delete c;
 }
 
@@ -264,6 +310,7 @@ extern "C" int gprn_last_info_gp(const gprn_ctx* c) { return c ? c->info_gp : -1
 extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* time,
                              const double* y, const double* yerr)
 {
+    DeviceLock lock_(c);
     if (!c || N <= 0 || p <= 0 || q <= 0 || !time || !y || !yerr) return bad(c, "set_data: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -307,6 +354,7 @@ extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* tim
 extern "C" int gprn_set_kernel(gprn_ctx* c, int gp, const int32_t* ops, int n_ops,
                                const double* params, int n_params, int add_nugget)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N) return bad(c, "set_kernel: call set_data first");
     if (gp < 0 || gp >= c->G || !ops || n_ops <= 0 || n_ops > GPRN_MAX_OPS || n_params < 0 ||
         n_params > GPRN_MAX_KPARAMS || (n_params && !params))
@@ -345,6 +393,7 @@ static int ensure_gp_storage(gprn_ctx* c, int g)
 
 extern "C" int gprn_upload_K(gprn_ctx* c, int gp, const double* Kh)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N) return bad(c, "upload_K: call set_data first");
     if (gp < 0 || gp >= c->G || !Kh) return bad(c, "upload_K: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -367,6 +416,7 @@ extern "C" int gprn_upload_K(gprn_ctx* c, int gp, const double* Kh)
 
 extern "C" int gprn_set_y_resid(gprn_ctx* c, const double* y)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !y) return bad(c, "set_y_resid: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -377,6 +427,7 @@ extern "C" int gprn_set_y_resid(gprn_ctx* c, const double* y)
 
 extern "C" int gprn_set_jitters(gprn_ctx* c, const double* jit)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !jit) return bad(c, "set_jitters: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -391,6 +442,7 @@ extern "C" int gprn_set_jitters(gprn_ctx* c, const double* jit)
 
 extern "C" int gprn_set_muvar(gprn_ctx* c, const double* mu, const double* var)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !mu || !var) return bad(c, "set_muvar: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -403,6 +455,7 @@ extern "C" int gprn_set_muvar(gprn_ctx* c, const double* mu, const double* var)
 
 extern "C" int gprn_get_muvar(gprn_ctx* c, double* mu, double* var)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !mu || !var) return bad(c, "get_muvar: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -607,6 +660,7 @@ static void comm_teardown(gprn_ctx* c)
 
 extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id128)
 {
+    DeviceLock lock_(c);
     if (!c || world < 1 || rank < 0 || rank >= world) return bad(c, "comm_init: bad argument");
     if (c->N) return bad(c, "comm_init: call before set_data");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -627,6 +681,7 @@ extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id12
 
 extern "C" int gprn_set_owners(gprn_ctx* c, const int* owner)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !owner) return bad(c, "set_owners: call set_data first");
     for (int g = 0; g < c->G; ++g)
         if (owner[g] < 0 || owner[g] >= c->world) return bad(c, "set_owners: rank out of range");
@@ -638,6 +693,7 @@ extern "C" int gprn_set_owners(gprn_ctx* c, const int* owner)
 
 extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 {
+    DeviceLock lock_(c);
     if (!c || !value) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (comm_active(c)) {
@@ -658,6 +714,7 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 // of independent ELBO evaluations (emcee walkers) needs to share its values
 extern "C" int gprn_comm_allreduce_sum(gprn_ctx* c, double* buf, int n)
 {
+    DeviceLock lock_(c);
     if (!c || !buf || n < 0) return bad(c, "comm_allreduce_sum: bad argument");
     if (!comm_active(c) || n == 0) return GPRN_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -782,6 +839,7 @@ static int factor_priors_impl(gprn_ctx* c);
 
 extern "C" int gprn_factor_priors(gprn_ctx* c)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N) return bad(c, "factor_priors: call set_data first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->owner.empty()) return bad(c, "factor_priors: call set_owners first");
@@ -960,6 +1018,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
 
 extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
 {
+    DeviceLock lock_(c);
     if (!c || n_sweeps <= 0 || !elbo_out) return bad(c, "sweep: bad argument");
     if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
         return bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
@@ -1027,6 +1086,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
 // ------------------------------------------------------------------ read-back
 extern "C" int gprn_keep_sigma(gprn_ctx* c, int on)
 {
+    DeviceLock lock_(c);
     if (!c) return GPRN_E_ARG;
     c->keep_sigma = on != 0;
     return GPRN_OK;
@@ -1034,6 +1094,7 @@ extern "C" int gprn_keep_sigma(gprn_ctx* c, int on)
 
 extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || gp < 0 || gp >= c->G || !out) return bad(c, "get_matrix: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     const double* src = nullptr;
@@ -1052,6 +1113,7 @@ extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
 
 extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !out) return bad(c, "get_logdet_K: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1069,6 +1131,7 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
 
 extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || ns <= 0 || !tstar || !mean_out || !var_out) return bad(c, "predict: bad argument");
     if (!c->have_muvar) return bad(c, "predict: set_muvar (or a sweep) first");
     if (c->owner.empty()) return bad(c, "predict: call set_owners first");
@@ -1206,6 +1269,7 @@ static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch);
 extern "C" int gprn_eval_kernel(gprn_ctx* c, const int32_t* ops, int n_ops, const double* params, int n_params,
                                 double nugget, double* K_out)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || !K_out) return bad(c, "eval_kernel: call set_data first");
     HIP_TRY(c, hipSetDevice(c->device));
     KernelSpec ks;
@@ -1269,6 +1333,7 @@ static int sample_prior_impl(gprn_ctx* c, const KernelSpec& ks, double nugget, i
 extern "C" int gprn_sample_prior(gprn_ctx* c, const int32_t* ops, int n_ops, const double* params, int n_params,
                                  double nugget, int n_samples, const double* z, double* out)
 {
+    DeviceLock lock_(c);
     if (!c || !c->N || n_samples <= 0 || !z || !out) return bad(c, "sample_prior: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     KernelSpec ks;
@@ -1286,9 +1351,10 @@ extern "C" int gprn_sample_prior(gprn_ctx* c, const int32_t* ops, int n_ops, con
 // from the factors of gprn_factor_priors and the explicit Sigma of the last sweep (gprn_keep_sigma).  The
 // O(N^2) contraction with dK/dtheta stays with the caller, who owns the kernel classes.
 // Kinv_out, P_out: (N, N), both symmetric (full).  One rank only (the node sum needs every node's Sigma).
-extern "C" int gprn_grad_matrices(gprn_ctx* c, int gp, double* Kinv_out, double* P_out)
+// kernel_grad != NULL: contract on the device instead of copying the matrices out -- needs a single SE / Periodic
+// / QuasiPeriodic kernel on latent GP `gp` and its mean vector m (N); kernel_grad[l], l < n_params.
+static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const double* m, double* kernel_grad)
 {
-    if (!c || !c->N || gp < 0 || gp >= c->G || !Kinv_out || !P_out) return bad(c, "grad_matrices: bad argument");
     if (c->world != 1) return bad(c, "grad_matrices: not available on a sharded context");
     if (!c->factored || !c->keep_sigma) return bad(c, "grad_matrices: needs factor_priors and a sweep with keep_sigma");
     const int nsum = gp < c->q ? gp + 1 : 1;
@@ -1340,18 +1406,56 @@ extern "C" int gprn_grad_matrices(gprn_ctx* c, int gp, double* Kinv_out, double*
     if (!rc && e == hipSuccess) rc = launch_tiles(c, d_t, n1, d_p, 1, ld, GPRN_T_UPDATE);
     if (!rc && e == hipSuccess) rc = launch_tiles(c, d_t + n1, tasks.size() - n1, d_p, 1, ld, GPRN_T_UPDATE);
     c->d_ptrs = sptrs;
-    if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (!rc && e == hipSuccess)
-        e = hipMemcpy2D(Kinv_out, (size_t)N * sizeof(double), dKinv, (size_t)ld * sizeof(double),
-                        (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
-    if (!rc && e == hipSuccess)
-        e = hipMemcpy2D(P_out, (size_t)N * sizeof(double), dS, (size_t)ld * sizeof(double),
-                        (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
+    if (kernel_grad) {
+        // slot 1's X workspace is free: [0, ld) the mean vector, [ld, 2 ld) a = K^-1 m, then the per-row partial sums
+        const KernelSpec& ks = c->kspec[gp];
+        double* const w = c->wsX[1];
+        double g4[4] = {0, 0, 0, 0};
+        if (!rc && e == hipSuccess) e = hipMemcpyAsync(w, m, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (!rc && e == hipSuccess)
+            rc = vec_grad_contract(c, ks.ops[1], ks.params, dKinv, dS, w, w + ld, w + 2 * (size_t)ld, w + 6 * (size_t)ld);
+        if (!rc && e == hipSuccess)
+            e = hipMemcpyAsync(g4, w + 6 * (size_t)ld, sizeof(g4), hipMemcpyDeviceToHost, c->stream);
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        for (int l = 0; l < ks.n_params && l < 4; ++l) kernel_grad[l] = g4[l];
+    } else {
+        if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (!rc && e == hipSuccess)
+            e = hipMemcpy2D(Kinv_out, (size_t)N * sizeof(double), dKinv, (size_t)ld * sizeof(double),
+                            (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
+        if (!rc && e == hipSuccess)
+            e = hipMemcpy2D(P_out, (size_t)N * sizeof(double), dS, (size_t)ld * sizeof(double),
+                            (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
+    }
     if (d_t) hipFree(d_t);
     if (d_p) hipFree(d_p);
     if (rc) return rc;
     HIP_TRY(c, e);
     return GPRN_OK;
+}
+
+extern "C" int gprn_grad_matrices(gprn_ctx* c, int gp, double* Kinv_out, double* P_out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || gp < 0 || gp >= c->G || !Kinv_out || !P_out) return bad(c, "grad_matrices: bad argument");
+    return grad_impl(c, gp, Kinv_out, P_out, nullptr, nullptr);
+}
+
+// The whole kernel-parameter gradient of latent GP `gp` on the device: < 1/2 (K^-1 S K^-1 + a a^T - K^-1), dK/dtheta_l >,
+// a = K^-1 m, for the kernels with a closed form in csrc/vecops.hip (a single SquaredExponential, Periodic or
+// QuasiPeriodic, as gprn_set_kernel received it); GPRN_E_ARG for any other kernel (the caller then contracts
+// gprn_grad_matrices' output itself).  m: the mean the reference pairs with that kernel (N); grad_out: n_params values
+// (NOT yet divided by q).
+extern "C" int gprn_grad_kernel(gprn_ctx* c, int gp, const double* m, double* grad_out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || gp < 0 || gp >= c->G || !m || !grad_out) return bad(c, "grad_kernel: bad argument");
+    const KernelSpec& ks = c->kspec[gp];
+    const int kid = (ks.set && !ks.uploaded && ks.n_ops == 1 && ks.ops[0] == GPRN_OP_PUSH && ks.ops[2] == 0) ? ks.ops[1] : -1;
+    if (kid != GPRN_K_SE && kid != GPRN_K_PERIODIC && kid != GPRN_K_QP)
+        return bad(c, "grad_kernel: no device-side derivative for this kernel");
+    if (c->ld < 8) return bad(c, "grad_kernel: problem too small");
+    return grad_impl(c, gp, nullptr, nullptr, m, grad_out);
 }
 
 // ------------------------------------------------------------------ diagnostics
@@ -1373,6 +1477,7 @@ static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch)
 extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int b_mode, int c_mode,
                               const double* A, const double* B, double* C)
 {
+    DeviceLock lock_(c);
     if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || !A || !B || !C)
         return bad(c, "test_gemm: bad argument");
     const int ld = std::max(std::max(M, N), K);
@@ -1498,12 +1603,14 @@ static int test_factor_impl(gprn_ctx* c, int n, int batch, const double* A, doub
 
 extern "C" int gprn_test_factor_invert(gprn_ctx* c, int n, int batch, const double* A, double* L, double* Linv)
 {
+    DeviceLock lock_(c);
     if (!L || !Linv) return bad(c, "test_factor_invert: bad argument");
     return test_factor_common(c, n, batch, A, L, Linv, false, nullptr);
 }
 
 extern "C" int gprn_test_lauum(gprn_ctx* c, int n, const double* X, double* out)
 {
+    DeviceLock lock_(c);
     if (!out) return bad(c, "test_lauum: bad argument");
     return test_factor_common(c, n, 1, X, nullptr, nullptr, true, out);
 }

@@ -680,30 +680,38 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
 
 // Do kernels of the chain stream and of stream4 run side by side?  With too few hardware queues the runtime
 // folds two streams onto one, and a kernel that waits in-kernel for a later launch of the "other" stream would
-// never see it start.  Tried once per context: a kernel on stream4 waits (20 ms at most) for a flag that a
-// kernel launched AFTER it on the chain stream raises.
-int factor_probe_streams(gprn_ctx* c)
+// never see it start.
+// true when a kernel on `waiter` that polls (20 ms at most) for a flag sees a kernel launched AFTER it on
+// `producer` raise it -- i.e. the two streams sit on different hardware queues
+static bool streams_overlap(hipStream_t waiter, hipStream_t producer)
 {
-    if (c->chain_streams >= 0) return c->chain_streams;
-    c->chain_streams = 0;
-    if (!c->stream4) return 0;
     unsigned* w = nullptr;                         // [0] flag, [2] time-out word, [3] budget in 100 MHz ticks
-    if (hipMalloc(&w, 4 * sizeof(unsigned)) != hipSuccess) return 0;
+    if (hipMalloc(&w, 4 * sizeof(unsigned)) != hipSuccess) return false;
     const unsigned init[4] = {0u, 0u, 0u, 2000000u};
     bool ok = hipMemcpy(w, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, c->stream4, (unsigned*)nullptr, 0u,
-                           (const unsigned*)w, 1u, w + 2);
-        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, c->stream, w, 1u, (const unsigned*)nullptr, 0u, w + 2);
-        ok = hipStreamSynchronize(c->stream4) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, waiter, (unsigned*)nullptr, 0u, (const unsigned*)w, 1u, w + 2);
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, producer, w, 1u, (const unsigned*)nullptr, 0u, w + 2);
+        ok = hipStreamSynchronize(waiter) == hipSuccess && hipStreamSynchronize(producer) == hipSuccess;
     }
     unsigned out[4] = {0, 0, 1, 0};
     if (ok) ok = hipMemcpy(out, w, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess;
     hipFree(w);
-    c->chain_streams = (ok && out[0] == 1u && out[2] == 0u) ? 1 : 0;
+    return ok && out[0] == 1u && out[2] == 0u;
+}
+
+int factor_probe_streams(gprn_ctx* c)
+{
+    if (c->chain_streams >= 0) return c->chain_streams;
+    c->chain_streams = (c->stream4 && streams_overlap(c->stream4, c->stream) && streams_overlap(c->stream, c->stream4)) ? 1 : 0;
     return c->chain_streams;
 }
 
+// Device-side flags or HIP events?  Flags need (1) stream memory operations, (2) no tool or setting that runs one
+// kernel at a time (counter collection, AMD_SERIALIZE_KERNEL, HIP_LAUNCH_BLOCKING, fewer than 4 hardware queues),
+// (3) the chain, side and bulk streams on different hardware queues -- probed once per device (the streams are
+// shared by every context on it): six tiny launch pairs, each a kernel polling for a flag raised by a kernel
+// launched after it on another stream.  GPRN_FLAGS=0/1 overrides (1) still needs the stream memory operations.
 int factor_use_flags(gprn_ctx* c)
 {
     if (c->use_flags >= 0) return c->use_flags;
@@ -714,8 +722,21 @@ int factor_use_flags(gprn_ctx* c)
                             on("HIP_LAUNCH_BLOCKING") || (hq && atoi(hq) > 0 && atoi(hq) < 4);
     int can = 0;                               // stream memory operations are optional in HIP
     if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device) != hipSuccess) can = 0;
-    c->use_flags = e ? (atoi(e) != 0 && can) : ((serialised || !can) ? 0 : 1);
-    return c->use_flags;
+    if (e) return c->use_flags = (atoi(e) != 0 && can) ? 1 : 0;
+    if (serialised || !can) return c->use_flags = 0;
+    DeviceStreams* d = c->shared;
+    if (d && d->use_flags < 0) {
+        hipStream_t st[3] = {c->stream, c->stream2, c->stream3};
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i)
+            for (int j = 0; j < 3 && ok; ++j)
+                if (i != j) ok = streams_overlap(st[i], st[j]);
+        d->use_flags = ok ? 1 : 0;
+        if (!ok)
+            fprintf(stderr, "[gprn] device %d: the library's streams share a hardware queue; cross-stream dependencies "
+                            "go through HIP events\n", c->device);
+    }
+    return c->use_flags = d ? d->use_flags : 1;
 }
 
 // Split schedule.  Per tile step k the only launches on the chain stream are the diagonal

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <functional>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gprn_hip.h"
@@ -69,8 +71,16 @@ struct KernelSpec {            // how latent GP g gets its K
     double params[GPRN_MAX_KPARAMS];
 };
 
+struct DeviceStreams {         // one per device and process, see gprn_create
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    int device = 0, refs = 0;
+    int use_flags = -1;        // the flag schedule's verdict for these streams (factor_use_flags), -1: not probed
+    std::recursive_mutex mu;   // held for the length of every entry point
+};
+
 struct gprn_ctx {
     int device = 0;
+    DeviceStreams* shared = nullptr;
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
     hipStream_t stream3 = nullptr;   // in-panel work that is off the chain (panel rest, inner rest)
@@ -167,6 +177,12 @@ struct gprn_ctx {
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
 };
+
+struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)
+    std::unique_lock<std::recursive_mutex> l;
+    explicit DeviceLock(const gprn_ctx* c) { if (c && c->shared) l = std::unique_lock<std::recursive_mutex>(c->shared->mu); }
+};
+
 
 // ---- launchers (each enqueues on ctx->stream; no sync) ----
 void prof_begin(gprn_ctx* c, int fam, hipStream_t stream = nullptr);   // nullptr = ctx->stream

@@ -18,3 +18,6 @@ int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol
                   double* mean, double* var);
 int vec_axpy_matrix(gprn_ctx* c, const double* src, double* dst, int N);   // dst += src on the N x N block (pitch ld)
 int vec_symmetrize(gprn_ctx* c, double* M);                                 // upper := lower^T on the ld x ld matrix
+// out4[l] = < 1/2 (P - Kinv + a a^T), dK/dtheta_l >, a = Kinv m, for a single SE / Periodic / QP kernel (kid, par[4])
+int vec_grad_contract(gprn_ctx* c, int kid, const double* par, const double* Kinv, const double* P, const double* m,
+                      double* a_scratch, double* part_scratch, double* out4);

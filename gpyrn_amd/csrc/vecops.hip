@@ -484,6 +484,80 @@ int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out)
     LAUNCH_END(c);
 }
 
+// ---- gradient contraction: per row m of G = 1/2 (P - Kinv + a a^T),
+//   part[m][l] = sum_n G[m][n] dK[m][n]/dtheta_l,   l < 4,
+// for the three kernels with closed forms here (SE: theta, ell; Periodic: theta, P, ell; QP: theta, le, P, lp --
+// the formulas of covfunc._dk_dpars), one wave per row, rows summed by k_sum_cols.  a = Kinv m is formed first.
+__global__ __launch_bounds__(256)
+void k_symv(const double* __restrict__ M, const double* __restrict__ v, int N, int ld, double* __restrict__ out)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    double acc = 0.0;
+    for (int c = lane; c < N; c += 64) acc += M[(size_t)i * ld + c] * v[c];
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+}
+
+__global__ __launch_bounds__(256)
+void k_grad_rows(int kid, double q0, double q1, double q2, double q3, const double* __restrict__ t,
+                 const double* __restrict__ Kinv, const double* __restrict__ P, const double* __restrict__ a,
+                 int N, int ld, double* __restrict__ part /* [N][4] */)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= N) return;
+    const double tm = t[m], am = a[m];
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const double G = 0.5 * (P[(size_t)m * ld + n] - Kinv[(size_t)m * ld + n] + am * a[n]);
+        const double r = tm - t[n];
+        if (kid == GPRN_K_SE) {
+            const double K = q0 * q0 * exp(-0.5 * (r * r) / (q1 * q1));
+            g0 += G * (2 * K / q0);
+            g1 += G * (K * (r * r) / (q1 * q1 * q1));
+        } else if (kid == GPRN_K_PERIODIC) {
+            const double x = 3.141592653589793 * fabs(r) / q1, sx = sin(x);
+            const double K = q0 * q0 * exp(-2 * (sx * sx) / (q2 * q2));
+            g0 += G * (2 * K / q0);
+            g1 += G * (K * 2 * x * sin(2 * x) / (q1 * (q2 * q2)));
+            g2 += G * (K * 4 * (sx * sx) / (q2 * q2 * q2));
+        } else {                                   // GPRN_K_QP
+            const double x = 3.141592653589793 * fabs(r) / q2, sx = sin(x);
+            const double K = q0 * q0 * exp(-2 * (sx * sx) / (q3 * q3) - (r * r) / (2 * (q1 * q1)));
+            g0 += G * (2 * K / q0);
+            g1 += G * (K * (r * r) / (q1 * q1 * q1));
+            g2 += G * (K * 2 * x * sin(2 * x) / (q2 * (q3 * q3)));
+            g3 += G * (K * 4 * (sx * sx) / (q3 * q3 * q3));
+        }
+    }
+    g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2); g3 = wave_sum(g3);
+    if (lane == 0) { part[4 * m] = g0; part[4 * m + 1] = g1; part[4 * m + 2] = g2; part[4 * m + 3] = g3; }
+}
+
+__global__ __launch_bounds__(256)
+void k_sum_cols4(const double* __restrict__ part, int n, double* __restrict__ out /* 4 */)
+{
+    __shared__ double sh[4];
+    for (int l = 0; l < 4; ++l) {                  // fixed order: the result does not depend on the launch
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += part[4 * i + l];
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) out[l] = acc;
+        __syncthreads();
+    }
+}
+
+int vec_grad_contract(gprn_ctx* c, int kid, const double* par, const double* Kinv, const double* P, const double* m,
+                      double* a_scratch, double* part_scratch, double* out4)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_symv, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, Kinv, m, c->N, c->ld, a_scratch);
+    hipLaunchKernelGGL(k_grad_rows, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, kid, par[0], par[1], par[2], par[3],
+                       c->d_time, Kinv, P, a_scratch, c->N, c->ld, part_scratch);
+    hipLaunchKernelGGL(k_sum_cols4, dim3(1), dim3(256), 0, c->stream, part_scratch, c->N, out4);
+    LAUNCH_END(c);
+}
+
 // dst += src on the N x N block of two ld-pitched matrices (the node sum of quirk Q1 for the gradient)
 __global__ __launch_bounds__(256)
 void k_axpy_matrix(const double* __restrict__ src, double* __restrict__ dst, int N, int ld)

@@ -668,28 +668,37 @@ class inference:
         try:
             elbo, _, info = ctx.sweep(1, commit=True)
             mu, var = ctx.get_muvar()
-            grads = self._grad_from_state(nodes, weights, means, jitters, mu, var, ctx.grad_matrices)
+            grads = self._grad_from_state(nodes, weights, means, jitters, mu, var, ctx.grad_matrices,
+                                          device=ctx.grad_kernel)
         finally:
             ctx.keep_sigma(False)
         self._mu, self._var = mu, var
         self.last_info = info
         return float(elbo[0]), np.array(grads)
 
-    def _grad_from_state(self, nodes, weights, means, jitters, mu, var, matrices):
+    def _grad_from_state(self, nodes, weights, means, jitters, mu, var, matrices, device=None):
         """The O(N^2) and O(pqN) part of grad_ELBO: `matrices(gp)` returns ``(K^-1, K^-1 S K^-1)`` of latent GP
-        `gp` (the GPU's ``gprn_grad_matrices``; a NumPy stand-in in the CPU tests)."""
+        `gp` (the GPU's ``gprn_grad_matrices``; a NumPy stand-in in the CPU tests).  `device(gp, m, n)`, when
+        given, is tried first: the whole contraction on the GPU for kernels it has closed forms for
+        (``gprn_grad_kernel``), None otherwise."""
         t = np.asarray(self.time, dtype=float)
         r = t[:, None] - t[None, :]
         q, p, N = self.q, self.p, self.N
         m_scr = mu[1:].reshape(q, p, N)                      # quirk Q2 (meanfield.py:1021)
         grads = []
         for gp, kernel in enumerate(chain(nodes, weights)):
-            Kinv, P = matrices(gp)
             if gp < q:
                 m = mu[0, gp]
             else:
                 jj, ii = divmod(gp - q, p)
                 m = m_scr[jj, ii]
+            if device is not None and type(kernel) in (covfunc.SquaredExponential, covfunc.Periodic,
+                                                        covfunc.QuasiPeriodic):
+                on_device = device(gp, m, kernel.pars.size)
+                if on_device is not None:
+                    grads += [float(v) / q for v in on_device]
+                    continue
+            Kinv, P = matrices(gp)
             a = Kinv @ m
             G = 0.5 * (P - Kinv + np.outer(a, a)) / q        # ELBO = (...) / q, meanfield.py:709
             if isinstance(kernel, _TWO_ARGUMENT):

@@ -74,7 +74,9 @@ enum { GPRN_OP_PUSH = 0, GPRN_OP_ADD = 1, GPRN_OP_MUL = 2 };
 
 /* ---- context ---- */
 int gprn_device_count(void);
-/* Replaces nothing in the reference (it has no device); one per GPU. */
+/* Replaces nothing in the reference (it has no device).  One context per model; contexts on one device share the
+ * library's streams (one set per device and process) and every call below is synchronous and takes the device's
+ * lock, so contexts may be used from several host threads -- their calls run one after the other. */
 int gprn_create(gprn_ctx** out, int device_id);
 void gprn_destroy(gprn_ctx* ctx);
 const char* gprn_last_error(const gprn_ctx* ctx);
@@ -157,6 +159,11 @@ int gprn_sample_prior(gprn_ctx* ctx, const int32_t* ops, int n_ops, const double
  * (N, N) symmetric; needs gprn_factor_priors and a committed sweep with gprn_keep_sigma(1).  Unsharded
  * contexts only. */
 int gprn_grad_matrices(gprn_ctx* ctx, int gp, double* Kinv_out, double* P_out);
+/* the contraction as well on the device, for a latent GP whose kernel is a single SquaredExponential, Periodic or
+ * QuasiPeriodic (closed-form dK/dtheta in csrc/vecops.hip, the formulas of covFunction._dk_dpars): grad_out[l] =
+ * < 1/2 (K^-1 S K^-1 + a a^T - K^-1), dK/dtheta_l >, l < n_params, a = K^-1 m (m: N values, the mean the reference
+ * pairs with that kernel; the 1/q of meanfield.py:709 is left to the caller).  GPRN_E_ARG for any other kernel. */
+int gprn_grad_kernel(gprn_ctx* ctx, int gp, const double* m, double* grad_out);
 
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */
 enum {

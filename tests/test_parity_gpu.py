@@ -633,6 +633,46 @@ def test_grad_elbo_against_finite_differences(tag):
     np.testing.assert_allclose(grad, fd, rtol=2e-5, atol=1e-6 * scale)
 
 
+def test_grad_contraction_on_device_matches_host_contraction():
+    """gprn_grad_kernel (K^-1 m, dK/dtheta and the <G, dK> sums all on the GPU) against the same gradient
+    contracted in NumPy from gprn_grad_matrices' output, for the three kernels with device-side closed forms
+    (one node each; the weights are SquaredExponential) -- and a kernel without one falls back, not fails."""
+    rng = np.random.default_rng(5)
+    N, p, q = 300, 2, 3
+    t = np.sort(rng.uniform(0, 60, N))
+    args = []
+    for _ in range(p):
+        args += [rng.normal(size=N), rng.uniform(0.1, 0.3, N)]
+    g = gpyrn.inference(q, t, *args)
+    nodes = [covfunc.SquaredExponential(1.0, 4.0), covfunc.Periodic(1.0, 11.0, 0.8),
+             covfunc.QuasiPeriodic(1.0, 20.0, 9.0, 0.7)]
+    weights = [covfunc.SquaredExponential(0.8, 15.0), covfunc.Matern32(0.9, 12.0)] * q
+    g.set_components(nodes, weights, [None] * p, [0.2] * p)
+    g.ELBOcalc(max_iter=20)
+    nd, wt, mn, jt = g._get_components()
+    ctx = g._setup_device(nd, wt, mn, jt)
+    ctx.set_muvar(g._mu, g._var)
+    ctx.keep_sigma(True)
+    try:
+        ctx.sweep(1, commit=True)
+        mu, var = ctx.get_muvar()
+        seen = []
+
+        def device(gp, m, n):
+            out = ctx.grad_kernel(gp, m, n)
+            seen.append((gp, out is not None))
+            return out
+
+        on_dev = np.array(g._grad_from_state(nd, wt, mn, jt, mu, var, ctx.grad_matrices, device=device))
+        on_host = np.array(g._grad_from_state(nd, wt, mn, jt, mu, var, ctx.grad_matrices))
+        assert ctx.grad_kernel(q + 1, np.zeros(N), 2) is None        # Matern32: no device-side closed form
+    finally:
+        ctx.keep_sigma(False)
+    # nodes 0..2 and the SE weights (gp 3, 5, 7) went through the device
+    assert [gp for gp, ok in seen if ok] == [0, 1, 2, 3, 5, 7]
+    np.testing.assert_allclose(on_dev, on_host, rtol=1e-6, atol=1e-9 * np.abs(on_host).max())
+
+
 def test_optimize_with_analytic_gradient():
     """optimize(method='L-BFGS-B', jac=True): runs on the analytic gradient and does not do worse than where
     it started; the gradient of the frozen parameters never reaches scipy."""
