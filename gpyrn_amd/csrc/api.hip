@@ -173,6 +173,7 @@ static void free_problem(gprn_ctx* c)
     for (auto& p : c->predKs) dev_free(p);
     for (auto& p : c->predWT) dev_free(p);
     c->predKs.clear(); c->predWT.clear(); c->pred_cap = 0;
+    tab_forget(c, nullptr);
     dev_free(c->tab_pred); dev_free(c->d_slotgp_all);
     dev_free(c->tab_node); dev_free(c->tab_weight); dev_free(c->tab_setup);
     dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
@@ -762,6 +763,7 @@ static int upload_table(gprn_ctx* c, double** d_tab, const std::vector<double*>&
     HIP_TRY(c, hipMemcpyAsync(d_tab, rows.data(), rows.size() * sizeof(double*),
                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tab_note(c, d_tab, rows.data(), rows.size());
     return GPRN_OK;
 }
 
@@ -781,6 +783,7 @@ static int build_tables(gprn_ctx* c)
             TRY(dev_alloc(c, &c->wsB[s], nn));
             TRY(dev_alloc(c, &c->wsX[s], nn));
         }
+        tab_forget(c, c->tab_node); tab_forget(c, c->tab_weight); tab_forget(c, c->tab_setup);
         dev_free(c->tab_node); dev_free(c->tab_weight); dev_free(c->tab_setup);
         dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
         dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
@@ -1163,6 +1166,7 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
             TRY(dev_alloc(c, &c->predWT[s], need));
         }
         c->pred_cap = need;
+        tab_forget(c, c->tab_pred);
         dev_free(c->tab_pred); dev_free(c->d_slotgp_all);
         TRY(dev_alloc(c, &c->tab_pred, (size_t)c->nslot * GPRN_NBUF));
         TRY(dev_alloc(c, &c->d_slotgp_all, c->nslot));
@@ -1304,6 +1308,7 @@ static int sample_prior_impl(gprn_ctx* c, const KernelSpec& ks, double nugget, i
     if (!rc) {
         double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], nullptr, nullptr};
         e = hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice);
+        if (e == hipSuccess) tab_note(c, d_p, hp, GPRN_NBUF);
         if (e == hipSuccess) e = hipMemset(d_i, 0, sizeof(int));
         if (e == hipSuccess) e = hipMemset(d_z, 0, (size_t)n_samples * ld * sizeof(double));
         if (e == hipSuccess) e = hipMemcpy2D(d_z, (size_t)ld * sizeof(double), z, (size_t)N * sizeof(double),
@@ -1321,7 +1326,7 @@ static int sample_prior_impl(gprn_ctx* c, const KernelSpec& ks, double nugget, i
                             (size_t)N * sizeof(double), n_samples, hipMemcpyDeviceToHost);
     }
     c->d_ptrs = sptrs; c->d_info_cur = sinfo;
-    if (d_p) hipFree(d_p);
+    if (d_p) { tab_forget(c, d_p); hipFree(d_p); }
     if (d_i) hipFree(d_i);
     if (d_z) hipFree(d_z);
     if (d_o) hipFree(d_o);
@@ -1428,7 +1433,7 @@ static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const
                             (size_t)N * sizeof(double), N, hipMemcpyDeviceToHost);
     }
     if (d_t) hipFree(d_t);
-    if (d_p) hipFree(d_p);
+    if (d_p) { tab_forget(c, d_p); hipFree(d_p); }
     if (rc) return rc;
     HIP_TRY(c, e);
     return GPRN_OK;
@@ -1523,7 +1528,7 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess)
         e = hipMemcpy(hc.data(), c->d_test[2], nn * sizeof(double), hipMemcpyDeviceToHost);
-    hipFree(d_t); hipFree(d_p);
+    hipFree(d_t); tab_forget(c, d_p); hipFree(d_p);
     if (rc) return rc;
     HIP_TRY(c, e);
     for (int m = 0; m < M; ++m)
@@ -1568,6 +1573,7 @@ static int test_factor_impl(gprn_ctx* c, int n, int batch, const double* A, doub
     int info0 = 0;
     if (!rc) {
         e = hipMemcpy(d_p, hp.data(), hp.size() * sizeof(double*), hipMemcpyHostToDevice);
+        if (e == hipSuccess) tab_note(c, d_p, hp.data(), hp.size());
         if (e == hipSuccess) e = hipMemset(d_i, 0, batch * sizeof(int));
         c->d_ptrs = d_p; c->d_info_cur = d_i;
         c->tasks_T = -1;                       // force a task rebuild for this n
@@ -1591,7 +1597,7 @@ static int test_factor_impl(gprn_ctx* c, int n, int batch, const double* A, doub
             }
         }
     }
-    if (d_p) hipFree(d_p);
+    if (d_p) { tab_forget(c, d_p); hipFree(d_p); }
     if (d_i) hipFree(d_i);
     c->N = sN; c->ld = sld; c->T = sT; c->d_ptrs = sptrs; c->d_info_cur = sinfo;
     c->tasks_T = -1;                           // the problem's own lists are rebuilt on demand

@@ -633,8 +633,10 @@ __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, g
     else diag_pivot(L, Xt, ld, info, slot, pivot0);
 }
 
+// PTRS: the two pointers per matrix come as kernel arguments (launch_diag), else from the table
+template <bool ARGS>
 __global__ __launch_bounds__(256)
-void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __restrict__ info,
+void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
                   unsigned* wait_timed_out)
 {
@@ -642,9 +644,42 @@ void k_diag_block(double* const* __restrict__ ptrs, int ld, int kblk, int* __res
     await_flag(wait_flag, wait_value, wait_timed_out);
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-    diag_tile(lds, (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + off),
-              (gptr_t)(ptrs[(size_t)slot * GPRN_NBUF + BUF_X] + off), ld, info, slot, kblk * GPRN_TILE);
+    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
+}
+
+void tab_note(gprn_ctx* c, double** d_tab, double* const* rows, size_t count)
+{
+    for (auto& e : c->tab_host)
+        if (e.first == d_tab) { e.second.assign(rows, rows + count); return; }
+    c->tab_host.emplace_back(d_tab, std::vector<double*>(rows, rows + count));
+}
+
+void tab_forget(gprn_ctx* c, double** d_tab)
+{
+    if (!d_tab) { c->tab_host.clear(); return; }
+    for (size_t i = 0; i < c->tab_host.size(); ++i)
+        if (c->tab_host[i].first == d_tab) { c->tab_host.erase(c->tab_host.begin() + i); return; }
+}
+
+bool tab_rows(gprn_ctx* c, double** d_ptrs, int nbatch, PtrArgs* out)
+{
+    static int on = -1;                            // GPRN_ARG_PTRS=0: always the table (experiments)
+    if (on < 0) { const char* e = getenv("GPRN_ARG_PTRS"); on = e ? atoi(e) : 1; }
+    if (!on || nbatch > GPRN_ARG_SLOTS) return false;
+    for (const auto& e : c->tab_host) {
+        if (d_ptrs < e.first || d_ptrs >= e.first + e.second.size()) continue;
+        const size_t first = (size_t)(d_ptrs - e.first);
+        if (first % GPRN_NBUF || first + (size_t)nbatch * GPRN_NBUF > e.second.size()) return false;
+        for (int b = 0; b < nbatch; ++b) {
+            out->p[b][0] = e.second[first + (size_t)b * GPRN_NBUF + BUF_B];
+            out->p[b][1] = e.second[first + (size_t)b * GPRN_NBUF + BUF_X];
+        }
+        return true;
+    }
+    return false;
 }
 
 // ------------------------------------------------------------------ chain
@@ -735,8 +770,13 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
 {
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
-    hipLaunchKernelGGL(k_diag_block, dim3(nbatch), dim3(256), 0, stream,
-                       (double* const*)d_ptrs, ld, kblk, d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+    PtrArgs pa;
+    if (tab_rows(c, d_ptrs, nbatch, &pa))
+        hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk,
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+    else
+        hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk,
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -1178,9 +1218,18 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 else l_waits = in_kernel_wait(k, F_DIAG);
             }
             hipStream_t sc = two_streams ? c->stream4 : s0;
-            if ((rc = tiles(s.panel0, 1, sc, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), l_waits))) return rc;
+            // (GPRN_CHAIN_ROWS=0: the throughput tile kernel for these two as well, as in round 1)
+            static int chain_rows = -1;
+            if (chain_rows < 0) { const char* e = getenv("GPRN_CHAIN_ROWS"); chain_rows = e ? atoi(e) : 1; }
+            if (chain_rows) {
+                if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, sc,
+                                           in_kernel(k, F_MINIL), l_waits))) return rc;
+            } else if ((rc = tiles(s.panel0, 1, sc, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), l_waits))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
-            if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
+            if (chain_rows) {
+                if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, sc,
+                                           two_streams ? in_kernel(k, F_U) : nosig, noaw))) return rc;
+            } else if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
             if ((rc = side_sync(k))) return rc;
             if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;

@@ -90,6 +90,154 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
+// ---- the latency chain's two products of a tile step, one 16 x 16 block of the output per WAVE
+//   MODE 0:  L_{k+1,k} = B_{k+1,k} X_kk^T, in place over B_{k+1,k}; X_kk lower triangular: block column Q of the
+//            result needs k < 16 (Q + 1) only
+//   MODE 1:  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T, lower blocks only (all the diagonal-block kernel reads)
+// Operands go (almost) straight from global memory into MFMA operand registers -- lane (fr, fk) takes 16 bytes of row
+// fr per load -- and a wave issues at most 32 MFMAs.  The throughput kernel above spends 14 us on the first product (two 64 x 128 workgroups: a 6.8 us MFMA
+// stream per wave inside its staging pipeline) and 8 us on the second (four 64 x 64 workgroups); these two are
+// latency only: wait, fetch, <= 0.9 us of MFMAs, store, signal.
+#ifdef ROWS_STAMPS         // _probe/rows_bench.hip: 100 MHz stamps of workgroup 0, wave 0
+__device__ unsigned long long rows_stamps[8];
+#define RW_STAMP(i) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rows_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RW_STAMP(i) do {} while (0)
+#endif
+// K index of a lane in both kernels: load j (16 bytes per lane) brings k = 8 j + 2 fk and 8 j + 2 fk + 1 of row fr,
+// the same split for both operands.
+//
+// MODE 0, one workgroup of 8 waves per block row P, wave = block column Q.  The row block of B_{k+1,k} (16 x 128,
+// operand A of all eight waves, and the memory the result goes to) passes through LDS once -- each wave fetches two
+// rows, fully coalesced; eight waves fetching all of it themselves kept the CU's vector memory path busy for 3.5 us
+// -- and the X_kk rows come straight from global memory, 16 (Q + 1) columns of them.
+#define ROWS_PITCH 136                              // doubles per LDS row: 16-byte reads of 64 lanes spread over all banks
+template <bool ARGS>
+__global__ __launch_bounds__(512)
+void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t b_off,
+               unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
+               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2)
+{
+    __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
+    RW_STAMP(0);
+    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    RW_STAMP(1);
+    const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
+    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    double* const Bm = ARGS ? pa.p[blockIdx.y][0] : ptrs[(size_t)blockIdx.y * GPRN_NBUF + BUF_B];
+    double* const Xm = ARGS ? pa.p[blockIdx.y][1] : ptrs[(size_t)blockIdx.y * GPRN_NBUF + BUF_X];
+    const int nj = 2 * (Q + 1);
+    const double* B = Xm + b_off + (size_t)(16 * Q + fr) * ld + 2 * fk;
+    double b[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < nj) {
+            const double2 bv = *(const double2*)(B + 8 * j);
+            b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
+        }
+    {   // rows 2Q, 2Q+1 of the block: lane l takes 16 bytes at column 2 l
+        const double* Ar = Bm + a_off + (size_t)(16 * P + 2 * Q) * ld + 2 * lane;
+        const double2 r0 = *(const double2*)Ar, r1 = *(const double2*)(Ar + ld);
+        *(double2*)(rows + (2 * Q) * ROWS_PITCH + 2 * lane) = r0;
+        *(double2*)(rows + (2 * Q + 1) * ROWS_PITCH + 2 * lane) = r1;
+    }
+    RW_STAMP(2);
+    __syncthreads();                 // the block is in LDS: from here on its memory may be overwritten (in place)
+    RW_STAMP(3);
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* ar = rows + fr * ROWS_PITCH + 2 * fk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < nj) {
+            const double2 av = *(const double2*)(ar + 8 * j);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, b[2 * j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, b[2 * j + 1], acc, 0, 0, 0);
+        }
+    gptr_t C = (gptr_t)(Bm + a_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
+    RW_STAMP(4);
+#ifdef ROWS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RW_STAMP(5);
+#endif
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    RW_STAMP(6);
+}
+
+// MODE 1, one single-wave workgroup per lower 16 x 16 block (36 per matrix, each on a CU of its own: 32 KiB of
+// operands per CU instead of 256)
+template <bool ARGS>
+__global__ __launch_bounds__(64)
+void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t c_off,
+               unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
+               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2)
+{
+    RW_STAMP(0);
+    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    RW_STAMP(1);
+    int P = 0;
+    while ((P + 1) * (P + 2) / 2 <= (int)blockIdx.x) ++P;
+    const int Q = (int)blockIdx.x - P * (P + 1) / 2;
+    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    double* const Bm = ARGS ? pa.p[blockIdx.y][0] : ptrs[(size_t)blockIdx.y * GPRN_NBUF + BUF_B];
+    const double* A = Bm + a_off + (size_t)(16 * P + fr) * ld + 2 * fk;
+    const double* B = Bm + a_off + (size_t)(16 * Q + fr) * ld + 2 * fk;
+    gptr_t C = (gptr_t)(Bm + c_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
+    double a[32], b[32];
+    v4d acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double2 av = *(const double2*)(A + 8 * j), bv = *(const double2*)(B + 8 * j);
+        a[2 * j] = av.x; a[2 * j + 1] = av.y;
+        b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every load in flight before the first MFMA
+    RW_STAMP(2);
+    RW_STAMP(3);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[j], b[j], acc, 0, 0, 0);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
+    RW_STAMP(4);
+#ifdef ROWS_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RW_STAMP(5);
+#endif
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    RW_STAMP(6);
+}
+
+// mode 0 / 1 as above, for tile step k: the operands are tiles (k+1, k), (k, k) [of X] resp. (k+1, k+1), (k+1, k) --
+// the first panel and the first update task of the step (ensure_tasks, factor.hip)
+int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
+                     hipStream_t stream, Signal sig, Await aw)
+{
+    if (!stream) stream = c->stream;
+    if (nbatch == 0) return GPRN_OK;
+    auto toff = [&](int ti, int tj) { return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE; };
+    const int64_t a_off = toff(k + 1, k), b_off = mode == 0 ? toff(k, k) : toff(k + 1, k);
+    const int64_t c_off = mode == 0 ? toff(k + 1, k) : toff(k + 1, k + 1);
+    prof_begin(c, fam, stream);
+    double* const* tab = (double* const*)d_ptrs;
+    PtrArgs pa;
+    const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
+    unsigned* const tmo = aw.timed_out ? aw.timed_out : sig.timed_out;
+#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
+                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2)
+#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
+                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2)
+    if (mode == 0) { if (args) GO_L(true); else GO_L(false); }
+    else { if (args) GO_U(true); else GO_U(false); }
+#undef GO_L
+#undef GO_U
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
 static int xcd_map()                               // GPRN_XCD_MAP=0: grid order as dispatched (experiments)
 {
     static int v = -1;

@@ -126,6 +126,10 @@ struct gprn_ctx {
     int slot0 = 0;                   // first slot of the running phase (0 nodes, #local nodes weights)
     std::vector<double*> wsB, wsX;
     double** d_ptrs = nullptr;       // the table the launchers use right now (one of the three below)
+    // host copies of the live pointer tables (device address -> rows): the chain's kernels take the few pointers
+    // they need as kernel arguments instead of fetching them from the table (one memory round trip less on the
+    // critical path of every tile step); tab_note / tab_forget / tab_rows, factor.hip
+    std::vector<std::pair<double**, std::vector<double*>>> tab_host;
     double **tab_node = nullptr, **tab_weight = nullptr, **tab_setup = nullptr;  // [nslot][GPRN_NBUF]
     int *d_slotgp_node = nullptr, *d_slotgp_weight = nullptr, *d_slotgp_setup = nullptr;
     bool tables_ready = false;
@@ -218,6 +222,18 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
                  Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},
                  int tag = TG_MISC);
+// BUF_B and BUF_X of up to GPRN_ARG_SLOTS matrices as a kernel argument
+#define GPRN_ARG_SLOTS 16
+struct PtrArgs { double* p[GPRN_ARG_SLOTS][2]; };
+void tab_note(gprn_ctx* c, double** d_tab, double* const* rows, size_t count);
+void tab_forget(gprn_ctx* c, double** d_tab);                    // d_tab null: all of them
+// rows of `nbatch` matrices starting at d_ptrs if a host copy is known (and nbatch fits), else false
+bool tab_rows(gprn_ctx* c, double** d_ptrs, int nbatch, PtrArgs* out);
+
+// the chain's two products of a tile step at 16 x 16 granularity (gemm_tile.hip); mode 0: L_{k+1,k} in place, 1: the
+// update of B_{k+1,k+1}
+int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
+                     hipStream_t stream, Signal sig, Await aw);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
                 Await aw = Await{nullptr, 0, nullptr, nullptr, 0});

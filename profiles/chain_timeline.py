@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Timeline of the factorisation's latency chain from a rocprofv3 kernel trace (CSV):
+for every diagonal-block launch, its duration, and what ran between its end and the start of the next one.
+
+    rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r2_tr -o runc -- python3 bench.py --config 2 --steps 3 --warmup 1 --blocks 1 --no-cpu --no-calc
+    python3 profiles/chain_timeline.py gpurun_out/r2_tr [first_step last_step]
+"""
+import csv, glob, sys, re
+
+d = sys.argv[1]
+f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+rows = []
+for r in csv.DictReader(open(f)):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
+rows.sort()
+diag = [i for i, r in enumerate(rows) if 'k_diag_block' in r[2]]
+print(f'{len(rows)} kernels, {len(diag)} diagonal blocks')
+# the longest run of diagonal blocks that follow each other within 300 us = one factorisation
+gaps = []
+for a, b in zip(diag[:-1], diag[1:]):
+    s0, e0, _ = rows[a]
+    s1, e1, _ = rows[b]
+    if s1 - e0 > 300e3:
+        continue
+    between = [(r[0], r[1], r[2]) for r in rows[a + 1:b]]
+    gaps.append((e0 - s0, s1 - e0, s1 - s0, between, a))
+import statistics as st
+print('diag us: median %.1f  | diag-end -> next diag-start us: median %.1f | step us: median %.1f (n = %d)' % (
+    st.median(g[0] for g in gaps) / 1e3, st.median(g[1] for g in gaps) / 1e3, st.median(g[2] for g in gaps) / 1e3, len(gaps)))
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else lo + 6
+for dd, gap, step, between, idx in gaps[lo:hi]:
+    t0 = rows[idx][0]
+    print('--- diag %.1f us, then (times relative to the diag start, us):' % (dd / 1e3))
+    for s, e, n in between:
+        m = re.search(r'k_tile_gemm<(\d+), (\d+), (\d+), (\d+), (\d+)>', n)
+        short = ('tile %sx%s w%s tri%s tag%s' % m.groups()) if m else n[:40]
+        print('    %-34s start %7.1f  end %7.1f  (%.1f)' % (short, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
