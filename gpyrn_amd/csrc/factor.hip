@@ -825,7 +825,7 @@ int ensure_tasks(gprn_ctx* c)
     const int outer = set ? std::max(outer_big, outer_small) : outer_big;
     std::vector<gprn_ctx::StepRange>& steps = c->steps[set];
     std::vector<gprn_ctx::OuterRange>& outers = c->outers[set];
-    steps.assign(T, gprn_ctx::StepRange{0, 0, 0, 0, 0});
+    steps.assign(T, gprn_ctx::StepRange{0, 0, 0, 0, 0, 0});
     outers.clear();
     for (int k0 = 0; k0 < T; k0 += outer) {
         const int k1 = std::min(T, k0 + outer);
@@ -844,10 +844,15 @@ int ensure_tasks(gprn_ctx* c)
             // columns of the panel right of step k; and of the NEXT panel its diagonal and sub-diagonal tiles
             // (j,j), (j+1,j), k1 <= j < n1 -- the tiles the chain works on there: kept up to date step by
             // step (K = 128), so that the chain never waits for a K = 512 update of the outer panel
-            for (int j = k + 1; j < std::min(T, k1 + outer); ++j)
-                for (int i = j; i < (j < k1 ? T : std::min(T, j + 2)); ++i)
+            for (int j = k + 1; j < std::min(T, k1 + outer); ++j) {
+                for (int i = j; i < (j < k1 ? T : std::min(T, j + 2)); ++i) {
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
                                          BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
+                    // ... and the diagonal tile of column k+2, which the chain's update of step k+1 writes next
+                    if (j == k + 2 && i == j) s.ncol1 = v.size() - s.upd0;
+                }
+                if (j == k + 1) s.ncol1 = v.size() - s.upd0;
+            }
             for (int i = k + 1; i < k1; ++i)
                 for (int cc = 0; cc <= k; ++cc)
                     v.push_back(TileTask{toff(i, cc, ld), toff(i, k, ld), toff(k, cc, ld), GPRN_TILE,
@@ -1232,13 +1237,22 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             } else if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
             // beside it: the rest of the panel, then the rest of the in-panel updates
             if ((rc = side_sync(k))) return rc;
-            if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
-            if (s.npanel > s.npanel_l && use_flags) {
-                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
-                                x_part_then(k)))) return rc;
+            // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
+            static int merge_panel = -1;
+            if (merge_panel < 0) { const char* e = getenv("GPRN_MERGE_PANEL"); merge_panel = e ? atoi(e) : 1; }
+            if (merge_panel && tri && use_flags) {
+                // (its last workgroup holds the launch open until L_{k+1,k} is there, see x_part_then)
+                if ((rc = launch_panel(c, c->d_tasks + s.panel0 + 1, s.npanel_l - 1, s.npanel - s.npanel_l, c->d_ptrs,
+                                       nbatch, c->ld, s1, x_part_then(k)))) return rc;
             } else {
-                if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
-                HIP_TRY(c, await(s1, k, F_MINIL));
+                if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
+                if (s.npanel > s.npanel_l && use_flags) {
+                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64, GPRN_T_PANEL,
+                                    x_part_then(k)))) return rc;
+                } else {
+                    if ((rc = tiles(s.panel0 + s.npanel_l, s.npanel - s.npanel_l, s1, TS_128x64))) return rc;
+                    HIP_TRY(c, await(s1, k, F_MINIL));
+                }
             }
             if (next_J >= 0) {                         // the other columns / rows of this panel
                 HIP_TRY(c, await(s1, next_J, F_NEXT));
@@ -1246,10 +1260,28 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             }
             // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write;
             // the flag goes up with stream3's next synchronisation kernel)
-            if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
-            if (use_flags) inner_k = k;                // raised by stream3's next synchronisation kernel
-            else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
-                                                       // chain's wait for step k is enqueued at step k + 1
+            // Column k+1 and the diagonal tile (k+2,k+2) first, in a launch of its own that raises F_INNER itself: all
+            // the chain's next step reads (L_{k+2,k+1}) or writes (its update of B_{k+2,k+2}); the other columns and
+            // the inverse's rows are next touched by stream3 itself (GPRN_SPLIT_INNER=1).  OFF by default: with one launch
+            // the chain's L kernel spends 40-107 us of every loaded step polling for the launch's last workgroup (node
+            // half-sweep of config 3, profiles/r02_chain_timeline_cfg3.txt), but stream3 is itself a serial chain of
+            // launches and one more per step costs more than the earlier flag gains (95.7 vs 103.2 sweeps/s at config 3,
+            // 566 vs 647 at config 2).  Default: one launch, the flag raised by stream3's next synchronisation kernel.
+            static int split_inner = -1;
+            if (split_inner < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner = e ? atoi(e) : 0; }
+            const size_t ncol = s.ncol1 > 0 ? s.ncol1 - 1 : 0;
+            if (split_inner && ncol > 0) {
+                const bool skip = withheld(F_INNER);
+                if ((rc = tiles(s.upd0 + 1, ncol, s1, shape_upd(ncol), GPRN_T_PANEL,
+                                use_flags && !skip ? in_kernel(k, F_INNER) : nosig))) return rc;
+                if (!use_flags) HIP_TRY(c, hipEventRecord(events[F_INNER], s1));
+                if ((rc = tiles(s.upd0 + 1 + ncol, s.nupd - 1 - ncol, s1, shape_upd(s.nupd - 1 - ncol)))) return rc;
+            } else {
+                if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
+                if (use_flags) inner_k = k;                // raised by stream3's next synchronisation kernel
+                else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
+                                                           // chain's wait for step k is enqueued at step k + 1
+            }
         }
         if ((rc = flush_inner())) return rc;           // the chain's next step must not queue behind the outer update
         if (o.nfirst + o.nnext + o.nrest == 0) continue;

@@ -90,6 +90,48 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
+// Both halves of a tile step's panel in ONE launch: tasks [0, n_l) are L_ik = B_ik X_kk^T (64 x 128 workgroups, B
+// triangular), the others X_kc = X_kk R_kc (128 x 64 workgroups, A triangular) -- two workgroups per task in either
+// form.  stream3 is the factorisation's second serial chain (synchronise, panel, in-panel update per tile step):
+// one launch less per step on it.
+__global__ __launch_bounds__(256, 2)
+void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
+                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
+                  unsigned* wait_timed_out)
+{
+    __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (64 + 128 + 32)];
+    const int ti = blockIdx.x >> 1, sub = blockIdx.x & 1;
+    const TileTask t = tasks[ti];
+    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
+    auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
+    const int c_mode = t.modes & 3, a_mode = (t.modes >> 2) & 1, b_mode = (t.modes >> 3) & 1;
+    if (ti < n_l) {                                             // rows split
+        const double* A = pick(t.a_buf) + t.a_off + (a_mode ? (size_t)sub * 64 : (size_t)sub * 64 * ld);
+        const double* B = pick(t.b_buf) + t.b_off;
+        gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sub * 64 * ld;
+        tile_mma<64, 128, 2, 2, 1, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, (sub * 64) >> 4, 0);
+    } else {                                                    // columns split
+        const double* A = pick(t.a_buf) + t.a_off;
+        const double* B = pick(t.b_buf) + t.b_off + (b_mode ? (size_t)sub * 64 : (size_t)sub * 64 * ld);
+        gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + sub * 64;
+        tile_mma<128, 64, 2, 2, 2, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, 0, (sub * 64) >> 4);
+    }
+    signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
+}
+
+int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
+                 hipStream_t stream, Signal sig)
+{
+    if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig);
+    prof_begin(c, GPRN_T_PANEL, stream);
+    hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
+                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
 // ---- the latency chain's two products of a tile step, one 16 x 16 block of the output per WAVE
 //   MODE 0:  L_{k+1,k} = B_{k+1,k} X_kk^T, in place over B_{k+1,k}; X_kk lower triangular: block column Q of the
 //            result needs k < 16 (Q + 1) only

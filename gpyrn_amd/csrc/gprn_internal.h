@@ -172,7 +172,7 @@ struct gprn_ctx {
     int stamps_T = 0;
     size_t tasks_cap = 0;
     std::vector<TileTask> h_tasks;
-    struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd; };   // per tile step: panel (L part first, then X part), in-panel update
+    struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: column k+1)
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
@@ -222,6 +222,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
                  Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},
                  int tag = TG_MISC);
+// the L part (n_l tasks) and the X part (n_x tasks) of a tile step's panel in one launch (gemm_tile.hip)
+int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
+                 hipStream_t stream, Signal sig);
 // BUF_B and BUF_X of up to GPRN_ARG_SLOTS matrices as a kernel argument
 #define GPRN_ARG_SLOTS 16
 struct PtrArgs { double* p[GPRN_ARG_SLOTS][2]; };

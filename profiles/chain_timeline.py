@@ -36,3 +36,42 @@ for dd, gap, step, between, idx in gaps[lo:hi]:
         m = re.search(r'k_tile_gemm<(\d+), (\d+), (\d+), (\d+), (\d+)>', n)
         short = ('tile %sx%s w%s tri%s tag%s' % m.groups()) if m else n[:40]
         print('    %-34s start %7.1f  end %7.1f  (%.1f)' % (short, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
+
+# ---- per factorisation (a run of diagonal blocks): how long, how many steps, how the step times are distributed
+runs, cur = [], [diag[0]]
+for a, b in zip(diag[:-1], diag[1:]):
+    if rows[b][0] - rows[a][1] > 300e3:
+        runs.append(cur); cur = []
+    cur.append(b)
+runs.append(cur)
+print('\nfactorisations (runs of diagonal blocks):')
+for r in runs[-8:]:
+    t0, t1 = rows[r[0]][0], rows[r[-1]][1]
+    steps = [(rows[b][0] - rows[a][0]) / 1e3 for a, b in zip(r[:-1], r[1:])]
+    if not steps:
+        continue
+    # batch = diagonal-block launches have one workgroup per matrix; not in the trace: report durations only
+    q = sorted(steps)
+    print('  %3d steps, %7.1f us first-diag-start -> last-diag-end; step us: min %.1f  median %.1f  p90 %.1f  max %.1f' % (
+        len(r), (t1 - t0) / 1e3, q[0], q[len(q) // 2], q[int(len(q) * 0.9)], q[-1]))
+
+# ---- the chain of the longest run, step by step: diag | wait | L | wait | U | wait (us)
+best = max(runs, key=len)
+print('\nlongest run (%d diagonal blocks), per step: diag | ->L | L | ->U | U | ->next diag   [other kernels running at the diag start]' % len(best))
+def find(after, before, pat):
+    for r in rows:
+        if r[0] >= after and r[0] < before and pat in r[2]:
+            return r
+    return None
+for a, b in zip(best[:-1], best[1:]):
+    s0, e0, _ = rows[a]
+    s1 = rows[b][0]
+    L = find(s0, s1, 'k_chain_l')
+    U = find(s0, s1, 'k_chain_u')
+    busy = sum(1 for r in rows if r[0] < s0 < r[1] and 'k_diag' not in r[2])
+    if L and U:
+        print('  %6.1f | %5.1f | %5.1f | %5.1f | %5.1f | %6.1f   = %6.1f  [%d]' % (
+            (e0 - s0) / 1e3, (L[0] - e0) / 1e3, (L[1] - L[0]) / 1e3, (U[0] - L[1]) / 1e3, (U[1] - U[0]) / 1e3,
+            (s1 - U[1]) / 1e3, (s1 - s0) / 1e3, busy))
+    else:
+        print('  %6.1f | (no chain products in this step)  = %6.1f  [%d]' % ((e0 - s0) / 1e3, (s1 - s0) / 1e3, busy))
