@@ -38,29 +38,40 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet, fp64 matrix (= fp64 vector)
 TILE = 128
 
 
-def update_flops(T, n_gp, outer=4):
-    """Algorithmic flops of the bulk-update launches of one sweep for n_gp latent GPs: the
-    K = 512 `k_tile_gemm<64,64>` launches on the look-ahead stream (csrc/factor.hip, the
-    "rest" half of each outer update: trailing SYRK tiles and inverse rows beyond the next
-    panel).  Diagonal SYRK tiles count their lower triangle only."""
-    per_gp = 0.0
+def update_flops(T, n_gp, outer=4, split=True):
+    """Algorithmic flops of one sweep's bulk-update launches for n_gp latent GPs, tile by tile as
+    csrc/factor.hip::ensure_tasks builds them: the K = 512 `k_tile_gemm<64,64,...>` launches on the look-ahead
+    stream ("rest" of each outer update: trailing SYRK tiles and inverse rows beyond the next panel; the
+    diagonal and sub-diagonal tiles of the panel after next go with the next-panel launch instead).  Diagonal
+    SYRK tiles count their lower triangle only.  Returns (bulk, ahead): with `split` the tiles the next panel's
+    update writes again -- the columns / rows of the panel after next, the diagonal and sub-diagonal tiles of
+    the one after that -- are a launch of their own (family 'update_ahead', kernel tag TG_AHEAD)."""
+    bulk = ahead = 0.0
     for k0 in range(0, T, outer):
         k1 = min(T, k0 + outer)
         n1 = min(T, k1 + outer)
+        n2 = min(T, n1 + outer)
+        n3 = min(T, n2 + outer)
         kw = (k1 - k0) * TILE
-        for i in range(n1, T):
-            per_gp += (i - n1) * 2.0 * TILE * TILE * kw            # B_ij, n1 <= j < i
-            per_gp += 2.0 * (TILE * (TILE + 1) / 2) * kw           # B_ii
-            per_gp += k0 * 2.0 * TILE * TILE * kw                  # R_ic, c < k0
+        for i in range(k1, T):
+            for j in range(k1, i + 1):
+                if j < n1 or (j < n2 and i <= j + 1):
+                    continue                                       # first / next / kept up to date step by step
+                fl = 2.0 * (TILE * (TILE + 1) / 2 if i == j else TILE * TILE) * kw
+                if split and (j < n2 or (j < n3 and i <= j + 1)):
+                    ahead += fl
+                else:
+                    bulk += fl
+            if i < n1:
+                continue
+            fl = k0 * 2.0 * TILE * TILE * kw                       # R_ic, c < k0
             for c in range(k0, k1):
-                per_gp += 2.0 * TILE * TILE * (k1 - c) * TILE      # R_ic, first touch
-        # the diagonal and sub-diagonal tiles of the panel after next are not part of "rest": the next
-        # panel's steps start on them early, so they go with the next-panel launch (csrc/factor.hip, ensure_tasks)
-        for j in range(n1, min(T, n1 + outer)):
-            per_gp -= 2.0 * (TILE * (TILE + 1) / 2) * kw
-            if j + 1 < T:
-                per_gp -= 2.0 * TILE * TILE * kw
-    return per_gp * n_gp
+                fl += 2.0 * TILE * TILE * (k1 - c) * TILE          # R_ic, first touch
+            if split and i < n2:
+                ahead += fl
+            else:
+                bulk += fl
+    return bulk * n_gp, ahead * n_gp
 
 
 def pmc_traffic():
@@ -209,7 +220,7 @@ def main():
 
     if a.warmup > 0:
         ctx.sweep(a.warmup, commit=True)
-    ctx.profile_enable(['update'])
+    ctx.profile_enable(['update', 'update_ahead'])
     block_s = []
     for _ in range(max(1, a.blocks)):
         ctx.barrier_max(0.0)                               # barrier + device sync
@@ -275,8 +286,10 @@ def main():
     if rank == 0:
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
         ms_upd, n_upd = prof['update']
+        ms_ahd, n_ahd = prof.get('update_ahead', (0.0, 0))
         T = (N + TILE - 1) // TILE
-        fl = update_flops(T, len(nodes_l) + len(weights_l)) * a.steps * len(block_s)
+        split = os.environ.get('GPRN_SPLIT_REST', '1') != '0'
+        fl, fl_ahd = (x * a.steps * len(block_s) for x in update_flops(T, len(nodes_l) + len(weights_l), split=split))
         achieved = fl / (ms_upd * 1e-3) / 1e12 if ms_upd > 0 else None
         out = {
             'metric': 'ELBO iterations/sec (N=%d, P=%d, Q=%d)' % (N, p, q),
@@ -323,6 +336,10 @@ def main():
                 'measured_mfma_ceiling': ctx.mfma_peak(2, 4000),
                 'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
                 'flops_per_launch': (fl / n_upd) if n_upd else None,
+                # the look-ahead part of the same updates (own launches, k_tile_gemm<..., TG_AHEAD>: the tiles the
+                # next panel's update writes again; they run beside that panel's "next" launch)
+                'ahead_launches': ({'launches': n_ahd, 'avg_launch_ms': ms_ahd / n_ahd, 'flops_per_launch': fl_ahd / n_ahd,
+                                    'achieved': fl_ahd / (ms_ahd * 1e-3) / 1e12} if n_ahd else None),
             },
         }
         if world == 1 and not a.no_cpu:

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('GPRN_HIP_LIB') or os.path.join(_HERE, 'libgprn_hip.so
 
 GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM = -1, -2, -3, -4, -5
 M_K, M_KLINV, M_SIGMA = 0, 1, 2
-T_NAMES = ('fill', 'build_B', 'diag', 'panel', 'update', 'lauum', 'vec')
+T_NAMES = ('fill', 'build_B', 'diag', 'panel', 'update', 'lauum', 'vec', 'update_ahead')
 TILE = 128
 
 _dp = POINTER(c_double)

@@ -8,6 +8,7 @@ void prof_begin(gprn_ctx*, int, hipStream_t) {}
 void prof_end(gprn_ctx*) {}
 int launch_tiles(gprn_ctx*, const TileTask*, size_t, double**, int, int, int, hipStream_t, int, Signal, Await, int) { return 0; }
 int launch_tile_rows(gprn_ctx*, int, double**, int, int, int, int, hipStream_t, Signal, Await) { return 0; }
+int launch_panel(gprn_ctx*, const TileTask*, size_t, size_t, double**, int, int, hipStream_t, Signal) { return 0; }
 
 __global__ __launch_bounds__(256) void k_bench(double* B, double* X, int ld, int* info, long long* total)
 {

@@ -216,8 +216,24 @@ static DeviceStreams* device_streams_acquire(int device)
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     const int prio[4] = {prio_hi, prio_lo, prio_hi, prio_hi};
+    // GPRN_RESERVE_CUS=n (experiments; default 0): the bulk, side and fourth stream are created with a CU mask that
+    // leaves the last n CUs of every XCD to the chain stream's kernels (bit i of the mask = CU i / 8 of XCD i % 8,
+    // _probe/cumask_map.hip); masked streams have no priority
+    static int reserve = -1;
+    if (reserve < 0) { const char* e = getenv("GPRN_RESERVE_CUS"); reserve = e ? atoi(e) : 0; }
+    int n_cu = 0;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    uint32_t mask[8];
+    const int per_xcd = n_cu / 8;
+    const bool masked = reserve > 0 && n_cu == 256 && reserve < per_xcd;
+    if (masked) {
+        for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
+        for (int i = 0; i < 256; ++i)
+            if (i / 8 >= per_xcd - reserve) mask[i / 32] &= ~(1u << (i % 32));
+    }
     for (int i = 0; i < 4; ++i)
-        if (hipStreamCreateWithPriority(&d->s[i], hipStreamNonBlocking, prio[i]) != hipSuccess) {
+        if ((masked && i > 0 ? hipExtStreamCreateWithCUMask(&d->s[i], 8, mask)
+                             : hipStreamCreateWithPriority(&d->s[i], hipStreamNonBlocking, prio[i])) != hipSuccess) {
             for (int j = 0; j < i; ++j) hipStreamDestroy(d->s[j]);
             delete d;
             return nullptr;
@@ -260,6 +276,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipEventCreateWithFlags(&c->ev_inner, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_resta, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
@@ -296,6 +313,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         hipEventDestroy(c->ev_inner);
         hipEventDestroy(c->ev_panel);
         hipEventDestroy(c->ev_rest);
+        hipEventDestroy(c->ev_resta);
         hipEventDestroy(c->ev_next);
         hipEventDestroy(c->ev_nodes);
         hipEventDestroy(c->ev_q1);

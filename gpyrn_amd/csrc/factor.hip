@@ -399,17 +399,19 @@ __device__ long long diag_stamps[4][NSB + 1][6];
 #else
 #define DG_STAMP(kb, i) do {} while (0)
 #endif
-#define DIAG_LDS_DOUBLES (2 * 128 * PP + 128 * PP + 2 * 16 * PP + 2 * 16 * PP + 16 * PP + 64)
+// 46.6 KB: the kernel fits on a CU beside two bulk-update workgroups (2 x (41 + 15) KB of the CU's 160) or one with the
+// small-batch pad.  (Round 1-2 form: 67 KB with the published column double-buffered -- it is read before barrier M and
+// rewritten after it, one buffer does -- and a scratch tile the pivot wave no longer needs.)
+#define DIAG_LDS_DOUBLES (128 * PP + 128 * PP + 2 * 16 * PP + 2 * 16 * PP + 64)
 
 struct DiagLds {
-    double *PA, *PB, *DG, *XD, *SC, *LINE;
+    double *PA, *PB, *DG, *XD, *LINE;
     __device__ explicit DiagLds(double* lds)
-        : PA(lds),                       // published column panels (by parity)     2 x 128 x PP
-          PB(PA + 2 * 128 * PP),         // current column after scaling by X_kb^T  128 x PP
-          DG(PB + 128 * PP),             // diagonal sub-tiles for / from the pivot wave
+        : PA(lds),                       // published column panel (before its scaling)        128 x PP
+          PB(PA + 128 * PP),             // current column after scaling by X_kb^T              128 x PP
+          DG(PB + 128 * PP),             // diagonal sub-tiles for / from the pivot wave (by parity)
           XD(DG + 2 * 16 * PP),          // X_kb by parity
-          SC(XD + 2 * 16 * PP),          // pivot wave scratch
-          LINE(SC + 16 * PP) {}
+          LINE(XD + 2 * 16 * PP) {}
 };
 
 // LDS-only workgroup barrier: global stores stay in flight across it
@@ -435,6 +437,117 @@ __device__ __forceinline__ Op16 op16_t(const double* __restrict__ T)
 #pragma unroll
     for (int s = 0; s < 4; ++s) o.v[s] = T[(4 * fk + s) * PP + fr];
     return o;
+}
+
+// one phase of a compute wave; KB and the wave's rows are compile-time constants, so every acc[][] index is one too
+// (as a loop over kb the body stayed rolled once -- the unroll pragma is a hint -- and the accumulators went to
+// scratch memory: 150 us per block instead of 23)
+template <int W, int kb>
+__device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld)
+{
+    constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
+    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    const double* xd = L.XD + (kb & 1) * 16 * PP;
+    const double* pa = L.PA;
+    double* pa_next = L.PA;                            // (read before barrier M, rewritten after it)
+    DG_STAMP(kb, 0);
+    // ---- panel(kb): S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back as L_kb
+    {
+        const Op16 xb = op16(xd);
+        Op16 a[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+            if (ROWS[pp] >= 0 && ROWS[pp] != kb) a[pp] = op16(pa + (16 * ROWS[pp]) * PP);
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp)
+            if (ROWS[pp] >= 0 && ROWS[pp] != kb) acc[pp][kb] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+                if (ROWS[pp] >= 0 && ROWS[pp] != kb)
+                    acc[pp][kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[pp].v[s], xb.v[s], acc[pp][kb], 0, 0, 0);
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            if (ROWS[pp] < 0) continue;
+            if (ROWS[pp] == kb) acc[pp][kb] = get16(L.DG + (kb & 1) * 16 * PP);
+            else put16(L.PB + (16 * ROWS[pp]) * PP, acc[pp][kb]);
+        }
+    }
+    DG_STAMP(kb, 1);
+    lds_barrier();                                     // M
+    DG_STAMP(kb, 2);
+    // ---- column kb is final: L's sub-tiles (P >= kb) from the registers; the inverse's (P < kb: S(P,kb) =
+    // X(kb,P)^T) read back transposed from the scaled column in LDS so that the stores run along rows, and
+    // zeros into the mirror block above the diagonal
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+        const int P = ROWS[pp];
+        if (P < 0) continue;
+        if (P >= kb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 16 * P + fk + 4 * t, col = 16 * kb + fr;
+                if (P > kb || col <= row) Bt[(size_t)row * ld + col] = acc[pp][kb][t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int r = fk + 4 * t;
+                Xt[(size_t)(16 * kb + r) * ld + 16 * P + fr] = L.PB[(16 * P + fr) * PP + r];
+                Xt[(size_t)(16 * P + r) * ld + 16 * kb + fr] = 0.0;
+            }
+        }
+    }
+    if (kb < NSB - 1) {
+        // ---- update(kb): S(P,Q) -= S(P,kb) S(Q,kb)^T (Q > kb; P < kb or P >= Q), S(kb,Q) = -X_kb^T S(Q,kb)^T;
+        // the operands: row blocks of the scaled column, and X_kb^T for row kb
+        Op16 rb[NSB];
+#pragma unroll
+        for (int Q = 0; Q < NSB; ++Q) {
+            bool need = Q > kb;                      // as B operand
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) need = need || (ROWS[pp] == Q && Q != kb);
+            if (need) rb[Q] = op16(L.PB + (16 * Q) * PP);
+        }
+        Op16 na[3];                                  // -A per owned row
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            const int P = ROWS[pp];
+            if (P < 0) continue;
+            const Op16 src = (P == kb) ? op16_t(xd) : rb[P];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) na[pp].v[s2] = -src.v[s2];
+        }
+        // column kb+1 first (published as the next panel), with it the diagonal sub-tile kb+2 for the pivot wave
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int Q = 0; Q < NSB; ++Q) {
+                        const int P = ROWS[pp];
+                        if (P < 0 || Q <= kb) continue;
+                        if (P == kb + 1 && Q == kb + 1) continue;          // the pivot wave's tile
+                        if (!(P == kb || P < kb || P >= Q)) continue;
+                        const int which = (Q == kb + 1) ? 0 : ((Q == kb + 2 && P == Q) ? 1 : 2);
+                        if (which != pass) continue;
+                        acc[pp][Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[pp].v[s2], rb[Q].v[s2], acc[pp][Q], 0, 0, 0);
+                    }
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                const int P = ROWS[pp];
+                if (P < 0) continue;
+                if (pass == 0 && kb + 1 < NSB && !(P == kb + 1)) put16(pa_next + (16 * P) * PP, acc[pp][kb + 1]);
+                if (pass == 1 && kb + 2 < NSB && P == kb + 2) put16(L.DG + (kb & 1) * 16 * PP, acc[pp][kb + 2]);
+            }
+        }
+    }
+    DG_STAMP(kb, 3);
+    lds_barrier();                                     // E
+    DG_STAMP(kb, 4);
 }
 
 template <int W>
@@ -471,110 +584,10 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     lds_barrier();                                  // (the pivot wave factored sub-tile 0 in between)
     DG_STAMP(NSB, 3);
 
-#pragma unroll
-    for (int kb = 0; kb < NSB; ++kb) {
-        const double* xd = L.XD + (kb & 1) * 16 * PP;
-        const double* pa = L.PA + (kb & 1) * 128 * PP;
-        double* pa_next = L.PA + ((kb + 1) & 1) * 128 * PP;
-        DG_STAMP(kb, 0);
-        // ---- panel(kb): S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back as L_kb
-        {
-            const Op16 xb = op16(xd);
-            Op16 a[3];
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
-                if (ROWS[pp] >= 0 && ROWS[pp] != kb) a[pp] = op16(pa + (16 * ROWS[pp]) * PP);
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
-                if (ROWS[pp] >= 0 && ROWS[pp] != kb) acc[pp][kb] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-                    if (ROWS[pp] >= 0 && ROWS[pp] != kb)
-                        acc[pp][kb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[pp].v[s], xb.v[s], acc[pp][kb], 0, 0, 0);
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                if (ROWS[pp] < 0) continue;
-                if (ROWS[pp] == kb) acc[pp][kb] = get16(L.DG + (kb & 1) * 16 * PP);
-                else put16(L.PB + (16 * ROWS[pp]) * PP, acc[pp][kb]);
-            }
-        }
-        DG_STAMP(kb, 1);
-        lds_barrier();                                     // M
-        DG_STAMP(kb, 2);
-        // ---- column kb is final: L's sub-tiles (P >= kb) from the registers; the inverse's (P < kb: S(P,kb) =
-        // X(kb,P)^T) read back transposed from the scaled column in LDS so that the stores run along rows, and
-        // zeros into the mirror block above the diagonal
-#pragma unroll
-        for (int pp = 0; pp < 3; ++pp) {
-            const int P = ROWS[pp];
-            if (P < 0) continue;
-            if (P >= kb) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int row = 16 * P + fk + 4 * t, col = 16 * kb + fr;
-                    if (P > kb || col <= row) Bt[(size_t)row * ld + col] = acc[pp][kb][t];
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int r = fk + 4 * t;
-                    Xt[(size_t)(16 * kb + r) * ld + 16 * P + fr] = L.PB[(16 * P + fr) * PP + r];
-                    Xt[(size_t)(16 * P + r) * ld + 16 * kb + fr] = 0.0;
-                }
-            }
-        }
-        if (kb < NSB - 1) {
-            // ---- update(kb): S(P,Q) -= S(P,kb) S(Q,kb)^T (Q > kb; P < kb or P >= Q), S(kb,Q) = -X_kb^T S(Q,kb)^T;
-            // the operands: row blocks of the scaled column, and X_kb^T for row kb
-            Op16 rb[NSB];
-#pragma unroll
-            for (int Q = 0; Q < NSB; ++Q) {
-                bool need = Q > kb;                      // as B operand
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) need = need || (ROWS[pp] == Q && Q != kb);
-                if (need) rb[Q] = op16(L.PB + (16 * Q) * PP);
-            }
-            Op16 na[3];                                  // -A per owned row
-#pragma unroll
-            for (int pp = 0; pp < 3; ++pp) {
-                const int P = ROWS[pp];
-                if (P < 0) continue;
-                const Op16 src = (P == kb) ? op16_t(xd) : rb[P];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) na[pp].v[s2] = -src.v[s2];
-            }
-            // column kb+1 first (published as the next panel), with it the diagonal sub-tile kb+2 for the pivot wave
-#pragma unroll
-            for (int pass = 0; pass < 3; ++pass) {
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                    for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                        for (int Q = 0; Q < NSB; ++Q) {
-                            const int P = ROWS[pp];
-                            if (P < 0 || Q <= kb) continue;
-                            if (P == kb + 1 && Q == kb + 1) continue;          // the pivot wave's tile
-                            if (!(P == kb || P < kb || P >= Q)) continue;
-                            const int which = (Q == kb + 1) ? 0 : ((Q == kb + 2 && P == Q) ? 1 : 2);
-                            if (which != pass) continue;
-                            acc[pp][Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[pp].v[s2], rb[Q].v[s2], acc[pp][Q], 0, 0, 0);
-                        }
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp) {
-                    const int P = ROWS[pp];
-                    if (P < 0) continue;
-                    if (pass == 0 && kb + 1 < NSB && !(P == kb + 1)) put16(pa_next + (16 * P) * PP, acc[pp][kb + 1]);
-                    if (pass == 1 && kb + 2 < NSB && P == kb + 2) put16(L.DG + (kb & 1) * 16 * PP, acc[pp][kb + 2]);
-                }
-            }
-        }
-        DG_STAMP(kb, 3);
-        lds_barrier();                                     // E
-        DG_STAMP(kb, 4);
-    }
+    diag_phase<W, 0>(acc, L, Bt, Xt, ld); diag_phase<W, 1>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 2>(acc, L, Bt, Xt, ld); diag_phase<W, 3>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 4>(acc, L, Bt, Xt, ld); diag_phase<W, 5>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
 __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Xt, int ld, int* __restrict__ info, int slot, int pivot0)
@@ -589,7 +602,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Xt, int ld, 
 #pragma unroll 1
     for (int kb = 0; kb < NSB; ++kb) {
         const double* xd = L.XD + (kb & 1) * 16 * PP;
-        const double* pa = L.PA + (kb & 1) * 128 * PP;
+        const double* pa = L.PA;
         const int n = kb + 1;
         DG_STAMP(kb, 0);
         v4d tt = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -634,8 +647,10 @@ __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, g
 }
 
 // PTRS: the two pointers per matrix come as kernel arguments (launch_diag), else from the table
+// (one wave per SIMD: the register-resident tile needs ~290 VGPRs per lane; without the second bound the compiler sizes
+// the allocation for the three workgroups per CU the LDS would allow and spills)
 template <bool ARGS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
                   unsigned* wait_timed_out)
@@ -860,7 +875,7 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
             s.nupd = v.size() - s.upd0;
         }
-        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0};
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
         // pass 0 ("first"): the next panel's first column of B / first row of R -- what stream3's half of
@@ -898,12 +913,24 @@ int ensure_tasks(gprn_ctx* c)
             if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
             else if (pass == 1) { o.next0 = begin; o.nnext = v.size() - begin; }
             else {
+                // "rest" in two parts: A = what the NEXT panel's outer update writes again (the columns / rows of the
+                // panel after next, and of the one after that its diagonal and sub-diagonal tiles), B = the others.
+                // The next panel's "first" and "next" launches wait for A only (F_RESTA).
+                const int n3 = std::min(T, n2 + outer);
+                auto in_a = [&](const TileTask& t) {
+                    const int i = (int)(t.c_off / ((int64_t)GPRN_TILE * ld)), j = (int)((t.c_off % ld) / GPRN_TILE);
+                    return t.c_buf == BUF_B ? (j < n2 || (j < n3 && i <= j + 1)) : i < n2;
+                };
+                std::stable_partition(v.begin() + begin, v.end(), in_a);
+                size_t na = 0;
+                while (begin + na < v.size() && in_a(v[begin + na])) ++na;
                 // Workgroups are dispatched in task order and are not preempted: with the short
                 // first-touch tasks (K = 128..384) in front, the first slots free up after a
                 // quarter of a full task instead of all at once.
-                std::stable_sort(v.begin() + begin, v.end(),
-                                 [](const TileTask& a, const TileTask& b) { return a.klen < b.klen; });
-                o.rest0 = begin; o.nrest = v.size() - begin;
+                auto by_klen = [](const TileTask& a, const TileTask& b) { return a.klen < b.klen; };
+                std::stable_sort(v.begin() + begin, v.begin() + begin + na, by_klen);
+                std::stable_sort(v.begin() + begin + na, v.end(), by_klen);
+                o.rest0 = begin; o.nrest = v.size() - begin; o.nrestA = na;
             }
         }
         outers.push_back(o);
@@ -943,7 +970,7 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
     if (wait_flag) spin_until(wait_flag, wait_value, timed_out);
 }
 
-#define GPRN_FLAG_KINDS 9           // flag kinds per tile step / outer panel (factor_invert_split)
+#define GPRN_FLAG_KINDS 10          // flag kinds per tile step / outer panel (factor_invert_split)
 
 // Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
 // beside them: every switch that serialises kernels or starves the hardware queues means events.
@@ -1047,7 +1074,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     const int use_flags = factor_use_flags(c);
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_KINDS };
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_RESTA, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
@@ -1065,7 +1092,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         c->sig_budget_ms = c->wait_budget_ms;
     }
     const unsigned epoch = ++c->epoch;
-    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr, nullptr};
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr, nullptr, c->ev_resta};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
@@ -1290,21 +1317,34 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // and sub-diagonal tiles); bulk stream: the rest of the next panel, then everything beyond.  The
         // chain itself goes straight on with the next diagonal block.
         HIP_TRY(c, raise(s1, (int)J, F_PANEL));
-        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, F_REST));      // same tiles as the previous panel's rest / next
+        // GPRN_SPLIT_REST=1 (default): the previous panel's "rest" went out as two launches and only the first (A: the
+        // tiles this panel's outer update writes again) is waited for here; "next" runs on a stream of its own instead
+        // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
+        static int split_rest = -1;
+        if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
+        const bool sr = split_rest && c->stream4 && !two_streams;
+        hipStream_t sn = sr ? c->stream4 : s2;
+        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
         if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
         if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, raise(s1, (int)J, F_FIRST));
         if (o.nfirst > 0) first_J = (int)J;
-        HIP_TRY(c, await(s2, (int)J, F_PANEL));
-        if ((rc = tiles(o.next0, o.nnext, s2, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
-        HIP_TRY(c, raise(s2, (int)J, F_NEXT));
+        HIP_TRY(c, await(sn, (int)J, F_PANEL));
+        if (sr && rest_J >= 0) HIP_TRY(c, await(sn, rest_J, F_RESTA));
+        if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        HIP_TRY(c, raise(sn, (int)J, F_NEXT));
         if (o.nnext > 0) next_J = (int)J;
         if (o.nrest) {
             // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
             // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
             static int bulk_shape = -1;
             if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
-            if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
+            if (sr) {
+                HIP_TRY(c, await(s2, (int)J, F_PANEL));
+                if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
+                HIP_TRY(c, raise(s2, (int)J, F_RESTA));
+                if ((rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
+            } else if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
             HIP_TRY(c, raise(s2, (int)J, F_REST));
             rest_J = (int)J;
         }

@@ -48,7 +48,7 @@
 // block are skipped -- 28 of 64 block products.
 // TAG only names the launch family in profiles (rocprofv3 reports one row per instantiation):
 // TG_PANEL panel products, TG_INNER in-panel K=128 updates, TG_NEXT next-panel K=512 updates,
-// TG_BULK bulk K=512 updates, TG_MISC the rest.
+// TG_BULK bulk K=512 updates, TG_AHEAD their look-ahead part, TG_MISC the rest.
 template <int BM, int BN, int NW, int TRI, int TAG>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
@@ -326,7 +326,7 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     static int pad_fams = -1;                      // GPRN_PAD_FAMS: bit per family that gets the pad (default: the
                                                    // bulk update and the X^T X product; the next-panel launches measured
                                                    // slightly better without it)
-    if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_LAUUM)); }
+    if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_UPDATE_AHEAD) | (1 << GPRN_T_LAUUM)); }
     static int pad_all = -1;                       // GPRN_PAD_ALL=1 (probes): pad on every stream
     if (pad_all < 0) { const char* e = getenv("GPRN_PAD_ALL"); pad_all = e ? atoi(e) : 0; }
     // Launches over one or two matrices (node half-sweep, sharded runs) ask for 64 KiB instead: with
@@ -363,6 +363,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // bulk of an outer update, K = 512
     case TS_64x64 * 8 + TG_BULK: GO(64, 64, 0, TG_BULK); break;
     case TS_128x128 * 8 + TG_BULK: GO(128, 128, 0, TG_BULK); break;
+    // ... its look-ahead part (what the next panel's outer update writes again), a launch of its own
+    case TS_64x64 * 8 + TG_AHEAD: GO(64, 64, 0, TG_AHEAD); break;
+    case TS_128x128 * 8 + TG_AHEAD: GO(128, 128, 0, TG_AHEAD); break;
     // X^T X, prediction products, diagnostics
     case TS_128x128 * 8 + TG_MISC: GO(128, 128, 0, TG_MISC); break;
     case TS_64x64 * 8 + TG_MISC: GO(64, 64, 0, TG_MISC); break;

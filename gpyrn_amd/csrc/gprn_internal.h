@@ -87,7 +87,7 @@ struct gprn_ctx {
     hipStream_t stream4 = nullptr;   // the chain's two tile launches of a step, dispatched ahead of their inputs
     int chain_streams = -1;          // 1: the chain runs on two streams (diagonal blocks | tile launches) whose
                                      // kernels wait for each other in-kernel; 0: one stream; -1: not probed yet
-    hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr;
+    hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr, ev_resta = nullptr;
     hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
     hipStream_t prof_stream = nullptr;
     std::string err;
@@ -176,7 +176,7 @@ struct gprn_ctx {
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
-    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1; };  // per outer panel of GPRN_OUTER tiles
+    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA; };  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
@@ -202,7 +202,7 @@ enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
 // launch family of a tile launch: a template tag of k_tile_gemm, so that a kernel trace reports every
 // family under its own kernel name (panel products, in-panel K=128 updates, next-panel K=512 updates,
 // bulk K=512 updates, everything else)
-enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4 };
+enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4, TG_AHEAD = 5 };
 // Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event

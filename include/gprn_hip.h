@@ -179,7 +179,9 @@ int gprn_get_logdet_K(gprn_ctx* ctx, double* out /* q+q*p */);
  * milliseconds spent in, and launches of, each kernel family since the last
  * reset; only collected while profiling is enabled (adds event records). */
 enum { GPRN_T_FILL = 0, GPRN_T_BUILD_B = 1, GPRN_T_DIAG = 2, GPRN_T_PANEL = 3,
-       GPRN_T_UPDATE = 4, GPRN_T_LAUUM = 5, GPRN_T_VEC = 6, GPRN_T_COUNT = 7 };
+       GPRN_T_UPDATE = 4, GPRN_T_LAUUM = 5, GPRN_T_VEC = 6,
+       GPRN_T_UPDATE_AHEAD = 7,   /* the part of a trailing update the next panel's update writes again (own launch) */
+       GPRN_T_COUNT = 8 };
 int gprn_profile_enable(gprn_ctx* ctx, int family_mask);   /* bit f = time family GPRN_T_f; 0 = off */
 int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
                       int64_t* launches /*GPRN_T_COUNT*/, int reset);
