@@ -20,6 +20,7 @@
 #include "tile_mma.h"
 
 #include <math.h>
+#include <time.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -1189,10 +1190,54 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         f.swap(c->chain_started);
         if ((rc = f())) return rc;
     }
+    int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
+    auto do_outer = [&](int Jp) -> int {
+        const size_t J = (size_t)Jp;
+        const gprn_ctx::OuterRange& o = c->outers[set][J];
+        pending_outer = -1;
+        // Outer update of panel J (K = its width).  stream3, which has seen every tile of the panel: what
+        // the chain touches first in the next panel (its first column of B and first row of R, its diagonal
+        // and sub-diagonal tiles); bulk stream: the rest of the next panel, then everything beyond.  The
+        // chain itself goes straight on with the next diagonal block.
+        HIP_TRY(c, raise(s1, (int)J, F_PANEL));
+        // GPRN_SPLIT_REST=1 (default): the previous panel's "rest" went out as two launches and only the first (A: the
+        // tiles this panel's outer update writes again) is waited for here; "next" runs on a stream of its own instead
+        // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
+        static int split_rest = -1;
+        if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
+        const bool sr = split_rest && c->stream4 && !two_streams;
+        hipStream_t sn = sr ? c->stream4 : s2;
+        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
+        if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+        if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        HIP_TRY(c, raise(s1, (int)J, F_FIRST));
+        if (o.nfirst > 0) first_J = (int)J;
+        HIP_TRY(c, await(sn, (int)J, F_PANEL));
+        if (sr && rest_J >= 0) HIP_TRY(c, await(sn, rest_J, F_RESTA));
+        if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        HIP_TRY(c, raise(sn, (int)J, F_NEXT));
+        if (o.nnext > 0) next_J = (int)J;
+        if (o.nrest) {
+            // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
+            // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
+            static int bulk_shape = -1;
+            if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
+            if (sr) {
+                HIP_TRY(c, await(s2, (int)J, F_PANEL));
+                if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
+                HIP_TRY(c, raise(s2, (int)J, F_RESTA));
+                if ((rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
+            } else if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
+            HIP_TRY(c, raise(s2, (int)J, F_REST));
+            rest_J = (int)J;
+        }
+            return GPRN_OK;
+    };
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
         for (int k = o.k0; k < o.k1; ++k) {
             const gprn_ctx::StepRange& s = c->steps[set][k];
+            if (pending_outer >= 0 && (use_chain || s.npanel_l == 0) && (rc = do_outer(pending_outer))) return rc;
             if (use_chain && s.npanel_l > 0) {
                 // stream3's half of the step; diag(k), L_{k+1,k} and B_{k+1,k+1} are k_chain's
                 if (first_J >= 0) first_J = -1;        // (k_chain waits for F_FIRST itself)
@@ -1242,8 +1287,19 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             }
             // L_{k+1,k} reads what stream3's in-panel update of step k-1 wrote: in the flag schedule its
             // two workgroups per matrix poll that flag themselves (a stream wait is a 5 us kernel of its own)
-            const bool spin = use_flags && k > 0;
-            if (k > 0 && !spin) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            // ... when the chain is what bounds the phase (one or two matrices); with more, the phase is bound by the
+            // tile kernels' throughput and 8 x batch resident 512-thread workgroups that only poll (80 us of every
+            // loaded step, 139 VGPRs per lane) keep bulk workgroups off their CUs: a one-wave kernel waits instead.
+            // GPRN_SPIN_MAX_BATCH overrides the limit (default 2).
+            static int spin_max = -1;
+            if (spin_max < 0) { const char* e = getenv("GPRN_SPIN_MAX_BATCH"); spin_max = e ? atoi(e) : 2; }
+            const bool spin = use_flags && k > 0 && (nbatch <= spin_max || two_streams);
+            if (use_flags && k > 0 && !spin) {
+                hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, s0, (unsigned*)nullptr, 0u,
+                                   (const unsigned*)(slot(k - 1, F_INNER) + 1), epoch, timed_out);
+                HIP_TRY(c, hipGetLastError());
+            }
+            if (k > 0 && !use_flags) HIP_TRY(c, await(s0, k - 1, F_INNER));
             Await l_waits = spin ? in_kernel_wait(k - 1, F_INNER) : noaw;
             if (two_streams) {
                 if (spin) { l_waits.flag2 = slot(k, F_DIAG) + 1; l_waits.value2 = epoch; }
@@ -1262,6 +1318,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, sc,
                                            two_streams ? in_kernel(k, F_U) : nosig, noaw))) return rc;
             } else if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
+            if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;    // the previous panel's trailing update
             // beside it: the rest of the panel, then the rest of the in-panel updates
             if ((rc = side_sync(k))) return rc;
             // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
@@ -1312,43 +1369,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         }
         if ((rc = flush_inner())) return rc;           // the chain's next step must not queue behind the outer update
         if (o.nfirst + o.nnext + o.nrest == 0) continue;
-        // Outer update of panel J (K = its width).  stream3, which has seen every tile of the panel: what
-        // the chain touches first in the next panel (its first column of B and first row of R, its diagonal
-        // and sub-diagonal tiles); bulk stream: the rest of the next panel, then everything beyond.  The
-        // chain itself goes straight on with the next diagonal block.
-        HIP_TRY(c, raise(s1, (int)J, F_PANEL));
-        // GPRN_SPLIT_REST=1 (default): the previous panel's "rest" went out as two launches and only the first (A: the
-        // tiles this panel's outer update writes again) is waited for here; "next" runs on a stream of its own instead
-        // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
-        static int split_rest = -1;
-        if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
-        const bool sr = split_rest && c->stream4 && !two_streams;
-        hipStream_t sn = sr ? c->stream4 : s2;
-        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
-        if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
-        if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
-        HIP_TRY(c, raise(s1, (int)J, F_FIRST));
-        if (o.nfirst > 0) first_J = (int)J;
-        HIP_TRY(c, await(sn, (int)J, F_PANEL));
-        if (sr && rest_J >= 0) HIP_TRY(c, await(sn, rest_J, F_RESTA));
-        if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
-        HIP_TRY(c, raise(sn, (int)J, F_NEXT));
-        if (o.nnext > 0) next_J = (int)J;
-        if (o.nrest) {
-            // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
-            // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
-            static int bulk_shape = -1;
-            if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
-            if (sr) {
-                HIP_TRY(c, await(s2, (int)J, F_PANEL));
-                if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
-                HIP_TRY(c, raise(s2, (int)J, F_RESTA));
-                if ((rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
-            } else if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
-            HIP_TRY(c, raise(s2, (int)J, F_REST));
-            rest_J = (int)J;
-        }
+        // The outer update of this panel is ENQUEUED after the chain's three launches of the next panel's first step
+        // (do_outer below): its dozen stream operations and launches take the host 60-100 us, during which the chain
+        // stream ran dry at every panel boundary (profiles/r02_chain_timeline_cfg3.txt).
+        pending_outer = (int)J;
     }
+    if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;
     if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
@@ -1385,7 +1411,26 @@ int factor_check_waits(gprn_ctx* c)
     return GPRN_OK;
 }
 
+static int factor_invert_impl(gprn_ctx* c, int nbatch);
+
+// GPRN_TIME_ENQUEUE=1 (probes): host time spent enqueueing factorisations, printed every 64 calls
 int factor_invert(gprn_ctx* c, int nbatch)
+{
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GPRN_TIME_ENQUEUE"); on = e ? atoi(e) : 0; }
+    if (!on) return factor_invert_impl(c, nbatch);
+    static double total = 0.0;
+    static int calls = 0;
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int rc = factor_invert_impl(c, nbatch);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    total += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    if (++calls % 64 == 0) fprintf(stderr, "[gprn] host enqueue of a factorisation: %.3f ms on average over %d calls (T = %d, batch %d)\n", total / calls, calls, c->T, nbatch);
+    return rc;
+}
+
+static int factor_invert_impl(gprn_ctx* c, int nbatch)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;

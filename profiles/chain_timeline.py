@@ -75,3 +75,23 @@ for a, b in zip(best[:-1], best[1:]):
             (s1 - U[1]) / 1e3, (s1 - s0) / 1e3, busy))
     else:
         print('  %6.1f | (no chain products in this step)  = %6.1f  [%d]' % ((e0 - s0) / 1e3, (s1 - s0) / 1e3, busy))
+
+# ---- what runs while the chain stands still after a step's update (gaps > 30 us in the longest run)
+print('\nkernels running between the end of a step\'s update and the start of the next diagonal block (gaps > 30 us):')
+shown = 0
+for a, b in zip(best[:-1], best[1:]):
+    s0 = rows[a][0]; s1 = rows[b][0]
+    U = find(s0, s1, 'k_chain_u')
+    if not U or s1 - U[1] < 30e3 or shown >= 3:
+        continue
+    shown += 1
+    print('  gap %.1f us after the step that started at %.1f us of the run:' % ((s1 - U[1]) / 1e3, (s0 - rows[best[0]][0]) / 1e3))
+    agg = {}
+    for r in rows:
+        if r[1] > U[1] and r[0] < s1:
+            m = TILE_RE.search(r[2]) if 'TILE_RE' in globals() else None
+            key = r[2][:60]
+            e = agg.setdefault(key, [0, 0.0, 1e18, 0])
+            e[0] += 1; e[1] += (min(r[1], s1) - max(r[0], U[1])) / 1e3; e[2] = min(e[2], r[0]); e[3] = max(e[3], r[1])
+    for k, e in sorted(agg.items(), key=lambda kv: kv[1][2]):
+        print('      %-62s x%d  first start %+7.1f  last end %+7.1f (us rel. to the update\'s end)' % (k, e[0], (e[2] - U[1]) / 1e3, (e[3] - U[1]) / 1e3))

@@ -3,7 +3,8 @@
 
 Every launch family of the tile kernel is its own instantiation now (last template argument of
 `k_tile_gemm<BM, BN, waves, TRI, TAG>`: 0 panel products, 1 in-panel K=128 updates, 2 next-panel K=512 updates,
-3 bulk K=512 updates, 4 X^T X / prediction / diagnostics), so a kernel trace isolates the bulk launches by name.
+3 bulk K=512 updates, 4 X^T X / prediction / diagnostics, 5 the look-ahead part of the bulk updates), so a kernel
+trace isolates the bulk launches by name.
 
     # on the GPU box (rocprofv3: cd /tmp && export TMPDIR=/tmp first)
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2_prof -o runc -- python3 bench.py --no-cpu
@@ -28,7 +29,8 @@ import re
 import sys
 
 FAMILY = {'0': 'panel products (K=128, triangular X_kk)', '1': 'in-panel updates (K=128)',
-          '2': 'next-panel updates (K=512)', '3': 'bulk updates (K=512)', '4': 'X^T X, prediction, diagnostics'}
+          '2': 'next-panel updates (K=512)', '3': 'bulk updates (K=512)', '4': 'X^T X, prediction, diagnostics',
+          '5': 'bulk updates, look-ahead part (K=512)'}
 TILE = re.compile(r'k_tile_gemm<(\d+), (\d+), (\d+), (\d+), (\d+)>')
 N_SIMD = 256 * 4
 
