@@ -288,7 +288,8 @@ def main():
         ms_upd, n_upd = prof['update']
         ms_ahd, n_ahd = prof.get('update_ahead', (0.0, 0))
         T = (N + TILE - 1) // TILE
-        split = os.environ.get('GPRN_SPLIT_REST', '1') != '0'
+        sr_env = os.environ.get('GPRN_SPLIT_REST', '1')           # csrc/factor.hip: two launches up to 64 tile steps
+        split = sr_env not in ('0',) and (sr_env == '2' or T <= 64)
         fl, fl_ahd = (x * a.steps * len(block_s) for x in update_flops(T, len(nodes_l) + len(weights_l), split=split))
         achieved = fl / (ms_upd * 1e-3) / 1e12 if ms_upd > 0 else None
         out = {

@@ -781,6 +781,26 @@ void k_chain(double* const* __restrict__ ptrs, int ld, int T, int outer, int* __
 #undef STAMP
 }
 
+// GPRN_CHAIN=2: every diagonal block of a matrix by ONE resident workgroup -- no dispatch and no search for a CU
+// between tile steps; it waits in-kernel for the flag of the previous step's update (F_U) and raises F_DIAG itself.
+// The step's two products stay launches of their own on the fourth stream (the two-stream form of the chain).
+template <bool ARGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_diag_chain(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int T, int* __restrict__ info,
+                  unsigned* sig, int kinds, int f_diag, int f_u, unsigned epoch, unsigned* timed_out)
+{
+    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    const int slot = blockIdx.x;
+    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    for (int k = 0; k < T; ++k) {
+        if (k > 0) await_flag(sig + ((size_t)(k - 1) * kinds + f_u) * 2 + 1, epoch, timed_out);
+        const size_t dk = ((size_t)k * GPRN_TILE) * ld + (size_t)k * GPRN_TILE;
+        diag_tile(lds, (gptr_t)(Bm + dk), (gptr_t)(Xm + dk), ld, info, slot, k * GPRN_TILE);
+        chain_publish(sig + ((size_t)k * kinds + f_diag) * 2 + 1, epoch);
+    }
+}
+
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
                 Signal sig, Await aw)
 {
@@ -1153,7 +1173,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // step is no shorter (measured 86 vs 97 sweeps/s at config 3, 365 vs 423 at config 2).
     static int chain_env = -1;
     if (chain_env < 0) { const char* e = getenv("GPRN_CHAIN"); chain_env = e ? atoi(e) : 0; }
-    const bool use_chain = use_flags && chain_env && c->T > 1;
+    const bool use_chain = use_flags && chain_env == 1 && c->T > 1;
     static int stamps_env = -1;                    // GPRN_CHAIN_STAMPS=1: clock stamps of matrix 0's chain (probes)
     if (stamps_env < 0) { const char* e = getenv("GPRN_CHAIN_STAMPS"); stamps_env = e ? atoi(e) : 0; }
     if (use_chain && stamps_env && c->stamps_T < c->T) {
@@ -1184,7 +1204,20 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // and operand latency, not its dispatch); default: one stream
     static int cs_env = -1;
     if (cs_env < 0) { const char* e = getenv("GPRN_CHAIN_STREAMS"); cs_env = e ? atoi(e) : 0; }
-    const bool two_streams = use_flags && !use_chain && cs_env && factor_probe_streams(c) == 1;
+    const bool persist = use_flags && chain_env == 2 && c->T > 1 && factor_probe_streams(c) == 1;
+    const bool two_streams = use_flags && !use_chain && (cs_env || persist) && factor_probe_streams(c) == 1;
+    if (persist) {
+        prof_begin(c, GPRN_T_DIAG, s0);
+        PtrArgs pa;
+        if (tab_rows(c, c->d_ptrs, nbatch, &pa))
+            hipLaunchKernelGGL(k_diag_chain<true>, dim3(nbatch), dim3(256), 0, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
+                               c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_U, epoch, timed_out);
+        else
+            hipLaunchKernelGGL(k_diag_chain<false>, dim3(nbatch), dim3(256), 0, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
+                               c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_U, epoch, timed_out);
+        prof_end(c);
+        HIP_TRY(c, hipGetLastError());
+    }
     if (!use_chain && !use_flags && c->chain_started) {    // event schedule: nothing to gate it on
         std::function<int()> f;
         f.swap(c->chain_started);
@@ -1205,7 +1238,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
         static int split_rest = -1;
         if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
-        const bool sr = split_rest && c->stream4 && !two_streams;
+        // (measured +2.1 % sweeps/s at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to
+        // 64 tile steps by default, GPRN_SPLIT_REST=2 forces it)
+        const bool sr = split_rest && c->stream4 && !two_streams && (split_rest >= 2 || c->T <= 64);
         hipStream_t sn = sr ? c->stream4 : s2;
         if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
         if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
@@ -1267,7 +1302,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // (arguments, task and pointer loads done, workgroups resident) while its predecessor still runs,
             // instead of after its completion has travelled through the stream
             const Await after_u = (two_streams && k > 0) ? in_kernel_wait(k - 1, F_U) : noaw;
-            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), after_u))) return rc;
+            if (!persist && (rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), after_u))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             if (use_flags && k == 0 && c->chain_started) {
                 // work handed over by the caller for the bulk stream (run_phase: the previous phase's X^T X
