@@ -58,7 +58,9 @@ def _spd(n, rng, cond_shift=1.0):
         + cond_shift * np.eye(n)
 
 
-@pytest.mark.parametrize('n,batch', [(128, 1), (256, 2), (640, 3)])
+# (384, 18): more matrices than the chain's kernels take pointers for as kernel arguments (GPRN_ARG_SLOTS = 16): their
+# pointer-table forms run
+@pytest.mark.parametrize('n,batch', [(128, 1), (256, 2), (640, 3), (384, 18)])
 def test_factor_invert(ctx, n, batch):
     rng = np.random.RandomState(n)
     A = np.array([_spd(n, rng, 1.0 + b) for b in range(batch)])
