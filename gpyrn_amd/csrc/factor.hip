@@ -570,13 +570,13 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
                 const double v = img ? img[(P * (P + 1) / 2 + Q) * 256 + (fk + 4 * t) * 16 + fr] : Bt[(size_t)row * ld + col];
                 acc[pp][Q][t] = (Q < P || col <= row) ? v : 0.0;
             }
-    // publish column 0 and the diagonal sub-tiles 0 and 1 as they are
+    // publish column 0 and the diagonal sub-tile 1 as they are
 #pragma unroll
     for (int pp = 0; pp < 3; ++pp) {
         const int P = ROWS[pp];
         if (P < 0) continue;
         put16(L.PA + (16 * P) * PP, acc[pp][0]);
-        if (P < 2) put16(L.DG + P * 16 * PP, acc[pp][P]);
+        if (P == 1) put16(L.DG + 16 * PP, acc[pp][1]);      // (sub-tile 0: the pivot wave fetches it itself)
     }
     DG_STAMP(NSB, 0);
     lds_barrier();
@@ -591,13 +591,20 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
-__device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Xt, int ld, int* __restrict__ info, int slot, int pivot0)
+__device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, int* __restrict__ info, int slot,
+                                           int pivot0, const double* __restrict__ img)
 {
     DG_STAMP(NSB, 0);
-    lds_barrier();
-    DG_STAMP(NSB, 1);
-    base16(L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
+    {   // sub-tile (0,0) straight from memory and factored while the compute waves still fetch theirs
+        const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+        v4d c0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c0[t] = img ? img[(fk + 4 * t) * 16 + fr] : Bt[(size_t)(fk + 4 * t) * ld + fr];
+        DG_STAMP(NSB, 1);
+        base16_regs(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
+    }
     DG_STAMP(NSB, 2);
+    lds_barrier();
     lds_barrier();
     DG_STAMP(NSB, 3);
 #pragma unroll 1
@@ -644,7 +651,7 @@ __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, g
     if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, img);
     else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, img);
     else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, img);
-    else diag_pivot(L, Xt, ld, info, slot, pivot0);
+    else diag_pivot(L, Bt, Xt, ld, info, slot, pivot0, img);
 }
 
 // PTRS: the two pointers per matrix come as kernel arguments (launch_diag), else from the table
