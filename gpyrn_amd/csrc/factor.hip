@@ -329,39 +329,6 @@ __device__ __forceinline__ void base16_lanes(double* __restrict__ St /* pitch PP
     }
 }
 
-// acc -= A B^T over K = 16: A rows at At (element (m,k) = At[m*as_r + k*as_k]), B rows at Bt (pitch PP)
-__device__ __forceinline__ void sub_abt(v4d& acc, const double* __restrict__ At, int as_r, int as_k,
-                                        const double* __restrict__ Bt)
-{
-    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
-    double af[4], bf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        af[s] = -At[fr * as_r + (4 * s + fk) * as_k];
-        bf[s] = Bt[fr * PP + 4 * s + fk];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], acc, 0, 0, 0);
-}
-
-// r = A B^T over K = 16 (A rows at At pitch PP, B rows at Bt pitch PP)
-__device__ __forceinline__ v4d mul_abt(const double* __restrict__ At, const double* __restrict__ Bt)
-{
-    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
-    v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
-    double af[4], bf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        af[s] = At[fr * PP + 4 * s + fk];
-        bf[s] = Bt[fr * PP + 4 * s + fk];
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        r = __builtin_amdgcn_mfma_f64_16x16x4f64(af[s], bf[s], r, 0, 0, 0);
-    return r;
-}
-
 // 16x16 tile in MFMA C/D layout <-> LDS image [row][col], pitch PP
 __device__ __forceinline__ void put16(double* __restrict__ T, const v4d& v)
 {
