@@ -120,11 +120,24 @@ void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
+__global__ void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
+                             unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
+                             unsigned* wait_timed_out);     // the same panel at 16-row / 16-column granularity, below
+
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                  hipStream_t stream, Signal sig)
 {
     if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig);
+    // GPRN_PANEL_ROWS=1 (experiments): k_panel_rows, 16-row / 16-column workgroups like the chain's kernels.  Slower:
+    // 106.4 vs 109.1 sweeps/s at config 3, 657 vs 684 at config 2, 232 vs 256 with one N = 4096 matrix per phase --
+    // eight times as many workgroups each fetch their share of X_kk, and their fixed costs add up.
+    static int panel_rows = -1;
+    if (panel_rows < 0) { const char* e = getenv("GPRN_PANEL_ROWS"); panel_rows = e ? atoi(e) : 0; }
     prof_begin(c, GPRN_T_PANEL, stream);
+    if (panel_rows)
+        hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)(8 * (n_l + n_x)), (unsigned)nbatch), dim3(512), 0, stream, d_tasks, (int)n_l,
+                           (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
+    else
     hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
                        (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
     prof_end(c);
@@ -205,6 +218,67 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
 #endif
     signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
+}
+
+// stream3's panel of a tile step at the same granularity (GPRN_PANEL_ROWS=1): tasks [0, n_l) are L_ik = B_ik X_kk^T (in
+// place over B_ik: one 8-wave workgroup per 16-ROW block, as k_chain_l), the others X_kc = X_kk R_kc (in place over
+// R_kc: one workgroup per 16-COLUMN block, which passes through LDS transposed, wave = row block, X_kk's rows up to
+// the diagonal straight from global memory).  Eight workgroups of 3-4 us per task instead of two of 14 -- and slower
+// in every configuration measured (launch_panel), so off by default.
+__global__ __launch_bounds__(512)
+void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
+                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
+                  unsigned* wait_timed_out)
+{
+    __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
+    const int ti = blockIdx.x >> 3, blk = blockIdx.x & 7;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+    const TileTask t = tasks[ti];
+    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
+    auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
+    const bool l_part = ti < n_l;
+    // the operand that is NOT in place: 16 rows of X_kk, k below 16 (wv + 1), straight into registers
+    const double* Xk = (l_part ? pick(t.b_buf) + t.b_off : pick(t.a_buf) + t.a_off) + (size_t)(16 * wv + fr) * ld + 2 * fk;
+    const int nj = 2 * (wv + 1);
+    double xo[32];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < nj) {
+            const double2 v = *(const double2*)(Xk + 8 * j);
+            xo[2 * j] = v.x; xo[2 * j + 1] = v.y;
+        }
+    double* const Cm = pick(t.c_buf) + t.c_off;
+    if (l_part) {
+        // rows 2 wv, 2 wv + 1 of row block `blk`: lane l takes 16 bytes at column 2 l
+        const double* Ar = Cm + (size_t)(16 * blk + 2 * wv) * ld + 2 * lane;
+        const double2 r0 = *(const double2*)Ar, r1 = *(const double2*)(Ar + ld);
+        *(double2*)(rows + (2 * wv) * ROWS_PITCH + 2 * lane) = r0;
+        *(double2*)(rows + (2 * wv + 1) * ROWS_PITCH + 2 * lane) = r1;
+    } else {
+        // rows 16 wv .. 16 wv + 15 of column block `blk`, transposed: rows[n][k]
+        const int r = 16 * wv + (lane >> 2), g = lane & 3;
+        const double* Br = Cm + (size_t)r * ld + 16 * blk + 4 * g;
+        const double2 c0 = *(const double2*)Br, c1 = *(const double2*)(Br + 2);
+        rows[(4 * g) * ROWS_PITCH + r] = c0.x; rows[(4 * g + 1) * ROWS_PITCH + r] = c0.y;
+        rows[(4 * g + 2) * ROWS_PITCH + r] = c1.x; rows[(4 * g + 3) * ROWS_PITCH + r] = c1.y;
+    }
+    __syncthreads();                 // the block is in LDS: from here on its memory may be overwritten (in place)
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* ar = rows + fr * ROWS_PITCH + 2 * fk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < nj) {
+            const double2 v = *(const double2*)(ar + 8 * j);
+            // L part: A = the row block (LDS), B = X_kk's rows; X part: A = X_kk's rows, B = the column block (LDS)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l_part ? v.x : xo[2 * j], l_part ? xo[2 * j] : v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l_part ? v.y : xo[2 * j + 1], l_part ? xo[2 * j + 1] : v.y, acc, 0, 0, 0);
+        }
+    gptr_t C = (gptr_t)Cm + (l_part ? (size_t)(16 * blk + fk) * ld + 16 * wv + fr : (size_t)(16 * wv + fk) * ld + 16 * blk + fr);
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
+    signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
 // MODE 1, one single-wave workgroup per lower 16 x 16 block (36 per matrix, each on a CU of its own: 32 KiB of
