@@ -269,8 +269,9 @@ class Context:
         return Kinv, P
 
     def grad_kernel(self, gp, m, n_params):
-        """Kernel-parameter gradient of latent GP `gp` contracted on the device (SE / Periodic / QuasiPeriodic
-        only; None for any other kernel -- use grad_matrices then)."""
+        """Kernel-parameter gradient of latent GP `gp` contracted on the device (closed forms for SE / Periodic /
+        QuasiPeriodic, central differences of the kernel program otherwise); None for a latent GP whose matrix
+        was uploaded (user-defined kernels) -- use grad_matrices then."""
         m = _f64(np.ravel(m), (self.N,))
         out = np.zeros(max(4, int(n_params)))
         rc = self._lib.gprn_grad_kernel(self._h, int(gp), _ptr(m), _ptr(out))

@@ -164,6 +164,10 @@ class Sum(_operator):
     def __call__(self, r):
         return self.k1(r) + self.k2(r)
 
+    def _dk_dpars(self, r):
+        # (the node's own `pars` is a copy of the children's, as in the reference: differentiate the children)
+        return list(self.k1._dk_dpars(r)) + list(self.k2._dk_dpars(r))
+
     def __repr__(self):
         return f'{self.k1} + {self.k2}'
 
@@ -174,6 +178,10 @@ class Multiplication(_operator):
 
     def __call__(self, r):
         return self.k1(r) * self.k2(r)
+
+    def _dk_dpars(self, r):
+        a, b = self.k1(r), self.k2(r)
+        return [d * b for d in self.k1._dk_dpars(r)] + [a * d for d in self.k2._dk_dpars(r)]
 
     def __repr__(self):
         return f'{self.k1} * {self.k2}'

@@ -1376,7 +1376,8 @@ extern "C" int gprn_sample_prior(gprn_ctx* c, const int32_t* ops, int n_ops, con
 // Kinv_out, P_out: (N, N), both symmetric (full).  One rank only (the node sum needs every node's Sigma).
 // kernel_grad != NULL: contract on the device instead of copying the matrices out -- needs a single SE / Periodic
 // / QuasiPeriodic kernel on latent GP `gp` and its mean vector m (N); kernel_grad[l], l < n_params.
-static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const double* m, double* kernel_grad)
+static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const double* m, double* kernel_grad,
+                     bool closed_form = false)
 {
     if (c->world != 1) return bad(c, "grad_matrices: not available on a sharded context");
     if (!c->factored || !c->keep_sigma) return bad(c, "grad_matrices: needs factor_priors and a sweep with keep_sigma");
@@ -1433,14 +1434,21 @@ static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const
         // slot 1's X workspace is free: [0, ld) the mean vector, [ld, 2 ld) a = K^-1 m, then the per-row partial sums
         const KernelSpec& ks = c->kspec[gp];
         double* const w = c->wsX[1];
-        double g4[4] = {0, 0, 0, 0};
+        double gh[GPRN_MAX_KPARAMS] = {0};
+        const int np_out = closed_form ? 4 : ks.n_params;
         if (!rc && e == hipSuccess) e = hipMemcpyAsync(w, m, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream);
+        if (!rc && e == hipSuccess) {
+            if (closed_form)
+                rc = vec_grad_contract(c, ks.ops[1], ks.params, dKinv, dS, w, w + ld, w + 2 * (size_t)ld, w + 6 * (size_t)ld);
+            else {
+                rc = vec_symv(c, dKinv, w, w + ld);
+                if (!rc) rc = launch_grad_fd(c, ks, dKinv, dS, w + ld, w + 2 * (size_t)ld, w + 6 * (size_t)ld);
+            }
+        }
         if (!rc && e == hipSuccess)
-            rc = vec_grad_contract(c, ks.ops[1], ks.params, dKinv, dS, w, w + ld, w + 2 * (size_t)ld, w + 6 * (size_t)ld);
-        if (!rc && e == hipSuccess)
-            e = hipMemcpyAsync(g4, w + 6 * (size_t)ld, sizeof(g4), hipMemcpyDeviceToHost, c->stream);
+            e = hipMemcpyAsync(gh, w + 6 * (size_t)ld, (size_t)np_out * sizeof(double), hipMemcpyDeviceToHost, c->stream);
         if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        for (int l = 0; l < ks.n_params && l < 4; ++l) kernel_grad[l] = g4[l];
+        for (int l = 0; l < ks.n_params && l < np_out; ++l) kernel_grad[l] = gh[l];
     } else {
         if (!rc && e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (!rc && e == hipSuccess)
@@ -1465,20 +1473,22 @@ extern "C" int gprn_grad_matrices(gprn_ctx* c, int gp, double* Kinv_out, double*
 }
 
 // The whole kernel-parameter gradient of latent GP `gp` on the device: < 1/2 (K^-1 S K^-1 + a a^T - K^-1), dK/dtheta_l >,
-// a = K^-1 m, for the kernels with a closed form in csrc/vecops.hip (a single SquaredExponential, Periodic or
-// QuasiPeriodic, as gprn_set_kernel received it); GPRN_E_ARG for any other kernel (the caller then contracts
-// gprn_grad_matrices' output itself).  m: the mean the reference pairs with that kernel (N); grad_out: n_params values
-// (NOT yet divided by q).
+// a = K^-1 m -- closed-form dK/dtheta for a single SquaredExponential, Periodic or QuasiPeriodic (csrc/vecops.hip), the
+// central difference of the kernel program itself for every other built-in and Sum / Multiplication tree
+// (csrc/fill.hip, launch_grad_fd); GPRN_E_ARG for a latent GP whose K was uploaded (user kernels: the caller then
+// contracts gprn_grad_matrices' output itself).  m: the mean the reference pairs with that kernel (N); grad_out:
+// n_params values (NOT yet divided by q).
 extern "C" int gprn_grad_kernel(gprn_ctx* c, int gp, const double* m, double* grad_out)
 {
     DeviceLock lock_(c);
     if (!c || !c->N || gp < 0 || gp >= c->G || !m || !grad_out) return bad(c, "grad_kernel: bad argument");
     const KernelSpec& ks = c->kspec[gp];
-    const int kid = (ks.set && !ks.uploaded && ks.n_ops == 1 && ks.ops[0] == GPRN_OP_PUSH && ks.ops[2] == 0) ? ks.ops[1] : -1;
-    if (kid != GPRN_K_SE && kid != GPRN_K_PERIODIC && kid != GPRN_K_QP)
-        return bad(c, "grad_kernel: no device-side derivative for this kernel");
-    if (c->ld < 8) return bad(c, "grad_kernel: problem too small");
-    return grad_impl(c, gp, nullptr, nullptr, m, grad_out);
+    if (!ks.set || ks.uploaded || ks.n_ops < 1)
+        return bad(c, "grad_kernel: the kernel of this latent GP has no device program (uploaded matrix)");
+    const int kid = (ks.n_ops == 1 && ks.ops[0] == GPRN_OP_PUSH && ks.ops[2] == 0) ? ks.ops[1] : -1;
+    const bool closed = kid == GPRN_K_SE || kid == GPRN_K_PERIODIC || kid == GPRN_K_QP;
+    if (c->ld < 8 + GPRN_MAX_KPARAMS / 8) return bad(c, "grad_kernel: problem too small");
+    return grad_impl(c, gp, nullptr, nullptr, m, grad_out, closed);
 }
 
 // ------------------------------------------------------------------ diagnostics

@@ -280,6 +280,66 @@ static void make_program(const KernelSpec& ks, double nugget_val, FillProgram& p
     for (int i = 3 * ks.n_ops; i < 3 * GPRN_MAX_OPS; ++i) pg.ops[i] = 0;
 }
 
+// ---- gradient of the ELBO in the hyper-parameters of ANY kernel program: per parameter l
+//   < 1/2 (P - Kinv + a a^T), (K(theta + h e_l) - K(theta - h e_l)) / 2h >,
+// the central difference of the program itself (relative step 1e-6, as covFunction._dk_dpars does on the host for
+// kernels without a closed form), evaluated and contracted on the fly: one wave per row, rows summed in a fixed order.
+// Nothing N x N is written or leaves the GPU.  The nugget is a constant of the parameters and drops out.
+__global__ __launch_bounds__(256)
+void k_grad_fd_rows(FillProgram pp, FillProgram pm, double inv2h, const double* __restrict__ t,
+                    const double* __restrict__ Kinv, const double* __restrict__ P, const double* __restrict__ a,
+                    int N, int ld, double* __restrict__ part /* N */)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= N) return;
+    const double tm = t[m], am = a[m];
+    double acc = 0.0;
+    for (int n = lane; n < N; n += 64) {
+        const double G = 0.5 * (P[(size_t)m * ld + n] - Kinv[(size_t)m * ld + n] + am * a[n]);
+        const double tn = t[n];
+        acc += G * (eval_program(pp, tm, tn, m == n) - eval_program(pm, tm, tn, m == n));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) part[m] = acc * inv2h;
+}
+
+__global__ __launch_bounds__(256)
+void k_sum_fixed(const double* __restrict__ part, int n, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// out[l], l < ks.n_params (device memory); a = Kinv m already formed; part: N doubles of scratch
+int launch_grad_fd(gprn_ctx* c, const KernelSpec& ks, const double* Kinv, const double* P, const double* a,
+                   double* part, double* out)
+{
+    prof_begin(c, GPRN_T_VEC);
+    for (int l = 0; l < ks.n_params; ++l) {
+        FillProgram pp, pm;
+        make_program(ks, 0.0, pp);
+        make_program(ks, 0.0, pm);
+        const double v = ks.params[l], h = 1e-6 * fmax(1.0, fabs(v));
+        pp.par[l] = v + h;
+        pm.par[l] = v - h;
+        hipLaunchKernelGGL(k_grad_fd_rows, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, pp, pm, 1.0 / (2 * h), c->d_time,
+                           Kinv, P, a, c->N, c->ld, part);
+        hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, c->stream, (const double*)part, c->N, out + l);
+    }
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
 int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val, const double* diag_add)
 {
     FillProgram pg;

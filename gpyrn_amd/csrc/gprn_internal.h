@@ -222,6 +222,10 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
                  Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},
                  int tag = TG_MISC);
+// < 1/2 (P - Kinv + a a^T), dK/dtheta_l > for every parameter of a kernel program by central differences of the
+// program, on the device (fill.hip); out: n_params doubles of device memory, part: N doubles of scratch
+int launch_grad_fd(gprn_ctx* c, const KernelSpec& ks, const double* Kinv, const double* P, const double* a,
+                   double* part, double* out);
 // the L part (n_l tasks) and the X part (n_x tasks) of a tile step's panel in one launch (gemm_tile.hip)
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                  hipStream_t stream, Signal sig);

@@ -21,3 +21,5 @@ int vec_symmetrize(gprn_ctx* c, double* M);                                 // u
 // out4[l] = < 1/2 (P - Kinv + a a^T), dK/dtheta_l >, a = Kinv m, for a single SE / Periodic / QP kernel (kid, par[4])
 int vec_grad_contract(gprn_ctx* c, int kid, const double* par, const double* Kinv, const double* P, const double* m,
                       double* a_scratch, double* part_scratch, double* out4);
+// out = M v on the N x N block of an ld-pitched matrix (one wave per row)
+int vec_symv(gprn_ctx* c, const double* M, const double* v, double* out);

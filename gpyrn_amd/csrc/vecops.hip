@@ -547,6 +547,13 @@ void k_sum_cols4(const double* __restrict__ part, int n, double* __restrict__ ou
     }
 }
 
+int vec_symv(gprn_ctx* c, const double* M, const double* v, double* out)
+{
+    prof_begin(c, GPRN_T_VEC);
+    hipLaunchKernelGGL(k_symv, dim3((c->N + 3) / 4), dim3(256), 0, c->stream, M, v, c->N, c->ld, out);
+    LAUNCH_END(c);
+}
+
 int vec_grad_contract(gprn_ctx* c, int kid, const double* par, const double* Kinv, const double* P, const double* m,
                       double* a_scratch, double* part_scratch, double* out4)
 {

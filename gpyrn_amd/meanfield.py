@@ -679,8 +679,8 @@ class inference:
     def _grad_from_state(self, nodes, weights, means, jitters, mu, var, matrices, device=None):
         """The O(N^2) and O(pqN) part of grad_ELBO: `matrices(gp)` returns ``(K^-1, K^-1 S K^-1)`` of latent GP
         `gp` (the GPU's ``gprn_grad_matrices``; a NumPy stand-in in the CPU tests).  `device(gp, m, n)`, when
-        given, is tried first: the whole contraction on the GPU for kernels it has closed forms for
-        (``gprn_grad_kernel``), None otherwise."""
+        given, is tried first: the whole contraction on the GPU (``gprn_grad_kernel``: closed-form or
+        central-difference dK/dtheta of the kernel's device program), None for kernels without one."""
         t = np.asarray(self.time, dtype=float)
         r = t[:, None] - t[None, :]
         q, p, N = self.q, self.p, self.N
@@ -692,8 +692,7 @@ class inference:
             else:
                 jj, ii = divmod(gp - q, p)
                 m = m_scr[jj, ii]
-            if device is not None and type(kernel) in (covfunc.SquaredExponential, covfunc.Periodic,
-                                                        covfunc.QuasiPeriodic):
+            if device is not None and kernel._device_program() is not None:
                 on_device = device(gp, m, kernel.pars.size)
                 if on_device is not None:
                     grads += [float(v) / q for v in on_device]

@@ -159,10 +159,11 @@ int gprn_sample_prior(gprn_ctx* ctx, const int32_t* ops, int n_ops, const double
  * (N, N) symmetric; needs gprn_factor_priors and a committed sweep with gprn_keep_sigma(1).  Unsharded
  * contexts only. */
 int gprn_grad_matrices(gprn_ctx* ctx, int gp, double* Kinv_out, double* P_out);
-/* the contraction as well on the device, for a latent GP whose kernel is a single SquaredExponential, Periodic or
- * QuasiPeriodic (closed-form dK/dtheta in csrc/vecops.hip, the formulas of covFunction._dk_dpars): grad_out[l] =
- * < 1/2 (K^-1 S K^-1 + a a^T - K^-1), dK/dtheta_l >, l < n_params, a = K^-1 m (m: N values, the mean the reference
- * pairs with that kernel; the 1/q of meanfield.py:709 is left to the caller).  GPRN_E_ARG for any other kernel. */
+/* the contraction as well on the device: grad_out[l] = < 1/2 (K^-1 S K^-1 + a a^T - K^-1), dK/dtheta_l >, l < n_params,
+ * a = K^-1 m (m: N values, the mean the reference pairs with that kernel; the 1/q of meanfield.py:709 is left to the
+ * caller).  dK/dtheta in closed form for a single SquaredExponential, Periodic or QuasiPeriodic (the formulas of
+ * covFunction._dk_dpars), by central differences of the kernel program (relative step 1e-6) for every other kernel
+ * gprn_set_kernel accepted.  GPRN_E_ARG for a latent GP whose matrix was uploaded (gprn_upload_K). */
 int gprn_grad_kernel(gprn_ctx* ctx, int gp, const double* m, double* grad_out);
 
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */

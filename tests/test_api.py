@@ -213,3 +213,32 @@ def test_init_mu_var_matches_reference():
         assert np.array_equal(f, d['mu_init_f']) and np.array_equal(w, d['mu_init_w'])
         y = np.concatenate(g.y) - g._mean(means)
         np.testing.assert_allclose(np.array(np.array_split(y, g.p)), d['y_resid'], atol=1e-14)
+
+
+def test_dk_dpars_of_composite_kernels_follow_the_children():
+    """A Sum / Multiplication node's own `pars` is a copy of its children's (as in the reference), so its
+    hyper-parameter derivatives must come from the children (chain rule), not from perturbing the copy."""
+    from gpyrn_amd import covfunc as cf
+    r = np.linspace(-3.0, 3.0, 41)[:, None] - np.linspace(-1.0, 2.0, 7)[None, :]
+    k1, k2 = cf.SquaredExponential(1.3, 0.9), cf.RationalQuadratic(0.7, 1.5, 2.0)
+    for node in (k1 + k2, k1 * k2, (k1 + k2) * cf.Cosine(0.4, 3.0)):
+        d = node._dk_dpars(r)
+        leaves = []
+
+        def collect(k):
+            if hasattr(k, 'k1'):
+                collect(k.k1); collect(k.k2)
+            else:
+                leaves.append(k)
+        collect(node)
+        assert len(d) == sum(leaf.pars.size for leaf in leaves) == node.pars.size
+        i = 0
+        for leaf in leaves:
+            for j in range(leaf.pars.size):
+                v = leaf.pars[j]
+                h = 1e-6 * max(1.0, abs(v))
+                leaf.pars[j] = v + h; up = node(r)
+                leaf.pars[j] = v - h; dn = node(r)
+                leaf.pars[j] = v
+                np.testing.assert_allclose(d[i], (up - dn) / (2 * h), rtol=1e-6, atol=1e-8)
+                i += 1

@@ -634,9 +634,16 @@ def test_grad_elbo_against_finite_differences(tag):
 
 
 def test_grad_contraction_on_device_matches_host_contraction():
-    """gprn_grad_kernel (K^-1 m, dK/dtheta and the <G, dK> sums all on the GPU) against the same gradient
-    contracted in NumPy from gprn_grad_matrices' output, for the three kernels with device-side closed forms
-    (one node each; the weights are SquaredExponential) -- and a kernel without one falls back, not fails."""
+    """gprn_grad_kernel (K^-1 m, dK/dtheta and the <G, dK> sums all on the GPU: closed forms for SE / Periodic /
+    QuasiPeriodic, central differences of the kernel program for the rest, a composite included) against the same
+    gradient contracted in NumPy from gprn_grad_matrices' output -- and a user-defined kernel (uploaded matrix)
+    falls back to the host, not fails."""
+    class MySE(covfunc.covFunction):              # a user kernel: no device program, K is uploaded
+        _param_names = ('a', 'l')
+
+        def __call__(self, r):
+            return self.pars[0]**2 * np.exp(-0.5 * r**2 / self.pars[1]**2)
+
     rng = np.random.default_rng(5)
     N, p, q = 300, 2, 3
     t = np.sort(rng.uniform(0, 60, N))
@@ -646,12 +653,14 @@ def test_grad_contraction_on_device_matches_host_contraction():
     g = gpyrn.inference(q, t, *args)
     nodes = [covfunc.SquaredExponential(1.0, 4.0), covfunc.Periodic(1.0, 11.0, 0.8),
              covfunc.QuasiPeriodic(1.0, 20.0, 9.0, 0.7)]
-    weights = [covfunc.SquaredExponential(0.8, 15.0), covfunc.Matern32(0.9, 12.0)] * q
+    weights = [covfunc.SquaredExponential(0.8, 15.0), covfunc.Matern32(0.9, 12.0),
+               covfunc.RationalQuadratic(0.7, 1.5, 9.0) + covfunc.Cosine(0.3, 7.0), MySE(0.8, 10.0),
+               covfunc.Matern52(0.6, 8.0), covfunc.Exponential(0.5, 20.0)]
     g.set_components(nodes, weights, [None] * p, [0.2] * p)
-    g.ELBOcalc(max_iter=20)
+    _, mu0, var0, _ = g.ELBOcalc(max_iter=20)
     nd, wt, mn, jt = g._get_components()
     ctx = g._setup_device(nd, wt, mn, jt)
-    ctx.set_muvar(g._mu, g._var)
+    ctx.set_muvar(mu0, var0)
     ctx.keep_sigma(True)
     try:
         ctx.sweep(1, commit=True)
@@ -665,12 +674,17 @@ def test_grad_contraction_on_device_matches_host_contraction():
 
         on_dev = np.array(g._grad_from_state(nd, wt, mn, jt, mu, var, ctx.grad_matrices, device=device))
         on_host = np.array(g._grad_from_state(nd, wt, mn, jt, mu, var, ctx.grad_matrices))
-        assert ctx.grad_kernel(q + 1, np.zeros(N), 2) is None        # Matern32: no device-side closed form
+        assert ctx.grad_kernel(q + 3, np.zeros(N), 2) is None        # the user kernel
     finally:
         ctx.keep_sigma(False)
-    # nodes 0..2 and the SE weights (gp 3, 5, 7) went through the device
-    assert [gp for gp, ok in seen if ok] == [0, 1, 2, 3, 5, 7]
-    np.testing.assert_allclose(on_dev, on_host, rtol=1e-6, atol=1e-9 * np.abs(on_host).max())
+    # every latent GP with a device program went through the device; the user kernel was never offered
+    assert [gp for gp, ok in seen if ok] == [0, 1, 2, 3, 4, 5, 7, 8]
+    assert on_dev.shape == on_host.shape
+    scale = np.abs(on_host).max()
+    # closed forms on both sides (the three nodes, the SE weight): to rounding; central differences on both sides
+    # (relative step 1e-6 against N^2 terms weighted by K^-1-sized factors): to their common noise
+    np.testing.assert_allclose(on_dev[:11], on_host[:11], rtol=2e-6, atol=1e-8 * scale)
+    np.testing.assert_allclose(on_dev, on_host, rtol=2e-3, atol=2e-7 * scale)
 
 
 def test_optimize_with_analytic_gradient():
