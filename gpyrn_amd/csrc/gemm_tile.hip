@@ -403,10 +403,11 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_UPDATE_AHEAD) | (1 << GPRN_T_LAUUM)); }
     static int pad_all = -1;                       // GPRN_PAD_ALL=1 (probes): pad on every stream
     if (pad_all < 0) { const char* e = getenv("GPRN_PAD_ALL"); pad_all = e ? atoi(e) : 0; }
-    // Launches over one or two matrices (node half-sweep, sharded runs) ask for 64 KiB instead: with
-    // 104 KiB taken, the diagonal-block kernel (67 KiB) cannot land on a CU that runs a bulk workgroup at
-    // all and runs undisturbed on the next CU that comes free -- those phases are bound by the chain, not
-    // by the bulk (+3 % sweeps/s at config 3).  GPRN_PAD_SMALL_KB / GPRN_PAD_SMALL_BATCH override.
+    // Launches over one or two matrices (node half-sweep, sharded runs) ask for 64 KiB instead: one bulk
+    // workgroup per CU, so that those phases' chain and side kernels find room on every CU -- they are bound by the
+    // chains, not by the bulk (+3 % sweeps/s at config 3 in round 1, when the 67 KiB diagonal-block kernel could not
+    // share a CU with such a workgroup at all; with its 46.6 KiB of round 2, pads of 74 KiB -- no sharing again --
+    // measure the same).  GPRN_PAD_SMALL_KB / GPRN_PAD_SMALL_BATCH override.
     static int pad_small_kb = -1, pad_small_batch = -1;
     if (pad_small_kb < 0) { const char* e = getenv("GPRN_PAD_SMALL_KB"); pad_small_kb = e ? atoi(e) : 64; }
     if (pad_small_batch < 0) { const char* e = getenv("GPRN_PAD_SMALL_BATCH"); pad_small_batch = e ? atoi(e) : 2; }
