@@ -1,7 +1,11 @@
 #!/bin/bash
 # Everything under profiles/r02_* in one go, on the GPU box:  bash profiles/run_r02_profiles.sh  (results land in gpurun_out/final/)
 set -x
-cd $GRAFT_REPO_ROOT
+cd ${GRAFT_REPO_ROOT:-.}
+# the stand-alone probes (binaries are not tracked)
+for f in diag_bench base16_bench rows_bench lat_bench; do
+  [ -x gpyrn_amd/csrc/_probe/$f ] || ( cd gpyrn_amd/csrc/_probe && hipcc --offload-arch=gfx950 -O3 -std=c++17 -I/opt/rocm/include $f.hip -o $f )
+done
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 timeout -k 10 900 python bench.py > $O/r02_bench.json 2> $O/bench.err
