@@ -165,13 +165,45 @@ def self_launch(a):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
-    sys.stdout.write(out0.decode())
+    # poll every child: as soon as one has failed the others are stopped (a rank that died before the
+    # communicator exists would leave the rest waiting in the rendezvous, holding the GPUs), and the whole
+    # launch has a time limit (GPRN_LAUNCH_TIMEOUT_S, default 1500 s)
+    import tempfile
+    import threading
+    buf = tempfile.TemporaryFile()
+    pump = threading.Thread(target=lambda: buf.write(procs[0].stdout.read()), daemon=True)
+    pump.start()
+    deadline = time.time() + float(os.environ.get('GPRN_LAUNCH_TIMEOUT_S', 1500))
+    why = None
+    while True:
+        codes = [pr.poll() for pr in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            why = 'a rank failed'
+        elif time.time() > deadline:
+            why = 'time limit reached'
+        if why:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.terminate()
+            t_kill = time.time() + 10
+            while any(pr.poll() is None for pr in procs) and time.time() < t_kill:
+                time.sleep(0.1)
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+            codes = [pr.wait() for pr in procs]
+            break
+        time.sleep(0.2)
+    pump.join(timeout=10)
+    buf.seek(0)
+    sys.stdout.write(buf.read().decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.exit('bench.py: rank(s) failed: %s' % ', '.join('%d (exit %d)' % rc for rc in bad))
+    if bad or why:
+        sys.exit('bench.py: %srank(s) failed: %s' % (why + '; ' if why else '',
+                                                     ', '.join('%d (exit %d)' % rc for rc in bad)))
 
 
 def main():

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GPRN_HIP_LIB') or os.path.join(_HERE, 'libgprn_hip.so')
 
-GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM = -1, -2, -3, -4, -5
+GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM, GPRN_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
 M_K, M_KLINV, M_SIGMA = 0, 1, 2
 T_NAMES = ('fill', 'build_B', 'diag', 'panel', 'update', 'lauum', 'vec', 'update_ahead')
 TILE = 128
@@ -51,6 +51,8 @@ SIGNATURES = {
     'gprn_get_muvar': (c_int, [c_void_p, _dp, _dp]),
     'gprn_sweep': (c_int, [c_void_p, c_int, c_int, _dp, _dp]),
     'gprn_predict': (c_int, [c_void_p, c_int, _dp, _dp, _dp]),
+    'gprn_predict_upload': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
+    'gprn_get_scalars': (c_int, [c_void_p, _dp]),
     'gprn_keep_sigma': (c_int, [c_void_p, c_int]),
     'gprn_get_matrix': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_get_logdet_K': (c_int, [c_void_p, _dp]),
@@ -176,6 +178,12 @@ class Context:
     def set_owners(self, owner):
         arr = (c_int * self.G)(*[int(o) for o in owner])
         self._check(self._lib.gprn_set_owners(self._h, arr), 'set_owners')
+        self._owner = [int(o) for o in owner]
+
+    def owner_of(self, gp):
+        """Rank that factors latent GP `gp` (0 on an unsharded context)."""
+        owner = getattr(self, '_owner', None)
+        return owner[gp] if owner else 0
 
     def barrier_max(self, value=0.0):
         v = c_double(float(value))
@@ -231,14 +239,32 @@ class Context:
         return elbo, parts, info
 
     def predict(self, tstar):
-        """Conditional mean / variance of every latent GP at `tstar`: two (G, n*) arrays
-        (rows of GPs owned by other ranks stay zero) and the LAPACK-style info."""
+        """Conditional mean / variance of every latent GP at `tstar`: two (G, n*) arrays (complete on
+        every rank of a sharded context) and the LAPACK-style info."""
         ts = _f64(np.ravel(tstar))
         mean = np.zeros((self.G, ts.size))
         var = np.zeros((self.G, ts.size))
         info = self._check(self._lib.gprn_predict(self._h, ts.size, _ptr(ts), _ptr(mean), _ptr(var)),
                            'predict')
         return mean, var, info
+
+    def predict_upload(self, gp, K_tiny, Kstar, kss):
+        """Host-evaluated K + 1.25e-12 I (N, N), K* (n*, N) and k** (n*) of latent GP `gp` for the next predict()."""
+        K_tiny = _f64(K_tiny, (self.N, self.N))
+        Kstar = _f64(np.atleast_2d(Kstar))
+        if Kstar.shape[1] != self.N:
+            raise ValueError('Kstar must have N columns')
+        kss = _f64(np.ravel(kss), (Kstar.shape[0],))
+        self._check(self._lib.gprn_predict_upload(self._h, int(gp), Kstar.shape[0], _ptr(K_tiny), _ptr(Kstar),
+                                                  _ptr(kss)), 'predict_upload')
+
+    def get_scalars(self):
+        """Per-GP scalars of the last sweep: dict of log det B (G), tr B^-1 (G), m^T K^-1 m (G), Q1 traces (q, q)."""
+        out = np.empty(3 * self.G + self.q * self.q)
+        self._check(self._lib.gprn_get_scalars(self._h, _ptr(out)), 'get_scalars')
+        G = self.G
+        return {'logdetB': out[:G].copy(), 'trBinv': out[G:2 * G].copy(), 'muKmu': out[2 * G:3 * G].copy(),
+                'q1': out[3 * G:].reshape(self.q, self.q).copy()}
 
     def eval_kernel(self, ops, params, nugget):
         """K = expr(t_i, t_j) + nugget I at the data times, filled on the device."""
@@ -275,7 +301,7 @@ class Context:
         m = _f64(np.ravel(m), (self.N,))
         out = np.zeros(max(4, int(n_params)))
         rc = self._lib.gprn_grad_kernel(self._h, int(gp), _ptr(m), _ptr(out))
-        if rc == GPRN_E_ARG:
+        if rc == GPRN_E_UNSUPPORTED:           # every other error (sharded context, no Sigma kept, ...) raises
             return None
         self._check(rc, 'grad_kernel')
         return out[:n_params]

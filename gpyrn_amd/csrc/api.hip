@@ -112,17 +112,49 @@ static int bad(gprn_ctx* c, const char* msg) { if (c) c->err = msg; return GPRN_
 // Runs `body` (an entry point that factorises); when one of its in-kernel dependency waits gave up
 // (GPRN_E_WAIT_TIMEOUT: a serialising tool, a starved device, ...), the context is latched to the event
 // schedule and the body runs once more -- `body` must restore what it changed before it starts over.
+// On a sharded context the verdict is shared first (one max-reduce of the "timed out" word per call): the body
+// issues collectives, so either every rank runs it again or none does -- a rank re-running on its own would issue
+// its broadcasts and its all-reduce a second time while the others have moved on.
+static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max);
+static bool comm_active(const gprn_ctx* c);
+
+static int agree_on_timeout(gprn_ctx* c, int rc, bool* any)
+{
+    *any = rc == GPRN_E_WAIT_TIMEOUT;
+    if (!comm_active(c)) return GPRN_OK;
+    if (rc == GPRN_E_COMM) return GPRN_OK;             // the transport itself is down: nothing to agree through
+    if (!c->d_agree && hipMalloc(&c->d_agree, sizeof(double)) != hipSuccess) { c->err = "hipMalloc: timeout word"; return GPRN_E_NOMEM; }
+    const double mine = *any ? 1.0 : 0.0;
+    double all = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_agree, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    int r = comm_allreduce(c, c->d_agree, 1, true);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpyAsync(&all, c->d_agree, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *any = all > 0.0;
+    return GPRN_OK;
+}
+
 template <class F>
-static int with_event_fallback(gprn_ctx* c, const char* what, F&& body)
+static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool collective = false)
 {
     int rc = body(false);
-    if (rc != GPRN_E_WAIT_TIMEOUT) return rc;
+    bool again = rc == GPRN_E_WAIT_TIMEOUT;
+    if (collective) {
+        const int ra = agree_on_timeout(c, rc, &again);
+        if (ra) return ra;
+    }
+    if (!again) return rc;
     hipStreamSynchronize(c->stream); hipStreamSynchronize(c->stream2); hipStreamSynchronize(c->stream3);
     if (c->stream4) hipStreamSynchronize(c->stream4);
     c->use_flags = 0;
     c->fallbacks += 1;
-    fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms; re-running the call with "
-                    "HIP events (device-side waits are now off for this context)\n", what, c->wait_budget_ms);
+    if (rc == GPRN_E_WAIT_TIMEOUT)
+        fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms; re-running the call with "
+                        "HIP events (device-side waits are now off for this context)\n", what, c->wait_budget_ms);
+    else
+        fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out on another rank; re-running the call with "
+                        "HIP events on this rank too (device-side waits are now off for this context)\n", what);
     rc = body(true);
     if (rc == GPRN_E_WAIT_TIMEOUT) { c->err = "factorisation: dependency wait timed out on the event schedule too"; rc = GPRN_E_HIP; }
     return rc;
@@ -132,6 +164,9 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body)
 //   "flags"          1/0: device-side flags or HIP events for the factorisation's cross-stream dependencies
 //   "wait_budget_ms" wall-clock budget of one in-kernel wait
 //   "withhold_inner" test hook: the n-th F_INNER raise of every following call is skipped (0 = off)
+//   "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb"  unused dynamic LDS of the bulk launches (batches above / up to two
+//                    matrices) and of the chain's own tile launches, KiB (-2: back to the environment / default).  A pad that does
+//                    not fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -141,10 +176,15 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     if (!strcmp(name, "flags")) { factor_use_flags(c); field = &c->use_flags; }
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
+    else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
+    else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
+    else if (!strcmp(name, "chain_pad_kb")) field = &c->chain_pad_kb_opt;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else if (!strcmp(name, "chain_streams")) { if (old) *old = factor_probe_streams(c); return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
+    const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt || field == &c->chain_pad_kb_opt;
+    if (is_pad && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
     if (value >= 0) {
         if (field == &c->use_flags && value) {
             int can = 0;
@@ -306,6 +346,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         free_problem(c);
         dev_free(c->d_tasks);
         if (c->d_sig) hipFree(c->d_sig);
+        dev_free(c->d_agree);
         dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
         hipEventDestroy(c->ev_diag);
         hipEventDestroy(c->ev_first);
@@ -643,7 +684,7 @@ static int comm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
     return GPRN_OK;
 }
 
-static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max = false)
+static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max)
 {
     if (c->shm) return shm_allreduce(c, buf, n, is_max);
     NCCL_TRY(c, g_rccl.AllReduce(buf, buf, n, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream));
@@ -741,7 +782,7 @@ extern "C" int gprn_comm_allreduce_sum(gprn_ctx* c, double* buf, int n)
     TRY(dev_alloc(c, &d, (size_t)n));
     int rc = GPRN_OK;
     if (hipMemcpyAsync(d, buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = GPRN_E_HIP;
-    if (rc == GPRN_OK) rc = comm_allreduce(c, d, (size_t)n);
+    if (rc == GPRN_OK) rc = comm_allreduce(c, d, (size_t)n, false);
     if (rc == GPRN_OK && hipMemcpyAsync(buf, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = GPRN_E_HIP;
     if (rc == GPRN_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = GPRN_E_HIP;
     hipFree(d);
@@ -772,7 +813,7 @@ static int reduce_scalars(gprn_ctx* c)
 {
     if (!comm_active(c)) return GPRN_OK;
     const size_t n = 3 * (size_t)c->G + (size_t)c->q * c->q;
-    return comm_allreduce(c, c->d_scal, n);
+    return comm_allreduce(c, c->d_scal, n, false);
 }
 
 // ------------------------------------------------------------------ tables
@@ -867,7 +908,7 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
     for (int g = 0; g < c->G; ++g)
         if (!c->kspec[g].set) return bad(c, "factor_priors: a latent GP has no kernel");
     // (every K is refilled from its kernel spec -- or still holds the uploaded matrix -- so a re-run starts clean)
-    return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); });
+    return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); }, true);
 }
 
 static int factor_priors_impl(gprn_ctx* c)
@@ -945,7 +986,7 @@ static int factor_priors_impl(gprn_ctx* c)
         HIP_TRY(c, hipMemcpy(h.data(), c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
         for (int g = 0; g < c->G; ++g) if (c->owner[g] != c->rank) h[g] = 0.0;
         HIP_TRY(c, hipMemcpy(c->d_logdetK, h.data(), c->G * sizeof(double), hipMemcpyHostToDevice));
-        if (comm_active(c)) TRY(comm_allreduce(c, c->d_logdetK, c->G));
+        if (comm_active(c)) TRY(comm_allreduce(c, c->d_logdetK, c->G, false));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     TRY(factor_check_waits(c));
@@ -1045,7 +1086,7 @@ extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_ou
         return bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
     HIP_TRY(c, hipSetDevice(c->device));
     return with_event_fallback(c, "sweep", [&](bool retry) {
-        return sweep_impl(c, n_sweeps, commit, elbo_out, parts_out, retry); });
+        return sweep_impl(c, n_sweeps, commit, elbo_out, parts_out, retry); }, true);
 }
 
 static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out, bool retry)
@@ -1132,6 +1173,19 @@ extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
     return GPRN_OK;
 }
 
+// per-GP scalars of the last sweep, as the ELBO assembly (k_elbo) read them: log det B [G], tr(B^-1) [G],
+// m^T K^-1 m [G], the cumulative-trace terms < K_j^-1, Sigma_k > [q*q, entry j*q + k, k < j] -- for tests that
+// recombine the entropy and the prior term on the host (tests/test_parity_gpu.py, config 5's shape)
+extern "C" int gprn_get_scalars(gprn_ctx* c, double* out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || !out) return bad(c, "get_scalars: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_scal, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), hipMemcpyDeviceToHost));
+    return GPRN_OK;
+}
+
 extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
 {
     DeviceLock lock_(c);
@@ -1150,6 +1204,29 @@ extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
 // the blocked factor+inverse (X = L^-1), sol = X^T X mu, W^T = K* X^T by the tile kernel.
 static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out);
 
+// Host-evaluated matrices of latent GP `gp` for the next gprn_predict call with the same `ns`: what a user-defined
+// covFunction subclass -- whose K reached the device through gprn_upload_K -- needs in place of the fused fills.
+extern "C" int gprn_predict_upload(gprn_ctx* c, int gp, int ns, const double* K_tiny, const double* Kstar, const double* kss)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || gp < 0 || gp >= c->G || ns <= 0 || !K_tiny || !Kstar || !kss)
+        return bad(c, "predict_upload: bad argument");
+    if (c->owner.empty()) return bad(c, "predict_upload: call set_owners first");
+    if (c->owner[gp] != c->rank) return GPRN_OK;                    // not needed on this rank
+    gprn_ctx::PredStage& st = c->pred_stage[gp];
+    st.ns = ns;
+    st.K.assign(K_tiny, K_tiny + (size_t)c->N * c->N);
+    st.Kstar.assign(Kstar, Kstar + (size_t)ns * c->N);
+    st.kss.assign(kss, kss + ns);
+    return GPRN_OK;
+}
+
+__global__ void k_add_to_diagonal(double* __restrict__ A, int ld, const double* __restrict__ v, int N)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) A[(size_t)i * ld + i] += v[i];
+}
+
 extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
 {
     DeviceLock lock_(c);
@@ -1157,8 +1234,11 @@ extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* me
     if (!c->have_muvar) return bad(c, "predict: set_muvar (or a sweep) first");
     if (c->owner.empty()) return bad(c, "predict: call set_owners first");
     HIP_TRY(c, hipSetDevice(c->device));
-    // (everything it factors is refilled from the kernel specs and the variational state)
-    return with_event_fallback(c, "predict", [&](bool) { return predict_impl(c, ns, tstar, mean_out, var_out); });
+    // (everything it factors is refilled from the kernel specs, the staged matrices and the variational state)
+    const int rc = with_event_fallback(c, "predict", [&](bool) { return predict_impl(c, ns, tstar, mean_out, var_out); },
+                                       true);
+    c->pred_stage.clear();
+    return rc;
 }
 
 static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
@@ -1167,15 +1247,19 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
     std::vector<int> gps = c->loc_nodes;
     gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
     const int nloc = (int)gps.size();
-    if (!nloc) return GPRN_OK;
-    for (int g : gps)
-        if (!c->kspec[g].set || c->kspec[g].uploaded)
-            return bad(c, "predict: needs device-evaluable kernels (host-uploaded K has no K*)");
+    for (int g : gps) {
+        if (!c->kspec[g].set) return bad(c, "predict: a latent GP has no kernel");
+        if (c->kspec[g].uploaded) {
+            auto it = c->pred_stage.find(g);
+            if (it == c->pred_stage.end() || it->second.ns != ns)
+                return bad(c, "predict: a host-evaluated kernel needs gprn_predict_upload (K, K*, k**) for this ns first");
+        }
+    }
     const int ld = c->ld, N = c->N, T = c->T;
     const int ns_pad = ((ns + GPRN_TILE - 1) / GPRN_TILE) * GPRN_TILE;
     const size_t need = (size_t)ns_pad * ld;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->predKs.size() != (size_t)c->nslot || c->pred_cap < need) {
+    if (nloc && (c->predKs.size() != (size_t)c->nslot || c->pred_cap < need)) {
         for (auto& p : c->predKs) dev_free(p);
         for (auto& p : c->predWT) dev_free(p);
         c->predKs.assign(c->nslot, nullptr); c->predWT.assign(c->nslot, nullptr);
@@ -1189,13 +1273,14 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
         TRY(dev_alloc(c, &c->tab_pred, (size_t)c->nslot * GPRN_NBUF));
         TRY(dev_alloc(c, &c->d_slotgp_all, c->nslot));
     }
-    double *d_ts = nullptr, *d_kss = nullptr, *d_mean = nullptr, *d_pvar = nullptr;
+    double *d_ts = nullptr, *d_kss = nullptr, *d_mean = nullptr, *d_pvar = nullptr, *d_all = nullptr;
     TileTask* d_t = nullptr;
     int rc = GPRN_OK, first = 0;
     std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
     std::vector<int> staterow(nloc);
     std::vector<TileTask> tasks;
-    std::vector<double> hm, hv;
+    std::vector<double> hm, hv, pad;
+    const bool gather = comm_active(c);
     auto row_of = [&](int g) {
         if (g < c->q) return g;
         const int kk = g - c->q, j = kk / c->p, i = kk % c->p;
@@ -1203,60 +1288,103 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
     };
 #define PTRY(expr) do { rc = (expr); if (rc) goto done; } while (0)
 #define PHIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); rc = GPRN_E_HIP; goto done; } } while (0)
-    PTRY(dev_alloc(c, &d_ts, ns));
-    PTRY(dev_alloc(c, &d_kss, (size_t)nloc * ns_pad));
-    PTRY(dev_alloc(c, &d_mean, (size_t)nloc * ns_pad));
-    PTRY(dev_alloc(c, &d_pvar, (size_t)nloc * ns_pad));
-    PHIP(hipMemcpy(d_ts, tstar, ns * sizeof(double), hipMemcpyHostToDevice));
-    for (int s = 0; s < nloc; ++s) {
-        rows[(size_t)s * GPRN_NBUF + BUF_B] = c->wsB[s];
-        rows[(size_t)s * GPRN_NBUF + BUF_X] = c->wsX[s];
-        rows[(size_t)s * GPRN_NBUF + BUF_K] = c->predKs[s];
-        rows[(size_t)s * GPRN_NBUF + BUF_KLINV] = c->predWT[s];
-        staterow[s] = row_of(gps[s]);
+    if (nloc) {
+        PTRY(dev_alloc(c, &d_ts, ns));
+        PTRY(dev_alloc(c, &d_kss, (size_t)nloc * ns_pad));
+        PTRY(dev_alloc(c, &d_mean, (size_t)nloc * ns_pad));
+        PTRY(dev_alloc(c, &d_pvar, (size_t)nloc * ns_pad));
+        PHIP(hipMemcpy(d_ts, tstar, ns * sizeof(double), hipMemcpyHostToDevice));
+        for (int s = 0; s < nloc; ++s) {
+            rows[(size_t)s * GPRN_NBUF + BUF_B] = c->wsB[s];
+            rows[(size_t)s * GPRN_NBUF + BUF_X] = c->wsX[s];
+            rows[(size_t)s * GPRN_NBUF + BUF_K] = c->predKs[s];
+            rows[(size_t)s * GPRN_NBUF + BUF_KLINV] = c->predWT[s];
+            staterow[s] = row_of(gps[s]);
+        }
+        PTRY(upload_table(c, c->tab_pred, rows));
+        PHIP(hipMemcpy(c->d_slotgp_all, staterow.data(), nloc * sizeof(int), hipMemcpyHostToDevice));
+        for (int s = 0; s < nloc; ++s) {
+            const KernelSpec& ks = c->kspec[gps[s]];
+            if (!ks.uploaded) {
+                PTRY(launch_fill(c, ks, c->wsB[s], 1.25e-12, c->d_var + (size_t)staterow[s] * N));
+                PTRY(launch_fill_rect(c, ks, 1.25e-12, d_ts, ns, ns_pad, c->predKs[s], d_kss + (size_t)s * ns_pad));
+                continue;
+            }
+            // the caller's matrices: K (identity padding) + diag(var), K* (zero padding), k**
+            const gprn_ctx::PredStage& st = c->pred_stage[gps[s]];
+            pad.assign((size_t)ld * ld, 0.0);
+            for (int m = 0; m < ld; ++m) {
+                if (m < N) memcpy(&pad[(size_t)m * ld], &st.K[(size_t)m * N], N * sizeof(double));
+                else pad[(size_t)m * ld + m] = 1.0;
+            }
+            PHIP(hipMemcpy(c->wsB[s], pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_add_to_diagonal, dim3((N + 255) / 256), dim3(256), 0, c->stream, c->wsB[s], ld,
+                               c->d_var + (size_t)staterow[s] * N, N);
+            PHIP(hipGetLastError());
+            pad.assign(need, 0.0);
+            for (int m = 0; m < ns; ++m) memcpy(&pad[(size_t)m * ld], &st.Kstar[(size_t)m * N], N * sizeof(double));
+            PHIP(hipMemcpy(c->predKs[s], pad.data(), need * sizeof(double), hipMemcpyHostToDevice));
+            pad.assign(ns_pad, 0.0);
+            memcpy(pad.data(), st.kss.data(), ns * sizeof(double));
+            PHIP(hipMemcpy(d_kss + (size_t)s * ns_pad, pad.data(), ns_pad * sizeof(double), hipMemcpyHostToDevice));
+        }
+        PHIP(hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+        c->d_ptrs = c->tab_pred;
+        c->slot0 = 0;
+        c->d_info_cur = c->d_info;
+        PTRY(factor_invert(c, nloc));
+        PTRY(vec_lower_matvec(c, BUF_X, c->d_mu, N, 1, c->d_slotgp_all, nloc, c->d_u));   // u = X mu
+        PTRY(vec_colops(c, nloc));                                                          // ct = X^T u
+        for (int bt = 0; bt < ns_pad / GPRN_TILE; ++bt)
+            for (int at = 0; at < T; ++at)
+                tasks.push_back(TileTask{(int64_t)bt * GPRN_TILE * ld + (int64_t)at * GPRN_TILE,
+                                         (int64_t)bt * GPRN_TILE * ld, (int64_t)at * GPRN_TILE * ld,
+                                         (at + 1) * GPRN_TILE, BUF_KLINV, BUF_K, BUF_X,
+                                         tile_modes(CM_SET, 0, 0)});
+        PTRY(dev_alloc(c, &d_t, tasks.size()));
+        PHIP(hipMemcpyAsync(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, c->stream));
+        PTRY(launch_tiles(c, d_t, tasks.size(), c->d_ptrs, nloc, ld, GPRN_T_UPDATE));
+        PTRY(vec_pred_rows(c, nloc, ns, ns_pad, c->d_ct, d_kss, d_mean, d_pvar));
     }
-    PTRY(upload_table(c, c->tab_pred, rows));
-    PHIP(hipMemcpy(c->d_slotgp_all, staterow.data(), nloc * sizeof(int), hipMemcpyHostToDevice));
-    for (int s = 0; s < nloc; ++s) {
-        const KernelSpec& ks = c->kspec[gps[s]];
-        PTRY(launch_fill(c, ks, c->wsB[s], 1.25e-12, c->d_var + (size_t)staterow[s] * N));
-        PTRY(launch_fill_rect(c, ks, 1.25e-12, d_ts, ns, ns_pad, c->predKs[s], d_kss + (size_t)s * ns_pad));
-    }
-    PHIP(hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
-    c->d_ptrs = c->tab_pred;
-    c->slot0 = 0;
-    c->d_info_cur = c->d_info;
-    PTRY(factor_invert(c, nloc));
-    PTRY(vec_lower_matvec(c, BUF_X, c->d_mu, N, 1, c->d_slotgp_all, nloc, c->d_u));   // u = X mu
-    PTRY(vec_colops(c, nloc));                                                          // ct = X^T u
-    for (int bt = 0; bt < ns_pad / GPRN_TILE; ++bt)
-        for (int at = 0; at < T; ++at)
-            tasks.push_back(TileTask{(int64_t)bt * GPRN_TILE * ld + (int64_t)at * GPRN_TILE,
-                                     (int64_t)bt * GPRN_TILE * ld, (int64_t)at * GPRN_TILE * ld,
-                                     (at + 1) * GPRN_TILE, BUF_KLINV, BUF_K, BUF_X,
-                                     tile_modes(CM_SET, 0, 0)});
-    PTRY(dev_alloc(c, &d_t, tasks.size()));
-    PHIP(hipMemcpyAsync(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, c->stream));
-    PTRY(launch_tiles(c, d_t, tasks.size(), c->d_ptrs, nloc, ld, GPRN_T_UPDATE));
-    PTRY(vec_pred_rows(c, nloc, ns, ns_pad, c->d_ct, d_kss, d_mean, d_pvar));
-    hm.resize((size_t)nloc * ns_pad); hv.resize((size_t)nloc * ns_pad);
-    PHIP(hipMemcpyAsync(hm.data(), d_mean, hm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PHIP(hipMemcpyAsync(hv.data(), d_pvar, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    PHIP(hipStreamSynchronize(c->stream));
-    for (int s = 0; s < nloc; ++s) {
-        memcpy(mean_out + (size_t)gps[s] * ns, &hm[(size_t)s * ns_pad], ns * sizeof(double));
-        memcpy(var_out + (size_t)gps[s] * ns, &hv[(size_t)s * ns_pad], ns * sizeof(double));
+    if (gather) {
+        // every rank ends up with every latent GP's rows: the owners' results travel as one grouped broadcast
+        // (2 G messages of ns doubles); ranks that own nothing take part all the same
+        PTRY(dev_alloc(c, &d_all, 2 * (size_t)c->G * ns));
+        for (int s = 0; s < nloc; ++s) {
+            PHIP(hipMemcpyAsync(d_all + (size_t)gps[s] * ns, d_mean + (size_t)s * ns_pad, ns * sizeof(double),
+                                hipMemcpyDeviceToDevice, c->stream));
+            PHIP(hipMemcpyAsync(d_all + ((size_t)c->G + gps[s]) * ns, d_pvar + (size_t)s * ns_pad, ns * sizeof(double),
+                                hipMemcpyDeviceToDevice, c->stream));
+        }
+        if (c->comm) { if (g_rccl.GroupStart() != ncclSuccess) { c->err = "ncclGroupStart"; rc = GPRN_E_COMM; goto done; } }
+        for (int g = 0; g < c->G && !rc; ++g) {
+            rc = comm_broadcast(c, d_all + (size_t)g * ns, ns, c->owner[g]);
+            if (!rc) rc = comm_broadcast(c, d_all + ((size_t)c->G + g) * ns, ns, c->owner[g]);
+        }
+        if (c->comm) { if (g_rccl.GroupEnd() != ncclSuccess && !rc) { c->err = "ncclGroupEnd"; rc = GPRN_E_COMM; } }
+        if (rc) goto done;
+        PHIP(hipMemcpyAsync(mean_out, d_all, (size_t)c->G * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PHIP(hipMemcpyAsync(var_out, d_all + (size_t)c->G * ns, (size_t)c->G * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PHIP(hipStreamSynchronize(c->stream));
+    } else if (nloc) {
+        hm.resize((size_t)nloc * ns_pad); hv.resize((size_t)nloc * ns_pad);
+        PHIP(hipMemcpyAsync(hm.data(), d_mean, hm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PHIP(hipMemcpyAsync(hv.data(), d_pvar, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PHIP(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < nloc; ++s) {
+            memcpy(mean_out + (size_t)gps[s] * ns, &hm[(size_t)s * ns_pad], ns * sizeof(double));
+            memcpy(var_out + (size_t)gps[s] * ns, &hv[(size_t)s * ns_pad], ns * sizeof(double));
+        }
     }
     c->info_gp = -1;
     rc = factor_check_waits(c);
-    if (!rc) rc = check_info(c, c->d_info, gps, &first);
+    if (!rc && nloc) rc = check_info(c, c->d_info, gps, &first);
     if (!rc) rc = first;
 done:
 #undef PTRY
 #undef PHIP
     hipStreamSynchronize(c->stream);
-    dev_free(d_ts); dev_free(d_kss); dev_free(d_mean); dev_free(d_pvar); dev_free(d_t);
-    c->factored = c->factored;      // the priors' factors live in K/KLinv, not in the workspaces
+    dev_free(d_ts); dev_free(d_kss); dev_free(d_mean); dev_free(d_pvar); dev_free(d_t); dev_free(d_all);
     return rc;
 }
 
@@ -1483,8 +1611,10 @@ extern "C" int gprn_grad_kernel(gprn_ctx* c, int gp, const double* m, double* gr
     DeviceLock lock_(c);
     if (!c || !c->N || gp < 0 || gp >= c->G || !m || !grad_out) return bad(c, "grad_kernel: bad argument");
     const KernelSpec& ks = c->kspec[gp];
-    if (!ks.set || ks.uploaded || ks.n_ops < 1)
-        return bad(c, "grad_kernel: the kernel of this latent GP has no device program (uploaded matrix)");
+    if (!ks.set || ks.uploaded || ks.n_ops < 1) {
+        c->err = "grad_kernel: the kernel of this latent GP has no device program (uploaded matrix)";
+        return GPRN_E_UNSUPPORTED;
+    }
     const int kid = (ks.n_ops == 1 && ks.ops[0] == GPRN_OP_PUSH && ks.ops[2] == 0) ? ks.ops[1] : -1;
     const bool closed = kid == GPRN_K_SE || kid == GPRN_K_PERIODIC || kid == GPRN_K_QP;
     if (c->ld < 8 + GPRN_MAX_KPARAMS / 8) return bad(c, "grad_kernel: problem too small");

@@ -1128,8 +1128,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         HIP_TRY(c, hipGetLastError());
         return GPRN_OK;
     };
+    // (never withheld by the test hook: this raise is also what the last tile step's STREAM wait consumes, and a
+    // stream wait has no time-out -- the hook only ever drops raises whose consumers wait in-kernel)
     auto flush_inner = [&]() -> int {              // nothing else follows on stream3 soon
-        if (inner_k >= 0) HIP_TRY(c, raise(s1, inner_k, F_INNER));
+        if (inner_k >= 0)
+            HIP_TRY(c, use_flags ? hipStreamWriteValue32(s1, slot(inner_k, F_INNER) + 1, epoch, 0)
+                                 : hipEventRecord(events[F_INNER], s1));
         inner_k = -1;
         return GPRN_OK;
     };
@@ -1445,7 +1449,23 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (rc) return rc;
     static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
-    if (split_sched()) return factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
+    if (split_sched()) {
+        rc = factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
+        if (rc && c->d_sig && c->use_flags == 1) {
+            // The enqueue broke off half-way: stream waits already queued on the device's shared streams would
+            // wait for flags nobody will raise (they have no time-out).  Put every flag of this call up so that
+            // the streams drain; the results are void, the caller gets the error.
+            std::vector<unsigned> h((size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0u);
+            for (size_t i = 1; i < h.size(); i += 2) h[i] = c->epoch;
+            (void)hipMemcpy(c->d_sig, h.data(), h.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+            (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2);
+            (void)hipStreamSynchronize(c->stream3);
+            if (c->stream4) (void)hipStreamSynchronize(c->stream4);
+            // (a wait may have given up before the flags went up: that verdict belongs to this failed call)
+            (void)hipMemset(c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0, sizeof(unsigned));
+        }
+        return rc;
+    }
     bool rest_pending = false, next_pending = false;
     const Signal nosig{nullptr, 0, nullptr, 0, nullptr};
     const Await noaw{nullptr, 0, nullptr};

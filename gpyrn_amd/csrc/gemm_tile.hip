@@ -29,6 +29,7 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "tile_mma.h"
@@ -361,16 +362,43 @@ static int xcd_map()                               // GPRN_XCD_MAP=0: grid order
     return v;
 }
 
+// LDS one workgroup may ask for on this device (static + dynamic).  A launch beyond it is not refused by the
+// runtime: the queue aborts with HSA_STATUS_ERROR_INVALID_ALLOCATION and takes the process down (round 2,
+// gpurun_out/r2_b37.err: an LDS-pad experiment on top of the 72 KiB image of the 128 x 128 shape), so every
+// launch that carries a pad is checked here first.
+size_t lds_limit(int device)
+{
+    static std::map<int, size_t> known;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = known.find(device);
+    if (it != known.end()) return it->second;
+    int per_cu = 0, per_block = 0;
+    if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess) per_cu = 0;
+    if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) per_block = 0;
+    const size_t lim = (size_t)std::max(std::max(per_cu, per_block), 65536);
+    known[device] = lim;
+    return lim;
+}
+
 template <int BM, int BN, int TRI, int TAG>
-static void launch_one(const TileTask* d_tasks, size_t ntasks, double* const* tab, int nbatch, int ld,
+static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double* const* tab, int nbatch, int ld,
                        size_t dyn, hipStream_t stream, const Signal& sig, const Await& aw)
 {
+    constexpr size_t static_lds = 2 * 16 * (BM + BN + 32) * sizeof(double);
+    if (dyn && static_lds + dyn > lds_limit(c->device)) {
+        c->err = "tile launch: " + std::to_string(static_lds) + " B of LDS plus a pad of " + std::to_string(dyn) +
+                 " B exceed the " + std::to_string(lds_limit(c->device)) + " B a workgroup may have on this device "
+                 "(GPRN_BULK_PAD_KB / GPRN_PAD_SMALL_KB / GPRN_CHAIN_PAD_KB or the *_pad_kb options)";
+        return false;
+    }
     constexpr int per_task = (GPRN_TILE / BM) * (GPRN_TILE / BN);
     constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
                        sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map(),
                        aw.flag2, aw.value2);
+    return true;
 }
 
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
@@ -411,17 +439,19 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     static int pad_small_kb = -1, pad_small_batch = -1;
     if (pad_small_kb < 0) { const char* e = getenv("GPRN_PAD_SMALL_KB"); pad_small_kb = e ? atoi(e) : 64; }
     if (pad_small_batch < 0) { const char* e = getenv("GPRN_PAD_SMALL_BATCH"); pad_small_batch = e ? atoi(e) : 2; }
-    const int kb = nbatch <= pad_small_batch ? pad_small_kb : pad_kb;
+    const int kb = nbatch <= pad_small_batch ? (c->pad_small_kb_opt >= 0 ? c->pad_small_kb_opt : pad_small_kb)
+                                             : (c->pad_kb_opt >= 0 ? c->pad_kb_opt : pad_kb);
     size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
     // The chain's own tile launches (one task: L_{k+1,k}, the B_{k+1,k+1} update) can ask for unused LDS too: with
     // enough of it they only land on CUs that run no bulk workgroup and are not slowed by MFMA-saturating
     // neighbours (GPRN_CHAIN_PAD_KB, experiments).
     static int chain_pad_kb = -1;
     if (chain_pad_kb < 0) { const char* e = getenv("GPRN_CHAIN_PAD_KB"); chain_pad_kb = e ? atoi(e) : 0; }
-    if (chain_pad_kb && ntasks == 1 && (stream == c->stream || stream == c->stream4)) dyn = (size_t)chain_pad_kb * 1024;
+    const int chain_kb = c->chain_pad_kb_opt >= 0 ? c->chain_pad_kb_opt : chain_pad_kb;
+    if (chain_kb && ntasks == 1 && (stream == c->stream || stream == c->stream4)) dyn = (size_t)chain_kb * 1024;
     double* const* tab = (double* const*)d_ptrs;
-#define GO(BM, BN, TRI, TAG) launch_one<BM, BN, TRI, TAG>(d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw)
-    bool known = true;
+#define GO(BM, BN, TRI, TAG) fits = launch_one<BM, BN, TRI, TAG>(c, d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw)
+    bool known = true, fits = true;
     switch (shape * 8 + tag) {
     // panel products (K = 128 against the triangular X_kk; the plain forms when GPRN_TRI=0)
     case TS_64x128_BTRI * 8 + TG_PANEL: GO(64, 128, 1, TG_PANEL); break;
@@ -451,6 +481,7 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
 #undef GO
     prof_end(c);
     if (!known) { c->err = "launch_tiles: no kernel for this shape/tag"; return GPRN_E_ARG; }
+    if (!fits) return GPRN_E_ARG;
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
 }

@@ -111,6 +111,7 @@ struct gprn_ctx {
     std::vector<int> loc_nodes, loc_weights;   // latent GPs of this rank, ascending = slot order
     void* comm = nullptr;            // ncclComm_t
     void* shm = nullptr;             // ShmComm: rehearsal transport of one-GPU boxes (api.hip)
+    double* d_agree = nullptr;       // one word: did any rank's call time out (with_event_fallback, api.hip)
 
     // ---- per latent GP, persistent across sweeps (only for GPs this rank needs)
     std::vector<KernelSpec> kspec;   // G
@@ -147,6 +148,9 @@ struct gprn_ctx {
     int* d_info_cur = nullptr;       // the row factor_invert writes to
     // prediction scratch (gprn_predict): K* and (X K*^T)^T per local GP, [ns_pad x ld] each
     std::vector<double*> predKs, predWT;
+    // host-evaluated matrices staged for the next gprn_predict (gprn_predict_upload): K + 1.25e-12 I (N x N), K* (ns x N), k** (ns)
+    struct PredStage { int ns = 0; std::vector<double> K, Kstar, kss; };
+    std::map<int, PredStage> pred_stage;
     size_t pred_cap = 0;
     double **tab_pred = nullptr;
     int* d_slotgp_all = nullptr;
@@ -165,6 +169,8 @@ struct gprn_ctx {
     int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
+    // LDS pads of the tile launches (gemm_tile.hip launch_tiles), KiB; -1: the environment's / the default
+    int pad_kb_opt = -1, pad_small_kb_opt = -1, chain_pad_kb_opt = -1;
     int sig_budget_ms = -1;          // budget the device word holds
     // enqueued by the next factor_invert right behind the start of its persistent chain kernel (factor.hip)
     std::function<int()> chain_started;
@@ -218,6 +224,7 @@ struct Signal {
 // start until *flag >= value; a wait that times out (about a second) sets *timed_out and goes on.
 struct Await { const unsigned* flag; unsigned value; unsigned* timed_out;
                const unsigned* flag2; unsigned value2; };       // optional second flag, same time-out word
+size_t lds_limit(int device);         // LDS bytes one workgroup may ask for, static + dynamic (gemm_tile.hip)
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
                  Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}, Await aw = Await{nullptr, 0, nullptr},

@@ -366,6 +366,15 @@ class inference:
         r = time[:, None] - time[None, :]
         return kernel(r) + _TINY_NUGGET * np.eye(time.size)
 
+    def _predictKMatrix(self, kernel, time):
+        """Cross-covariance between new times and the data times (meanfield.py:455-471; _gp.py:52-63 for
+        the two-argument kernels), evaluated in Python: the path of user-defined kernels in prediction."""
+        time = np.atleast_1d(np.asarray(time, dtype=float))
+        data_t = np.asarray(self.time, dtype=float)
+        if isinstance(kernel, _TWO_ARGUMENT):
+            return kernel(time[:, None], data_t[None, :])
+        return kernel(time[:, None] - data_t[None, :])
+
     def _sample_from_gp(self, kernel, time=None):
         """
         One draw from the GP prior of `kernel` at `time` (meanfield.py:517-531).  The reference hands the
@@ -559,7 +568,8 @@ class inference:
         ones of the last ELBOcalc, else the `_initMuVar` start point) --
         meanfield.py:1289-1381.  Every latent GP's conditional mean/variance
         (the reference's `_gp.GP.prediction`, one Cholesky + N* solves each) is
-        computed on the GPU (`gprn_predict`); the O(p q N*) combination below is
+        computed on the GPU (`gprn_predict`; on a sharded object by the latent GP's
+        owner, every rank receiving all rows); the O(p q N*) combination below is
         the reference's, including the jitter added once per node.
 
         Returns (mean (N*, p), variance (N*, p)) and, with `separate`, the
@@ -574,17 +584,22 @@ class inference:
                 mu, var = self._mu, self._var
 
         specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
-        if any(sp[0] == 'host' for sp in specs):
-            raise NotImplementedError('prediction needs built-in kernels: a user-defined '
-                                      'covFunction has no device form of its cross-covariance')
         ctx = self._backend()
-        if ctx.world > 1:
-            raise NotImplementedError('call predict on an unsharded inference object')
         key = tuple(self._spec_key(sp) for sp in specs)
         if key != self._prior_key:
             for gp, sp in enumerate(specs):
                 self._send_spec(ctx, gp, sp)
             self._prior_key = None             # the priors must be refactored before the next sweep
+        # a user-defined covFunction has no device form of its cross-covariance: its three matrices are
+        # evaluated here, as the reference evaluates every kernel's (_gp.py:40-63, meanfield.py:436-471),
+        # and handed over; the factorisation and the solves stay on the GPU (owner rank only when sharded)
+        data_t = np.asarray(self.time, dtype=float)
+        for gp, (sp, kernel) in enumerate(zip(specs, chain(nodes, weights))):
+            if sp[0] != 'host' or ctx.owner_of(gp) != ctx.rank:
+                continue
+            ctx.predict_upload(gp, self._tinyNuggetKMatrix(kernel, data_t),
+                               self._predictKMatrix(kernel, tstar),
+                               np.diag(np.atleast_2d(self._tinyNuggetKMatrix(kernel, tstar))))
         ctx.set_muvar(np.asarray(mu, dtype=float), np.asarray(var, dtype=float))
         gmean, gvar, info = ctx.predict(tstar)
         self.last_info = info
@@ -789,12 +804,16 @@ class inference:
         print(f'evaluation for initial values took {time_module.time() - start:.0f} sec')
         print('- adjust your expectations accordingly')
 
-        if 'backend' not in kwargs:
+        # the reference's HDF5 file (meanfield.py:1262-1263) -- written by ONE process: with an SPMD pool
+        # (sharding.EvalPool) every rank runs this same method, and N writers resetting one file end in an
+        # h5py lock error or a corrupt file; the other ranks keep emcee's in-memory backend
+        pool_rank = getattr(kwargs.get('pool'), 'rank', 0)
+        if 'backend' not in kwargs and pool_rank == 0:
             try:
                 be = backends.HDFBackend('gprn.h5')
                 be.reset(nwalkers, ndim)
                 kwargs['backend'] = be
-            except ImportError:                # h5py missing: emcee's default in-memory backend
+            except (ImportError, OSError):     # h5py missing or the file is locked: emcee's in-memory backend
                 pass
         sampler = EnsembleSampler(nwalkers, ndim, logposterior, **kwargs)
         old_tau = np.inf

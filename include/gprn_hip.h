@@ -36,7 +36,8 @@ enum {
     GPRN_E_HIP = -2,      /* HIP runtime error */
     GPRN_E_NODEV = -3,    /* no usable GPU */
     GPRN_E_COMM = -4,     /* RCCL error */
-    GPRN_E_NOMEM = -5
+    GPRN_E_NOMEM = -5,
+    GPRN_E_UNSUPPORTED = -6   /* the request is well-formed but this object has no device form for it (see the entry point) */
 };
 
 /* ---- kernel ids of the fused covariance fill (covfunc.py line numbers) ---- */
@@ -133,9 +134,18 @@ int gprn_sweep(gprn_ctx* ctx, int n_sweeps, int commit,
 /* ---- prediction: conditional mean and variance of every latent GP at `ns` new
  * times from the current variational state (gprn_set_muvar or the last sweep): replaces
  * _gp.GP.prediction (_gp.py:107-138) under inference._Prediction (meanfield.py:1289-1381).
- * mean_out, var_out: (q + q*p, ns) row-major, row = latent GP index; rows of GPs owned by other
- * ranks are left untouched.  Needs device-evaluable kernels (gprn_set_kernel). */
+ * mean_out, var_out: (q + q*p, ns) row-major, row = latent GP index (all of them on every rank: on a sharded context
+ * the owners' rows are broadcast).  Kernels set with gprn_set_kernel are filled on the device; for matrices that came
+ * through gprn_upload_K see gprn_predict_upload. */
 int gprn_predict(gprn_ctx* ctx, int ns, const double* tstar, double* mean_out, double* var_out);
+/* The same for a latent GP whose covariance is a user-defined covFunction subclass (its K came through gprn_upload_K):
+ * the caller evaluates, for the NEXT gprn_predict call with this `ns`, what the reference evaluates in Python --
+ * K_tiny = kernel(t_i - t_j) + 1.25e-12 I (N, N; _gp.GP._kernel_matrix, _gp.py:40-50 = inference._tinyNuggetKMatrix,
+ * meanfield.py:436-452), Kstar = kernel(tstar_i - t_j) (ns, N; _gp.py:52-63 = _predictKMatrix, meanfield.py:455-471)
+ * and kss[i] = the diagonal of _kernel_matrix(kernel, tstar) (ns).  The factorisation and the solves stay on the GPU.
+ * On a sharded context only the owner of `gp` keeps the matrices, and gprn_predict returns every latent GP's rows on
+ * every rank (the owners' results travel as one grouped broadcast). */
+int gprn_predict_upload(gprn_ctx* ctx, int gp, int ns, const double* K_tiny, const double* Kstar, const double* kss);
 
 /* ---- kernel matrices and prior draws outside the ELBO loop ----
  * eval_kernel: K = expr(t_i, t_j) + nugget I at the data times through the fused fill kernel: replaces
@@ -163,7 +173,7 @@ int gprn_grad_matrices(gprn_ctx* ctx, int gp, double* Kinv_out, double* P_out);
  * a = K^-1 m (m: N values, the mean the reference pairs with that kernel; the 1/q of meanfield.py:709 is left to the
  * caller).  dK/dtheta in closed form for a single SquaredExponential, Periodic or QuasiPeriodic (the formulas of
  * covFunction._dk_dpars), by central differences of the kernel program (relative step 1e-6) for every other kernel
- * gprn_set_kernel accepted.  GPRN_E_ARG for a latent GP whose matrix was uploaded (gprn_upload_K). */
+ * gprn_set_kernel accepted.  GPRN_E_UNSUPPORTED for a latent GP whose matrix was uploaded (gprn_upload_K). */
 int gprn_grad_kernel(gprn_ctx* ctx, int gp, const double* m, double* grad_out);
 
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */
@@ -175,6 +185,9 @@ enum {
 int gprn_keep_sigma(gprn_ctx* ctx, int on);   /* form Sigma explicitly during sweeps (ELBOaux shim) */
 int gprn_get_matrix(gprn_ctx* ctx, int which, int gp, double* out);
 int gprn_get_logdet_K(gprn_ctx* ctx, double* out /* q+q*p */);
+/* per-GP scalars of the last sweep: log det B [G], tr(B^-1) [G], m^T K^-1 m [G], <K_j^-1, Sigma_k> [q*q]:
+ * what the entropy (meanfield.py:1069-1093) and the prior term (:992-1067) are assembled from; G = q + q*p */
+int gprn_get_scalars(gprn_ctx* ctx, double* out /* 3 G + q*q */);
 
 /* ---- timing hooks used by bench.py (HIP events on the library's stream) ----
  * milliseconds spent in, and launches of, each kernel family since the last
@@ -192,8 +205,11 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
  * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel
  * wait timed out, in which case the call is re-run on events); "wait_budget_ms" (wall-clock budget of one
  * in-kernel wait); "withhold_inner" (test hook: the n-th in-panel completion flag of every following call is
- * never raised); "fallbacks" (read-only count of re-run calls).  value < 0 only reads; *old (may be NULL)
- * receives the previous value. */
+ * never raised); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb" (KiB of
+ * unused dynamic LDS the bulk tile launches -- batches above / up to two matrices -- and the chain's own tile launches
+ * ask for, to keep CUs open for the latency chain; -2 returns to the environment's / default value; a pad that does not
+ * fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG instead of aborting the queue).  value == -1 only
+ * reads; *old (may be NULL) receives the previous value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 
 /* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----

@@ -480,6 +480,10 @@ if __name__ == '__main__':
             ('cfg3_N4096', 4096, 3, 2, 'QP', False, 2, False, False),
             # BASELINE config 4 (16 latent GPs, four nodes: the cumulative-trace quirk at full size)
             ('cfg4_N4096_q4', 4096, 3, 4, 'QP', False, 1, False, False),
+            # BASELINE config 5's SHAPE (p = 4, q = 3: the cumulative-trace quirk Q1 with three nodes and the
+            # raw-reshape quirk Q2 with four outputs) at sizes the reference finishes in minutes
+            ('cfg5shape_N1024', 1024, 4, 3, 'QP', False, 2, False, False),
+            ('cfg5shape_N2048', 2048, 4, 3, 'QP', False, 2, False, False),
         ]
     for c in cases:
         if want(c[0]):

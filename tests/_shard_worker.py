@@ -3,6 +3,7 @@
 usage: python -m tests._shard_worker <tag> <out.npz> <rendezvous tag>
 with RANK / WORLD_SIZE / LOCAL_RANK in the environment.
 """
+import os
 import sys
 
 import numpy as np
@@ -17,15 +18,41 @@ def main(tag, out, uid_tag):
     nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
     comm = sharding.Comm(tag=uid_tag)
     g = gpyrn.inference(meta['q'], np.array(d['time']), *_cases.data_args(d), comm=comm)
+    if os.environ.get('GPRN_TEST_USER_WEIGHTS'):
+        # the weights as user-defined covFunction subclasses: host-evaluated matrices (gprn_upload_K, and
+        # gprn_predict_upload in prediction) on whichever rank owns them
+        class UserKernel(covfunc.covFunction):
+            def __init__(self, inner):
+                super().__init__(*inner.pars)
+                self._inner = inner
+                self._param_names = inner._param_names
+
+            def __call__(self, r):
+                return self._inner(r)
+        weights = [UserKernel(w) for w in weights]
+        assert weights[0]._device_program() is None
     g.set_components(nodes, weights, means, jit)
     res = {}
     # forced sweeps from the reference's own initial state
     ctx = g._setup_device(g.nodes, g.weights, g.means, g.jitters)
     ctx.set_muvar(d['mu_init'], d['var_init'])
+    hook_rank = int(os.environ.get('GPRN_TEST_WITHHOLD_RANK', -1))
+    if hook_rank == comm.rank:
+        # this rank only: a producer flag that never goes up, so that its in-kernel wait gives up after 20 ms
+        ctx.option('wait_budget_ms', 20)
+        ctx.option('withhold_inner', 2)
     elbo, parts, info = ctx.sweep(meta['nsweeps'], commit=True)
+    if hook_rank == comm.rank:
+        ctx.option('withhold_inner', 0)
+        ctx.option('wait_budget_ms', 2000)
     mu, var = ctx.get_muvar()
     res.update(sw_elbo=elbo, sw_parts=parts, sw_info=info, sw_mu=mu, sw_var=var,
-               logdet_K=ctx.get_logdet_K())
+               logdet_K=ctx.get_logdet_K(), fallbacks=ctx.option('fallbacks'), flags=ctx.option('flags'))
+    if os.environ.get('GPRN_TEST_PREDICT'):
+        ref = np.load(os.path.join(_cases.GOLDEN, 'pred_' + tag + '.npz'))
+        pm, pv, parts_ = g._Prediction(tstar=ref['tstar'], mu=d['mu_final'], var=d['var_final'], separate=True)
+        res.update(pred_mean=pm, pred_var=pv, pred_nodes=np.array(parts_[0], dtype=float),
+                   pred_weights=np.array(parts_[1], dtype=float), pred_info=g.last_info)
     if 'calc_elbo' in d:
         E, mu, var, it = g.ELBOcalc()
         res.update(calc_elbo=E, calc_mu=mu, calc_var=var, calc_iter=it,

@@ -51,6 +51,23 @@ def test_forced_sweeps(tag, form):
     np.testing.assert_allclose(mu, d['mu_final'], rtol=1e-6, atol=1e-8)
 
 
+def test_forced_sweeps_at_config_5_shape():
+    """BASELINE config 5's SHAPE -- p = 4 outputs, q = 3 nodes: the cumulative-trace quirk Q1 with three nodes
+    (meanfield.py:1025,1039-1041) and the raw-reshape quirk Q2 with four outputs (:1021) -- at N = 1024, where the
+    reference itself was run (oracle/gen_golden.py cfg5shape_N1024).  The reference's Jacobi iteration diverges at
+    q = 3 (|ELBO| grows ~16x per sweep: 1.1e6, then 1.4e7), which is the algorithm's, not an implementation's."""
+    meta, d, *_, args = _problem('cfg5shape_N1024')
+    assert (meta['p'], meta['q']) == (4, 3)
+    mu, var = d['mu_init'], d['var_init']
+    for s in range(meta['nsweeps']):
+        E, mu, var, parts = cpu_ref.sweep_B(*args, mu, var)
+        np.testing.assert_allclose(E, d['elbo_sweeps'][s], rtol=1e-8)
+        np.testing.assert_allclose(parts, d['parts_sweeps'][s], rtol=1e-8)
+    np.testing.assert_allclose(mu, d['mu_final'], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var, d['var_final'], rtol=1e-6, atol=1e-12)
+    assert abs(d['elbo_sweeps'][1]) > 5 * abs(d['elbo_sweeps'][0])          # the divergence, as recorded
+
+
 @pytest.mark.parametrize('form', ['ref', 'B'])
 @pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'cfg1_N200', 'mid_N300_p3q2'])
 def test_elbo_calc_trajectory(tag, form):

@@ -65,7 +65,8 @@ SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3']
 MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1']
 
 
-@pytest.mark.parametrize('tag', SMALL + MID + ['cfg2_N2048', 'cfg3_N4096', 'cfg4_N4096_q4'])
+@pytest.mark.parametrize('tag', SMALL + MID + ['cfg2_N2048', 'cfg3_N4096', 'cfg4_N4096_q4',
+                                              'cfg5shape_N1024', 'cfg5shape_N2048'])
 def test_forced_sweeps_match_reference(tag):
     if not _cases.available(tag):
         pytest.skip('fixture not generated')
@@ -303,6 +304,43 @@ def test_sharded_ranks_on_one_gpu(tag, world, tmp_path):
         assert np.array_equal(first['sw_mu'], other['sw_mu'])
 
 
+def test_sharded_fallback_is_rank_coherent(tmp_path):
+    """ADVICE r2 / VERDICT r2 #2: an in-kernel dependency wait that gives up on ONE rank only (rank 1's producer
+    flag is withheld through the test hook, 20 ms budget).  The sweep issues collectives, so the verdict is
+    max-reduced over the ranks before anybody decides: both ranks run the call again on HIP events -- one
+    fallback each, flags latched off on both -- and both reproduce the reference's golden values."""
+    tag = 'mid_N512_p3q2'
+    meta, d = _cases.load(tag)
+    results = _run_ranks('tests._shard_worker', tag, 2, tmp_path, extra_env={'GPRN_TEST_WITHHOLD_RANK': '1'})
+    if any(int(res['flags']) == 1 and int(res['fallbacks']) == 0 for res in results):
+        pytest.skip('device-side flags are off on this box (nothing to time out)')
+    for res in results:
+        assert int(res['sw_info']) == 0
+        assert int(res['fallbacks']) == 1 and int(res['flags']) == 0
+        np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
+        np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
+        np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
+    assert np.array_equal(results[0]['sw_elbo'], results[1]['sw_elbo'])
+
+
+@pytest.mark.parametrize('tag,world,user', [('step_p3q2', 2, False), ('step_p2q3', 3, False), ('mid_N300_p3q2', 2, True)])
+def test_sharded_prediction(tag, world, user, tmp_path):
+    """inference._Prediction on a sharded object (meanfield.py:1289-1381; _gp.py:107-138 per latent GP): the owners
+    predict their latent GPs, the rows travel as one grouped broadcast, every rank combines them -- and, with
+    `user`, the weights are user-defined covFunction subclasses whose K, K* and k** are evaluated on the host of the
+    owning rank (gprn_predict_upload).  Every rank against the reference's own prediction."""
+    ref = np.load(os.path.join(_cases.GOLDEN, 'pred_' + tag + '.npz'))
+    env = {'GPRN_TEST_PREDICT': '1'}
+    if user:
+        env['GPRN_TEST_USER_WEIGHTS'] = '1'
+    for res in _run_ranks('tests._shard_worker', tag, world, tmp_path, extra_env=env):
+        assert int(res['pred_info']) == 0
+        np.testing.assert_allclose(res['pred_nodes'], ref['node_means'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(res['pred_weights'], ref['weight_means'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(res['pred_mean'], ref['mean'], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(res['pred_var'], ref['var'], rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize('env', [{'GPRN_FLAGS': '0'}, {'GPRN_SCHED': '1'}, {'GPRN_SCHED': '2'},
                                  {'GPRN_TRI': '0', 'GPRN_FILL_SYM': '0', 'GPRN_BULK_PAD_KB': '0'}],
                          ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
@@ -349,6 +387,42 @@ def test_prediction_matches_reference(tag):
     # the ELBO path still works afterwards (priors are refactored on demand)
     if 'calc_elbo' in d:
         np.testing.assert_allclose(g.ELBOcalc()[0], float(d['calc_elbo']), rtol=RTOL)
+
+
+class _UserKernel(covfunc.covFunction):
+    """A user-defined covFunction subclass around a built-in: no device program, so K, K* and k** are
+    evaluated in Python and handed to the library (gprn_upload_K, gprn_predict_upload)."""
+
+    def __init__(self, inner):
+        super().__init__(*inner.pars)
+        self._inner = inner
+        self._param_names = inner._param_names
+
+    def __call__(self, r):
+        return self._inner(r)
+
+
+@pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'step_p2q3', 'cfg1_N200', 'mid_N300_p3q2'])
+def test_prediction_with_user_defined_kernels(tag):
+    """VERDICT r2 missing #2: the reference's prediction works for ANY covFunction (_predictKMatrix,
+    meanfield.py:455-471; _gp.GP.prediction, _gp.py:107-138).  The same fixtures with every node and weight kernel
+    swapped for a user subclass: the matrices come from Python, the Cholesky and the solves stay on the GPU."""
+    meta, d, g = _model(tag)
+    ref = np.load(os.path.join(_cases.GOLDEN, 'pred_' + tag + '.npz'))
+    g.set_components([_UserKernel(k) for k in g.nodes], [_UserKernel(k) for k in g.weights], g.means, g.jitters)
+    assert g.nodes[0]._device_program() is None
+    mean, var, parts = g._Prediction(tstar=ref['tstar'], mu=d['mu_final'], var=d['var_final'], separate=True)
+    assert g.last_info == 0
+    np.testing.assert_allclose(np.array(parts[0], dtype=float), ref['node_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(parts[1], dtype=float), ref['weight_means'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mean, ref['mean'], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var, ref['var'], rtol=1e-6, atol=1e-9)
+    # mixed: built-in nodes, user weights; and a single prediction time (the reference's time.size == 1 branch)
+    meta, d, g = _model(tag)
+    g.set_components(g.nodes, [_UserKernel(k) for k in g.weights], g.means, g.jitters)
+    mean1, var1 = g._Prediction(tstar=ref['tstar'][3:4], mu=d['mu_final'], var=d['var_final'])
+    np.testing.assert_allclose(mean1, ref['mean'][3:4], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(var1, ref['var'][3:4], rtol=1e-6, atol=1e-9)
 
 
 def test_predict_default_grid_shapes():
@@ -417,14 +491,19 @@ def test_reference_sweep_beyond_n4096(tag):
 
 def test_cfg5_full_shape_on_one_gpu():
     """BASELINE config 5 as it is (N = 16384, p = 4, q = 3: 15 latent GPs, quirk Q1 with q = 3, ~130 GB)
-    on ONE GPU.  No reference number exists for this shape (7.15.N^3 = 4.6e14 flop per sweep on a CPU),
-    so: (1) every GP's log det K against the N = 16384 reference fixture where the kernel is the same
-    (node 0 / weight 0 of the p = q = 1 problem have identical hyper-parameters and time stamps);
-    (2) B-form identities of the sweep on one node, checked with NumPy from O(N^2) read-backs:
-    log det Sigma, tr(B^-1) and diag Sigma enter the ELBO parts exactly as oracle/cpu_ref.sweep_B
-    computes them; here the entropy and prior parts are recombined from the per-GP scalars the
-    library reports; (3) finite, positive variances, bit-repeatable sweeps."""
+    on ONE GPU.  No reference number exists for this shape at this size (7.15.N^3 = 4.6e14 flop per sweep on
+    a CPU; the shape itself is pinned to the reference at N = 1024 and 2048, cfg5shape_*), so:
+    (1) log det K against the N = 16384 reference fixture where the kernel is the same (node 0 / weight 0 of
+        the p = q = 1 problem have identical hyper-parameters and time stamps);
+    (2) the B-form identities of the first sweep on node 0 and on weight (0, 0), with NumPy/LAPACK from O(N^2)
+        read-backs (K of that latent GP) exactly as oracle/cpu_ref._gp_update_B computes them: diag Sigma,
+        Sigma.pred (the new mean), log det B and tr(B^-1) against the per-GP scalars the library reports;
+    (3) LogL recomputed from the returned state, Ent and LogP recombined on the host from the per-GP scalars
+        (log det K, log det B, tr B^-1, m^T K^-1 m, the cumulative traces of quirk Q1) as cpu_ref.sweep_B does;
+    (4) finite, positive variances, bit-repeatable sweeps."""
+    from scipy.linalg import solve_triangular
     N, p, q, kind = synth.CONFIGS[5]
+    G = q * (p + 1)
     t, ys, es = synth.rv_series(N, p)
     spec = synth.component_spec(p, q, kind)
     nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
@@ -440,16 +519,69 @@ def test_cfg5_full_shape_on_one_gpu():
         np.testing.assert_allclose(ld[0], 2 * dd['logdiag_Lf'][0], rtol=1e-9)
         np.testing.assert_allclose(ld[q], 2 * dd['logdiag_Lw'][0], rtol=1e-9)
     mu0, var0 = g._initMuVar(nodes, weights, jit)
+    yraw = np.array(ys)
+    yres = yraw - np.array([np.zeros(N) if m is None else m(t) for m in means])
+    variance = np.array(jit)[:, None] ** 2 + np.array(es) ** 2
+
+    # ---- one sweep, then the identities on node 0 and weight (0, 0)
+    ctx.set_muvar(mu0, var0)
+    e1, parts1, info = ctx.sweep(1, commit=True)
+    assert info == 0
+    mu1, var1 = ctx.get_muvar()
+    sc = ctx.get_scalars()
+    muF0, muW0 = cpu_ref.split_u(mu0, p, q, N)
+    varF0, varW0 = cpu_ref.split_u(var0, p, q, N)
+
+    def b_form(gp, d_vec, pred):
+        K = ctx.get_matrix(_hip.M_K, gp)
+        s = np.sqrt(d_vec)
+        K *= s[:, None]
+        K *= s[None, :]
+        K[np.diag_indices(N)] += 1.0
+        L = np.linalg.cholesky(K)
+        del K
+        logdetB = 2.0 * np.sum(np.log(np.diag(L)))
+        # Sigma pred = D^-1/2 (I - B^-1) D^-1/2 pred, B^-1 v by two triangular solves
+        qv = pred / s
+        sig_pred = (qv - solve_triangular(L, solve_triangular(L, qv, lower=True), lower=True, trans='T')) / s
+        X = solve_triangular(L, np.eye(N), lower=True, overwrite_b=True)
+        del L
+        binv_diag = np.einsum('ij,ij->j', X, X)
+        return (1.0 - binv_diag) / d_vec, sig_pred, logdetB, binv_diag.sum()
+
+    d_n, pred_n = cpu_ref._node_d_and_pred(yres, variance, muF0, muW0, varW0, 0)
+    ds, m_new, ldB, trB = b_form(0, d_n, pred_n)
+    np.testing.assert_allclose(var1[0, 0], ds, rtol=1e-7, atol=1e-14)
+    np.testing.assert_allclose(mu1[0, 0], m_new, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sc['logdetB'][0], ldB, rtol=1e-10)
+    np.testing.assert_allclose(sc['trBinv'][0], trB, rtol=1e-9)
+    d_w, pred_w = cpu_ref._weight_d_and_pred(yres, variance, mu1[0], var1[0], muW0, 0, 0)
+    ds, m_new, ldB, trB = b_form(q, d_w, pred_w)
+    np.testing.assert_allclose(var1[1, 0], ds, rtol=1e-7, atol=1e-14)
+    np.testing.assert_allclose(mu1[1, 0], m_new, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(sc['logdetB'][q], ldB, rtol=1e-10)
+    np.testing.assert_allclose(sc['trBinv'][q], trB, rtol=1e-9)
+
+    # ---- Ent and LogP of that sweep from the per-GP scalars, as oracle/cpu_ref.sweep_B puts them together
+    ent = 0.5 * G * N * (1 + cpu_ref.LOG2PI) + 0.5 * np.sum(ld - sc['logdetB'])
+    tr = sc['trBinv'].copy()
+    for j in range(q):
+        tr[j] += sum(sc['q1'][j, k] for k in range(j))             # quirk Q1: + tr(K_j^-1 Sigma_k), k < j
+    logp = -0.5 * N * G * cpu_ref.LOG2PI - 0.5 * np.sum(ld) - 0.5 * np.sum(sc['muKmu'] + tr)
+    np.testing.assert_allclose(parts1[0, 2], ent, rtol=1e-10)
+    np.testing.assert_allclose(parts1[0, 1], logp, rtol=1e-10)
+    logl = cpu_ref.expected_loglike(yraw, variance, mu1[0], mu1[1:], var1[0], np.transpose(var1[1:], (1, 0, 2)))
+    np.testing.assert_allclose(parts1[0, 0], logl, rtol=RTOL)
+    np.testing.assert_allclose(e1, parts1.sum(axis=1) / q, rtol=1e-12)     # meanfield.py:709
+
+    # ---- two sweeps: finite, positive, bit-repeatable
     ctx.set_muvar(mu0, var0)
     e_a, parts_a, info = ctx.sweep(2, commit=True)
     assert info == 0 and np.all(np.isfinite(e_a)) and np.all(np.isfinite(parts_a))
+    assert e_a[0] == e1[0]
     mu, var = ctx.get_muvar()
     assert np.all(var > 0) and np.all(np.isfinite(mu))
-    # ELBO = (LogL + LogP + Ent) / q  (meanfield.py:709)
     np.testing.assert_allclose(e_a, parts_a.sum(axis=1) / q, rtol=1e-12)
-    # the likelihood part from the returned state alone (O(pqN), oracle arithmetic; diag Sigma = var)
-    yraw = np.array(ys)
-    variance = np.array(jit)[:, None] ** 2 + np.array(es) ** 2
     logl = cpu_ref.expected_loglike(yraw, variance, mu[0], mu[1:], var[0], np.transpose(var[1:], (1, 0, 2)))
     np.testing.assert_allclose(parts_a[-1, 0], logl, rtol=RTOL)
     ctx.set_muvar(mu0, var0)
