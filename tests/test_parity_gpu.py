@@ -420,8 +420,11 @@ def test_prediction_with_user_defined_kernels(tag):
     # mixed: built-in nodes, user weights; and a single prediction time (the reference's time.size == 1 branch)
     meta, d, g = _model(tag)
     g.set_components(g.nodes, [_UserKernel(k) for k in g.weights], g.means, g.jitters)
-    mean1, var1 = g._Prediction(tstar=ref['tstar'][3:4], mu=d['mu_final'], var=d['var_final'])
-    np.testing.assert_allclose(mean1, ref['mean'][3:4], rtol=1e-7, atol=1e-9)
+    # (the latent GPs' own predictions and the variance: a mean function such as Linear centres on the mean of the
+    # times it is given, meanfunc.py, so the GPRN mean at ONE time is not row 3 of the fixture)
+    _, var1, parts1 = g._Prediction(tstar=ref['tstar'][3:4], mu=d['mu_final'], var=d['var_final'], separate=True)
+    np.testing.assert_allclose(np.array(parts1[0], dtype=float), ref['node_means'][:, 3:4], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(np.array(parts1[1], dtype=float), ref['weight_means'][:, 3:4], rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(var1, ref['var'][3:4], rtol=1e-6, atol=1e-9)
 
 
