@@ -62,6 +62,7 @@ SIGNATURES = {
     'gprn_comm_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
+    'gprn_test_queue_plan': (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
@@ -96,6 +97,20 @@ def load_library():
 
 def device_count():
     return int(load_library().gprn_device_count())
+
+
+def queue_plan(T, outer=4):
+    """Nodes (n, 12) and edges (m, 2) of the dataflow schedule's task graph for T tile steps (host only)."""
+    lib = load_library()
+    n, m = c_int64(0), c_int64(0)
+    rc = lib.gprn_test_queue_plan(int(T), int(outer), byref(n), byref(m), None, None)
+    if rc:
+        raise BackendError(f'gprn_test_queue_plan failed ({rc})')
+    ops = np.zeros((n.value, 12), dtype=np.int64)
+    edges = np.zeros((m.value, 2), dtype=np.int64)
+    lib.gprn_test_queue_plan(int(T), int(outer), byref(n), byref(m), ops.ctypes.data_as(POINTER(c_int64)),
+                             edges.ctypes.data_as(POINTER(c_int64)))
+    return ops, edges
 
 
 def _f64(a, shape=None):

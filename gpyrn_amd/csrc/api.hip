@@ -167,6 +167,8 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //   "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb"  unused dynamic LDS of the bulk launches (batches above / up to two
 //                    matrices) and of the chain's own tile launches, KiB (-2: back to the environment / default).  A pad that does
 //                    not fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG
+//   "queue"          1/0: the factorisation as a task graph run by a persistent worker kernel (queue.hip; needs "flags"), or
+//                    the launch-per-step schedule of factor.hip
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -176,6 +178,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     if (!strcmp(name, "flags")) { factor_use_flags(c); field = &c->use_flags; }
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
+    else if (!strcmp(name, "queue")) { queue_enabled(c); field = &c->queue_mode; }
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "chain_pad_kb")) field = &c->chain_pad_kb_opt;
@@ -345,6 +348,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         comm_teardown(c);
         free_problem(c);
         dev_free(c->d_tasks);
+        queue_free(c);
         if (c->d_sig) hipFree(c->d_sig);
         dev_free(c->d_agree);
         dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
@@ -1038,7 +1042,9 @@ static int run_phase(gprn_ctx* c, bool weights)
                 c->d_ptrs = node_tab;
                 HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
                 int rc = GPRN_OK;
-                if (n_inv && !c->keep_sigma) rc = lauum_lower(c, n_inv, c->stream2);
+                // (the dataflow schedule takes the product along as filler of its worker kernel: queue.hip)
+                if (n_inv && !c->keep_sigma && !c->q_lauum_in_queue) rc = lauum_lower(c, n_inv, c->stream2);
+                c->q_lauum.n = 0;
                 for (int s = 0; s < ns && !rc; ++s) {
                     const int k = node_gps[s];
                     for (int j = k + 1; j < c->q && !rc; ++j)
@@ -1051,6 +1057,16 @@ static int run_phase(gprn_ctx* c, bool weights)
                 return GPRN_OK;
             };
             c->q1_pending = true;
+            // offer the product to the next factorisation's worker kernel (taken when the dataflow schedule runs it)
+            c->q_lauum.n = 0;
+            if (n_inv && !c->keep_sigma && n_inv <= 16) {
+                c->q_lauum.rows.assign((size_t)n_inv * GPRN_NBUF, nullptr);
+                for (int s = 0; s < n_inv; ++s) {
+                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_B] = c->wsB[s];
+                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_X] = c->wsX[s];
+                }
+                c->q_lauum.n = n_inv;
+            }
         }
     }
     if (weights && c->chain_started) {

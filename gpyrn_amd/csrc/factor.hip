@@ -17,6 +17,7 @@
 // update touches (T-1-k)(T-k)/2 + (T-1-k)(k+1) tiles -- roughly constant until
 // the tail, unlike POTRF alone.  Flops: N^3/3 + N^3/3.
 #include "gprn_internal.h"
+#include "dag.h"
 #include "tile_mma.h"
 
 #include <math.h>
@@ -638,6 +639,36 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
     diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
+}
+
+// The same kernel as a node of the dataflow schedule (queue.hip): it polls its own node and tells its successors.
+template <bool ARGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_diag_block_q(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
+                    QueueCtl q, unsigned qop)
+{
+    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    const int slot = blockIdx.x;
+    q_await(q, slot, qop);
+    const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
+    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
+    q_complete(q, slot, qop, false);
+}
+
+int launch_diag_q(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
+                  const QueueCtl& q, unsigned op)
+{
+    prof_begin(c, GPRN_T_DIAG, stream);
+    PtrArgs pa;
+    if (tab_rows(c, d_ptrs, nbatch, &pa))
+        hipLaunchKernelGGL(k_diag_block_q<true>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info, q, op);
+    else
+        hipLaunchKernelGGL(k_diag_block_q<false>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info, q, op);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
 }
 
 void tab_note(gprn_ctx* c, double** d_tab, double* const* rows, size_t count)
@@ -1413,6 +1444,10 @@ int factor_check_waits(gprn_ctx* c)
                         sum[5] / n, sum[6] / n + sum[7] / n);
         }
     }
+    {
+        const int rq = queue_check_waits(c);
+        if (rq) return rq;
+    }
     if (!c->d_sig) return GPRN_OK;
     unsigned flag = 0;
     HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -1449,6 +1484,23 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (rc) return rc;
     static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
+    if (split_sched() && queue_enabled(c) && c->T > 1) {
+        rc = factor_invert_queue(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
+        if (rc) {
+            // an enqueue that broke off half-way leaves kernels polling for nodes nobody will finish: end their waits
+            // (the results are void, the caller gets the error), then clear the verdict that belongs to this call
+            if (c->d_qctr) {
+                const unsigned one = 1u;
+                unsigned* const tmo = c->d_qctr + (2 * GPRN_QCLASSES + 1) * GPRN_QCTR_STRIDE;
+                (void)hipMemcpy(tmo, &one, sizeof(unsigned), hipMemcpyHostToDevice);
+                (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2);
+                (void)hipStreamSynchronize(c->stream3);
+                (void)hipMemset(tmo, 0, sizeof(unsigned));
+            }
+            c->q_lauum.n = 0;
+        }
+        return rc;
+    }
     if (split_sched()) {
         rc = factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
         if (rc && c->d_sig && c->use_flags == 1) {

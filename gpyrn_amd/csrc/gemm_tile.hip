@@ -28,10 +28,12 @@
 #include "gprn_internal.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <type_traits>
 
+#include "dag.h"
 #include "tile_mma.h"
 
 // Output tile of one workgroup: BM x BN in {64,128}^2, computed by NW = 4 waves (2 x 2) or 8 waves (2 x 4).
@@ -168,15 +170,18 @@ __device__ unsigned long long rows_stamps[8];
 // rows, fully coalesced; eight waves fetching all of it themselves kept the CU's vector memory path busy for 3.5 us
 // -- and the X_kk rows come straight from global memory, 16 (Q + 1) columns of them.
 #define ROWS_PITCH 136                              // doubles per LDS row: 16-byte reads of 64 lanes spread over all banks
-template <bool ARGS>
+// QUEUE: a node of the dataflow schedule (queue.hip) -- q / qop / q_skip_wait replace the flag arguments
+template <bool ARGS, bool QUEUE = false>
 __global__ __launch_bounds__(512)
 void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t b_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2)
+               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2,
+               QueueCtl q, unsigned qop, int q_skip_wait)
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
     RW_STAMP(0);
-    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
+    else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
     RW_STAMP(1);
     const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -217,7 +222,8 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    if (QUEUE) q_complete(q, blockIdx.y, qop, false);
+    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 
@@ -284,14 +290,16 @@ void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __
 
 // MODE 1, one single-wave workgroup per lower 16 x 16 block (36 per matrix, each on a CU of its own: 32 KiB of
 // operands per CU instead of 256)
-template <bool ARGS>
+template <bool ARGS, bool QUEUE = false>
 __global__ __launch_bounds__(64)
 void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t c_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2)
+               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2,
+               QueueCtl q, unsigned qop, int q_skip_wait)
 {
     RW_STAMP(0);
-    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
+    else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
     RW_STAMP(1);
     int P = 0;
     while ((P + 1) * (P + 2) / 2 <= (int)blockIdx.x) ++P;
@@ -323,7 +331,8 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    if (QUEUE) q_complete(q, blockIdx.y, qop, false);
+    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 
@@ -342,14 +351,43 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
     PtrArgs pa;
     const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
     unsigned* const tmo = aw.timed_out ? aw.timed_out : sig.timed_out;
-#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
-                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2)
-#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2)
+    QueueCtl noq;
+    memset(&noq, 0, sizeof(noq));
+#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A, false>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
+                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0)
+#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A, false>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
+                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0)
     if (mode == 0) { if (args) GO_L(true); else GO_L(false); }
     else { if (args) GO_U(true); else GO_U(false); }
 #undef GO_L
 #undef GO_U
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// the same two launches as nodes of the dataflow schedule (queue.hip)
+int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, hipStream_t stream,
+                       const QueueCtl& q, unsigned op, bool skip_wait)
+{
+    if (nbatch == 0) return GPRN_OK;
+    auto toff = [&](int ti, int tj) { return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE; };
+    const int64_t a_off = toff(k + 1, k), b_off = mode == 0 ? toff(k, k) : toff(k + 1, k);
+    const int64_t c_off = mode == 0 ? toff(k + 1, k) : toff(k + 1, k + 1);
+    prof_begin(c, GPRN_T_PANEL, stream);
+    double* const* tab = (double* const*)d_ptrs;
+    PtrArgs pa;
+    const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
+    const unsigned* const nf = nullptr;
+    unsigned* const ns = nullptr;
+#define GO_LQ(A) hipLaunchKernelGGL((k_chain_l<A, true>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
+                                    b_off, ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0)
+#define GO_UQ(A) hipLaunchKernelGGL((k_chain_u<A, true>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
+                                    ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0)
+    if (mode == 0) { if (args) GO_LQ(true); else GO_LQ(false); }
+    else { if (args) GO_UQ(true); else GO_UQ(false); }
+#undef GO_LQ
+#undef GO_UQ
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

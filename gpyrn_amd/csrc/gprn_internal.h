@@ -55,6 +55,40 @@ static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode) {
         }                                                                      \
     } while (0)
 
+// ---- dataflow schedule of the factorisation (queue.hip) -------------------------------------
+// The factorisation as ONE task graph per matrix: the latency chain's three kernels per tile step stay launches
+// on the chain stream; every other tile product is a node that a persistent worker kernel executes as soon as
+// its inputs exist.  Dependencies are edges between tasks (derived on the host from the sequential algorithm:
+// read-after-write, write-after-write, write-after-read on 128 x 128 tiles); a finished task decrements its
+// successors' counters and pushes the ones that reach zero onto a ready queue of their priority class.
+struct QOp {                       // one node (the graph is the same for every matrix of a batch)
+    TileTask t;                    // tile nodes: the product; chain nodes: unused
+    uint32_t succ0, nsucc;         // successors: succ[succ0 .. succ0 + nsucc)
+    uint8_t kind, cls, nent, flags;// QK_*; priority class; ready-queue entries the node is pushed as; QF_*
+    uint8_t pad[4];
+};
+enum { QK_TILE = 0, QK_PANEL_L = 1, QK_PANEL_X = 2, QK_CHAIN = 3 };
+enum { QF_DIAG_SYRK = 1 };         // C -= A A^T on a diagonal tile: the upper-right 64 x 64 quarter is never read
+#define GPRN_QCLASSES 5            // ready queues, most urgent first; the last holds the previous phase's X^T X
+#define GPRN_QCTR_STRIDE 32        // words between two counters (a 128-byte line each)
+#define GPRN_Q_EMPTY 0xffffffffu       // slot of a ready queue: nothing pushed yet
+#define GPRN_Q_TAKEN 0xfffffffeu       // ... its entry has been claimed
+#define GPRN_Q_WHOLE 7u            // sub-tile field of a queue entry: the whole 128 x 128 node
+struct QueueCtl {                  // by value to every kernel that takes part
+    const QOp* ops;
+    const uint32_t* succ;
+    unsigned* state;               // [matrix][node]: bits 0-15 unmet dependencies, bits 16-31 entries not finished
+    unsigned* slots[GPRN_QCLASSES];
+    unsigned cap[GPRN_QCLASSES];
+    unsigned* ctr;                 // counters, GPRN_QCTR_STRIDE apart: head[c] at c, tail[c] at QCLASSES + c, then `left`
+    unsigned* timed_out;           // [0] sticky "a wait gave up", [1] budget of one wait, 100 MHz ticks
+    int nops;
+};
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline unsigned q_entry(unsigned m, unsigned sub, unsigned op) { return (m << 24) | (sub << 21) | op; }
+
 struct Profiler {
     bool on = false;
     struct Rec { int fam; hipEvent_t a, b; };
@@ -177,6 +211,18 @@ struct gprn_ctx {
     unsigned long long* d_stamps = nullptr;   // GPRN_CHAIN_STAMPS: clock stamps of the chain kernel (probes)
     int stamps_T = 0;
     size_t tasks_cap = 0;
+    // dataflow schedule (queue.hip): one plan per (T, set), device buffers grown on demand
+    struct QueuePlanRef* qplan[2] = {nullptr, nullptr};
+    unsigned* d_qstate = nullptr; size_t qstate_cap = 0;
+    unsigned* d_qslots = nullptr; size_t qslots_cap = 0;
+    unsigned* d_qctr = nullptr;      // counters + time-out word + budget
+    hipEvent_t ev_qreset = nullptr, ev_qdone = nullptr;
+    int queue_mode = -1;             // 1: dataflow schedule when device-side waits are usable; 0: launches; -1: environment
+    int q_budget_ms = -1;
+    // X^T X of the previous phase handed to the next factorisation's worker kernel as filler (run_phase, api.hip)
+    struct { int n = 0; std::vector<double*> rows; } q_lauum;     // rows: n x GPRN_NBUF pointers (BUF_B out, BUF_X in)
+    bool q_lauum_in_queue = false;   // while the hand-over hook runs: the product was the worker kernel's
+    double q_last_ms = 0.0;          // (profiling) duration of the last worker kernel
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: column k+1)
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
@@ -321,4 +367,15 @@ int ensure_tasks(gprn_ctx* c);
 #define GPRN_E_WAIT_TIMEOUT (-100)
 int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel dependency wait timed out since the last check
 int factor_use_flags(gprn_ctx* c);
+// queue.hip
+int queue_enabled(gprn_ctx* c);                          // dataflow schedule for this context's next factorisation?
+int factor_invert_queue(gprn_ctx* c, int nbatch, int set);
+void queue_free(gprn_ctx* c);
+int queue_check_waits(gprn_ctx* c);                      // GPRN_E_WAIT_TIMEOUT if a wait of the dataflow schedule gave up
+// chain kernels inside the dataflow schedule: op = node of the launch (same for every matrix), skip_wait: the launch is
+// preceded by a one-wave wait kernel on its stream and does not poll itself
+int launch_diag_q(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
+                  const QueueCtl& q, unsigned op);
+int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, hipStream_t stream,
+                       const QueueCtl& q, unsigned op, bool skip_wait);
 int factor_probe_streams(gprn_ctx* c);

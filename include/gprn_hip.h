@@ -205,7 +205,9 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
  * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel
  * wait timed out, in which case the call is re-run on events); "wait_budget_ms" (wall-clock budget of one
  * in-kernel wait); "withhold_inner" (test hook: the n-th in-panel completion flag of every following call is
- * never raised); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb" (KiB of
+ * never raised -- under the dataflow schedule: one node of the task graph never becomes ready); "queue" (1: the factorisation
+ * runs as a task graph on a persistent worker kernel, csrc/queue.hip -- the default wherever "flags" is 1 --, 0: one launch
+ * per family and tile step, csrc/factor.hip); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb" (KiB of
  * unused dynamic LDS the bulk tile launches -- batches above / up to two matrices -- and the chain's own tile launches
  * ask for, to keep CUs open for the latency chain; -2 returns to the environment's / default value; a pad that does not
  * fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG instead of aborting the queue).  value == -1 only
@@ -225,6 +227,11 @@ int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
 /* back-to-back v_mfma_f64_16x16x4_f64 from registers on every CU: the measured fp64 MFMA
  * ceiling of this device in TFLOP/s (what roofline fractions can be judged against) */
 int gprn_test_mfma_peak(gprn_ctx* ctx, int wg_per_cu, int iters, double* tflops);
+/* The task graph of the dataflow schedule (csrc/queue.hip) for T tile steps and outer panels of `outer` tiles, for
+ * host-side checks (no GPU is touched): n_ops nodes x 12 int64 (kind 0 tile / 1 panel L / 2 panel X / 3 chain, priority
+ * class, queue entries, flags, c_buf, a_buf, b_buf, modes, c_off, a_off, b_off, klen; ld = 128 T; chain nodes: c_buf =
+ * 0 diag / 1 L_{k+1,k} / 2 update of B_{k+1,k+1}, klen = k) and n_edges x 2 (from, to).  Null arrays: counts only. */
+int gprn_test_queue_plan(int T, int outer, int64_t* n_ops, int64_t* n_edges, int64_t* ops_out, int64_t* edges_out);
 /* out = lower(X^T X) for lower-triangular X */
 int gprn_test_lauum(gprn_ctx* ctx, int n, const double* X, double* out);
 
