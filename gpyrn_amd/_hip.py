@@ -62,6 +62,7 @@ SIGNATURES = {
     'gprn_comm_allreduce_sum': (c_int, [c_void_p, _dp, c_int]),
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
+    'gprn_test_gemm_rate': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp]),
     'gprn_test_queue_plan': (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
@@ -374,6 +375,13 @@ class Context:
         info = self._check(self._lib.gprn_test_factor_invert(self._h, n, batch, _ptr(A), _ptr(L), _ptr(X)),
                            'test_factor_invert')
         return L, X, info
+
+    def gemm_rate(self, M, N, K, how, reps=3):
+        """TFLOP/s of C -= A.B^T (M x N x K) through the tile contraction: how 0 / 1 = one launch (64 x 64 / 128 x 128
+        workgroups), 2 / 3 = independent nodes of the dataflow schedule's worker kernel (per quarter / per node)."""
+        v = c_double(0.0)
+        self._check(self._lib.gprn_test_gemm_rate(self._h, int(M), int(N), int(K), int(how), int(reps), byref(v)), 'test_gemm_rate')
+        return 2.0 * M * N * K / (v.value * 1e-3) / 1e12
 
     def mfma_peak(self, wg_per_cu=1, iters=2000):
         """Measured fp64 MFMA issue ceiling (TFLOP/s) of this device."""

@@ -81,6 +81,7 @@ extern "C" int gprn_profile_read(gprn_ctx* c, double* ms, int64_t* launches, int
     DeviceLock lock_(c);
     if (!c) return GPRN_E_ARG;
     prof_collect(c);
+    queue_print_stats(c);
     for (int i = 0; i < GPRN_T_COUNT; ++i) {
         if (ms) ms[i] = c->prof.ms[i];
         if (launches) launches[i] = c->prof.n[i];
@@ -1708,6 +1709,60 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
     for (int m = 0; m < M; ++m)
         for (int n = 0; n < N; ++n) C[(size_t)m * N + n] = hc[(size_t)m * ld + n];
     return GPRN_OK;
+}
+
+// Rate of the tile contraction on an M x N x K product C -= A.B^T of random data already on the device (diagnostic):
+// how = 0 / 1: one launch of the tile kernel, 64 x 64 / 128 x 128 workgroups; 2 / 3: the same tasks as independent nodes
+// of the dataflow schedule's worker kernel, one queue entry per 64 x 64 quarter / per node.  ms: average of `reps` runs.
+extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, int reps, double* ms)
+{
+    DeviceLock lock_(c);
+    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || reps < 1 || !ms || how < 0 || how > 3)
+        return bad(c, "test_gemm_rate: bad argument");
+    const int ld = std::max(std::max(M, N), K);
+    TRY(test_setup(c, ld, 3, 1));
+    const size_t nn = (size_t)ld * ld;
+    {
+        std::vector<double> h(nn);
+        unsigned long long x = 88172645463325252ull;
+        for (size_t i = 0; i < nn; ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; h[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+        for (int b = 0; b < 3; ++b) HIP_TRY(c, hipMemcpy(c->d_test[b], h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    }
+    std::vector<TileTask> tasks;
+    for (int ti = 0; ti < M / GPRN_TILE; ++ti)
+        for (int tj = 0; tj < N / GPRN_TILE; ++tj)
+            tasks.push_back(TileTask{(int64_t)ti * GPRN_TILE * ld + (int64_t)tj * GPRN_TILE, (int64_t)ti * GPRN_TILE * ld,
+                                     (int64_t)tj * GPRN_TILE * ld, K, 2, 0, 1, tile_modes(CM_SUB, 0, 0)});
+    TileTask* d_t = nullptr;
+    double** d_p = nullptr;
+    TRY(dev_alloc(c, &d_t, tasks.size()));
+    TRY(dev_alloc(c, &d_p, GPRN_NBUF));
+    double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], c->d_test[2], nullptr};
+    HIP_TRY(c, hipMemcpy(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice));
+    int rc = GPRN_OK;
+    float t = 0.f;
+    if (how >= 2) rc = queue_run_independent(c, tasks, d_p, ld, how == 3, reps, &t);
+    else {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        float total = 0.f;
+        for (int r = 0; r < reps + 1 && !rc; ++r) {
+            hipEventRecord(e0, c->stream);
+            rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, how == 0 ? TS_64x64 : TS_128x128);
+            hipEventRecord(e1, c->stream);
+            hipEventSynchronize(e1);
+            float tt = 0.f;
+            hipEventElapsedTime(&tt, e0, e1);
+            if (r) total += tt;
+        }
+        t = total / reps;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    hipStreamSynchronize(c->stream);
+    hipFree(d_t); tab_forget(c, d_p); hipFree(d_p);
+    *ms = t;
+    return rc;
 }
 
 // run the library's own factorisation on caller matrices: temporarily a tiny "problem"

@@ -23,7 +23,8 @@ __device__ __forceinline__ void q_store(unsigned* p, unsigned v)
 }
 __device__ __forceinline__ unsigned* q_head(const QueueCtl& q, int c) { return q.ctr + c * GPRN_QCTR_STRIDE; }
 __device__ __forceinline__ unsigned* q_tail(const QueueCtl& q, int c) { return q.ctr + (GPRN_QCLASSES + c) * GPRN_QCTR_STRIDE; }
-__device__ __forceinline__ unsigned* q_left(const QueueCtl& q) { return q.ctr + 2 * GPRN_QCLASSES * GPRN_QCTR_STRIDE; }
+__device__ __forceinline__ unsigned* q_left(const QueueCtl& q) { return q.ctr + QC_LEFT * GPRN_QCTR_STRIDE; }
+__device__ __forceinline__ unsigned* q_bell(const QueueCtl& q) { return q.ctr + QC_BELL * GPRN_QCTR_STRIDE; }
 
 // one lane: node `op` of matrix m has all its inputs -- onto the ready queue of its class, nent entries
 __device__ __forceinline__ void q_push(const QueueCtl& q, unsigned m, unsigned op)
@@ -31,23 +32,42 @@ __device__ __forceinline__ void q_push(const QueueCtl& q, unsigned m, unsigned o
     const QOp* o = q.ops + op;
     const unsigned cls = o->cls, n = o->nent;
     const unsigned at = __hip_atomic_fetch_add(q_tail(q, cls), n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (n == 1) { q_store(q.slots[cls] + at, q_entry(m, GPRN_Q_WHOLE, op)); return; }
-    const bool syrk = o->flags & QF_DIAG_SYRK;             // quarters 0, 2, 3 only
-    for (unsigned e = 0; e < n; ++e) q_store(q.slots[cls] + at + e, q_entry(m, syrk && e ? e + 1 : e, op));
+    if (n == 1) q_store(q.slots[cls] + at, q_entry(m, GPRN_Q_WHOLE, op));
+    else {
+        const bool syrk = o->flags & QF_DIAG_SYRK;         // quarters 0, 2, 3 only
+        for (unsigned e = 0; e < n; ++e) q_store(q.slots[cls] + at + e, q_entry(m, syrk && e ? e + 1 : e, op));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the entries have landed before the bell rings
+    // the doorbell: ONE word that idle workers watch, instead of every class's head and tail (hundreds of idle
+    // workgroups polling ten lines each every few microseconds slowed every kernel on the chip two- to threefold)
+    __hip_atomic_fetch_add(q_bell(q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // a wait of the schedule: *p & mask == 0 within the budget; false when it (or an earlier one) gave up
-__device__ __forceinline__ bool q_spin_zero(const unsigned* p, unsigned mask, unsigned* timed_out)
+__device__ __forceinline__ bool q_spin_zero(const unsigned* p, unsigned mask, unsigned* timed_out, unsigned at_most = 0)
 {
-    if ((q_load(p) & mask) == 0) return true;
+    if ((q_load(p) & mask) <= at_most) return true;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long budget = timed_out[1];
     for (;;) {
-        __builtin_amdgcn_s_sleep(4);
-        if ((q_load(p) & mask) == 0) return true;
+        __builtin_amdgcn_s_sleep(32);                      // ~1 us: up to 36 workgroups per matrix poll the same word
+        if ((q_load(p) & mask) <= at_most) return true;
         if (q_load(timed_out)) return false;
         if (__builtin_amdgcn_s_memrealtime() - t0 > budget) { atomicExch(timed_out, 1u); return false; }
     }
+}
+
+// GPRN_QUEUE_TRACE: one record of the call's timeline -- who (a queue entry and the worker, or a chain node), and three
+// stamps of the 100 MHz clock.  One lane calls it.
+__device__ __forceinline__ void q_trace(const QueueCtl& q, unsigned long long who, unsigned long long t1, unsigned long long t2,
+                                        unsigned long long t3)
+{
+    if (!q.trace) return;
+    const unsigned long long at = atomicAdd(q.trace, 1ull);
+    if (at >= (unsigned long long)q.trace_cap) return;
+    unsigned long long* r = q.trace + 1 + 4 * at;
+    r[0] = who | ((unsigned long long)(unsigned)q.call_id << 56);
+    r[1] = t1; r[2] = t2; r[3] = t3;
 }
 
 // start of a chain kernel: every thread of the workgroup calls it; returns once the node's inputs are there

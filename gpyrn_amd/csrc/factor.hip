@@ -649,12 +649,16 @@ void k_diag_block_q(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kb
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
     const int slot = blockIdx.x;
+    const unsigned long long t0 = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     q_await(q, slot, qop);
+    const unsigned long long t1 = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
     diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     q_complete(q, slot, qop, false);
+    if (q.trace && threadIdx.x == 0)
+        q_trace(q, (unsigned long long)q_entry(slot, 0, qop) | (0xffffull << 32), t0, t1, __builtin_amdgcn_s_memrealtime());
 }
 
 int launch_diag_q(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
@@ -1491,7 +1495,7 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
             // (the results are void, the caller gets the error), then clear the verdict that belongs to this call
             if (c->d_qctr) {
                 const unsigned one = 1u;
-                unsigned* const tmo = c->d_qctr + (2 * GPRN_QCLASSES + 1) * GPRN_QCTR_STRIDE;
+                unsigned* const tmo = c->d_qctr + QC_TIMEOUT * GPRN_QCTR_STRIDE;
                 (void)hipMemcpy(tmo, &one, sizeof(unsigned), hipMemcpyHostToDevice);
                 (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->stream2);
                 (void)hipStreamSynchronize(c->stream3);

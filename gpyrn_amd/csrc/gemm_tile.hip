@@ -180,8 +180,10 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
     RW_STAMP(0);
+    const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -222,8 +224,11 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    if (QUEUE) q_complete(q, blockIdx.y, qop, false);
-    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    if (QUEUE) {
+        q_complete(q, blockIdx.y, qop, false);
+        if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
+            q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
+    } else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 
@@ -298,8 +303,10 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
                QueueCtl q, unsigned qop, int q_skip_wait)
 {
     RW_STAMP(0);
+    const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     int P = 0;
     while ((P + 1) * (P + 2) / 2 <= (int)blockIdx.x) ++P;
@@ -331,8 +338,11 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    if (QUEUE) q_complete(q, blockIdx.y, qop, false);
-    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    if (QUEUE) {
+        q_complete(q, blockIdx.y, qop, false);
+        if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
+            q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
+    } else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 

@@ -71,6 +71,12 @@ enum { QK_TILE = 0, QK_PANEL_L = 1, QK_PANEL_X = 2, QK_CHAIN = 3 };
 enum { QF_DIAG_SYRK = 1 };         // C -= A A^T on a diagonal tile: the upper-right 64 x 64 quarter is never read
 #define GPRN_QCLASSES 5            // ready queues, most urgent first; the last holds the previous phase's X^T X
 #define GPRN_QCTR_STRIDE 32        // words between two counters (a 128-byte line each)
+// counters of a call (index x GPRN_QCTR_STRIDE words into QueueCtl::ctr): per class the head hint and the tail, entries
+// not finished yet, the time-out word (+1: budget), the doorbell idle workers watch, CUs registered per XCD (8 words in
+// one line); behind them the CU registry (one word per CU) and an image of the control block
+enum { QC_HEAD = 0, QC_TAIL = GPRN_QCLASSES, QC_LEFT = 2 * GPRN_QCLASSES, QC_TIMEOUT, QC_BELL, QC_XCC, QC_COUNT };
+#define GPRN_QCU_WORDS 1024        // registry: word xcc * 128 + se * 32 + sh * 16 + cu
+#define GPRN_QCTR_WORDS (QC_COUNT * GPRN_QCTR_STRIDE + GPRN_QCU_WORDS)
 #define GPRN_Q_EMPTY 0xffffffffu       // slot of a ready queue: nothing pushed yet
 #define GPRN_Q_TAKEN 0xfffffffeu       // ... its entry has been claimed
 #define GPRN_Q_WHOLE 7u            // sub-tile field of a queue entry: the whole 128 x 128 node
@@ -80,9 +86,11 @@ struct QueueCtl {                  // by value to every kernel that takes part
     unsigned* state;               // [matrix][node]: bits 0-15 unmet dependencies, bits 16-31 entries not finished
     unsigned* slots[GPRN_QCLASSES];
     unsigned cap[GPRN_QCLASSES];
-    unsigned* ctr;                 // counters, GPRN_QCTR_STRIDE apart: head[c] at c, tail[c] at QCLASSES + c, then `left`
+    unsigned* ctr;                 // counters (QC_*), GPRN_QCTR_STRIDE words apart, then the CU registry
     unsigned* timed_out;           // [0] sticky "a wait gave up", [1] budget of one wait, 100 MHz ticks
-    int nops;
+    unsigned long long* trace;     // GPRN_QUEUE_TRACE: [0] records written, then 4 words per record (queue.hip); else null
+    int nops, trace_cap, call_id;
+    int per_cu, reserve_per_xcc;   // workers that stay per CU; CUs per XCD left to the chain's kernels (0 workers)
 };
 #ifdef __HIPCC__
 __host__ __device__
@@ -222,7 +230,9 @@ struct gprn_ctx {
     // X^T X of the previous phase handed to the next factorisation's worker kernel as filler (run_phase, api.hip)
     struct { int n = 0; std::vector<double*> rows; } q_lauum;     // rows: n x GPRN_NBUF pointers (BUF_B out, BUF_X in)
     bool q_lauum_in_queue = false;   // while the hand-over hook runs: the product was the worker kernel's
-    double q_last_ms = 0.0;          // (profiling) duration of the last worker kernel
+    unsigned long long* d_qstats = nullptr;   // GPRN_QUEUE_STATS=1: per-worker tick counters (queue.hip)
+    unsigned long long* d_qtrace = nullptr;   // GPRN_QUEUE_TRACE=n: n records of what ran when (queue.hip)
+    int qtrace_cap = 0, q_calls = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: column k+1)
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
@@ -371,6 +381,8 @@ int factor_use_flags(gprn_ctx* c);
 int queue_enabled(gprn_ctx* c);                          // dataflow schedule for this context's next factorisation?
 int factor_invert_queue(gprn_ctx* c, int nbatch, int set);
 void queue_free(gprn_ctx* c);
+void queue_print_stats(gprn_ctx* c);
+int queue_run_independent(gprn_ctx* c, const std::vector<TileTask>& tasks, double** d_ptrs, int ld, bool whole, int reps, float* ms);
 int queue_check_waits(gprn_ctx* c);                      // GPRN_E_WAIT_TIMEOUT if a wait of the dataflow schedule gave up
 // chain kernels inside the dataflow schedule: op = node of the launch (same for every matrix), skip_wait: the launch is
 // preceded by a one-wave wait kernel on its stream and does not poll itself

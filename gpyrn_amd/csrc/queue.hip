@@ -265,8 +265,70 @@ static void plan_free(QueuePlanRef* P)
     delete P;
 }
 
+// GPRN_QUEUE_STATS=1: what the workers did since the last call of this, summed over the workers (printed by
+// gprn_destroy and by gprn_profile_read)
+// GPRN_QUEUE_TRACE=n: the records so far go to $GPRN_QUEUE_TRACE_FILE (default gpurun_out/queue_trace.bin): a header
+// {magic, records, nodes of the last plan}, the records (4 x u64), then per node of that plan 4 x i32 (kind, class, K,
+// C tile as buf << 16 | i << 8 | j) -- profiles/queue_timeline.py reads it
+static void queue_dump_trace(gprn_ctx* c)
+{
+    if (!c->d_qtrace) return;
+    (void)hipDeviceSynchronize();
+    unsigned long long n = 0;
+    if (hipMemcpy(&n, c->d_qtrace, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess || n == 0) return;
+    n = std::min<unsigned long long>(n, (unsigned long long)c->qtrace_cap);
+    std::vector<unsigned long long> rec((size_t)n * 4);
+    if (hipMemcpy(rec.data(), c->d_qtrace + 1, rec.size() * sizeof(rec[0]), hipMemcpyDeviceToHost) != hipSuccess) return;
+    (void)hipMemset(c->d_qtrace, 0, sizeof(unsigned long long));
+    const QueuePlanRef* P = c->qplan[0] ? c->qplan[0] : c->qplan[1];
+    const char* path = getenv("GPRN_QUEUE_TRACE_FILE");
+    FILE* f = fopen(path ? path : "gpurun_out/queue_trace.bin", "wb");
+    if (!f) return;
+    const unsigned long long head[4] = {0x47505251ull, n, P ? (unsigned long long)P->ops.size() : 0ull, P ? (unsigned long long)P->T : 0ull};
+    fwrite(head, sizeof(head), 1, f);
+    fwrite(rec.data(), sizeof(rec[0]), rec.size(), f);
+    if (P)
+        for (const QOp& o : P->ops) {
+            const int64_t row = (int64_t)GPRN_TILE * P->T * GPRN_TILE;
+            const int ld = P->T * GPRN_TILE;
+            int32_t v[4] = {o.kind, o.cls, o.t.klen,
+                            o.kind == QK_CHAIN ? (int32_t)o.t.c_buf : (int32_t)((o.t.c_buf << 16) | ((o.t.c_off / row) << 8) | ((o.t.c_off % ld) / GPRN_TILE))};
+            fwrite(v, sizeof(v), 1, f);
+        }
+    fclose(f);
+    fprintf(stderr, "[gprn] queue trace: %llu records written\n", n);
+}
+
+void queue_print_stats(gprn_ctx* c)
+{
+    queue_dump_trace(c);
+    if (!c->d_qstats) return;
+    std::vector<unsigned long long> h((size_t)4096 * 16);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(h.data(), c->d_qstats, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) != hipSuccess) return;
+    (void)hipMemset(c->d_qstats, 0, h.size() * sizeof(h[0]));
+    double tot[16] = {0};
+    int nw = 0;
+    for (int w = 0; w < 4096; ++w) {
+        if (!h[(size_t)w * 16 + 6]) continue;
+        ++nw;
+        for (int i = 0; i < 16; ++i) tot[i] += (double)h[(size_t)w * 16 + i];
+    }
+    if (!nw || tot[4] == 0) return;
+    const double us = 0.01;                        // 100 MHz ticks
+    const double all = tot[0] + tot[1] + tot[2] + tot[3] + tot[7] + tot[8];
+    fprintf(stderr, "[gprn] queue workers: %d workgroups x %.0f launches, %.0f entries; per entry us: idle %.2f  claim %.2f  acquire %.2f  "
+                    "node+pointers %.2f  contraction %.2f  completion %.2f  (K per entry %.0f); share of worker time: idle %.1f %%, "
+                    "contraction %.1f %%\n",
+            nw, tot[6] / nw, tot[4], tot[0] * us / tot[4], tot[7] * us / tot[4], tot[1] * us / tot[4], tot[8] * us / tot[4],
+            tot[2] * us / tot[4], tot[3] * us / tot[4], 16.0 * tot[5] / tot[4], 100.0 * tot[0] / all, 100.0 * tot[2] / all);
+}
+
 void queue_free(gprn_ctx* c)
 {
+    queue_print_stats(c);
+    if (c->d_qstats) { hipFree(c->d_qstats); c->d_qstats = nullptr; }
+    if (c->d_qtrace) { hipFree(c->d_qtrace); c->d_qtrace = nullptr; }
     for (int s = 0; s < 2; ++s) { plan_free(c->qplan[s]); c->qplan[s] = nullptr; }
     if (c->d_qstate) hipFree(c->d_qstate);
     if (c->d_qslots) hipFree(c->d_qslots);
@@ -300,19 +362,26 @@ __global__ void k_queue_init(QueueCtl q, QueueCtl* __restrict__ qimg, const uint
                 v = q_entry((unsigned)(nbatch + i / n_lauum), GPRN_Q_WHOLE, (unsigned)(lauum0 + i % n_lauum));
             q.slots[cl][i] = v;
         }
-    if (tid < 2 * GPRN_QCLASSES + 1) {
+    if (tid < QC_COUNT && tid != QC_TIMEOUT) {
         unsigned v = 0;
-        if (tid == 2 * GPRN_QCLASSES) v = left_total;
-        if (tid == 2 * GPRN_QCLASSES - 1) v = (unsigned)n_extra * (unsigned)n_lauum;       // tail of the last class
+        if (tid == QC_LEFT) v = left_total;
+        if (tid == QC_TAIL + GPRN_QCLASSES - 1) v = (unsigned)n_extra * (unsigned)n_lauum;       // tail of the last class
+        if (tid == QC_XCC) for (int x = 1; x < 8; ++x) q.ctr[tid * GPRN_QCTR_STRIDE + x] = 0u;
         q.ctr[tid * GPRN_QCTR_STRIDE] = v;
     }
+    for (size_t i = tid; i < GPRN_QCU_WORDS; i += nth) q.ctr[QC_COUNT * GPRN_QCTR_STRIDE + i] = 0u;
 }
 
 // One-wave wait on a stream, in front of a chain launch whose workgroups would otherwise all poll: lane m waits for
 // node `op` of matrix m.
-__global__ void k_queue_wait(QueueCtl q, unsigned op, int nbatch)
+// (op2: a second node that may start once all but `left2` of its inputs are there -- the B_{k+1,k+1} update, whose
+// last input is the L_{k+1,k} launch right in front of it on the stream)
+__global__ void k_queue_wait(QueueCtl q, unsigned op, int nbatch, unsigned op2, unsigned left2)
 {
-    for (int m = threadIdx.x; m < nbatch; m += 64) (void)q_spin_zero(q.state + (size_t)m * q.nops + op, 0xffffu, q.timed_out);
+    for (int m = threadIdx.x; m < nbatch; m += 64) {
+        (void)q_spin_zero(q.state + (size_t)m * q.nops + op, 0xffffu, q.timed_out);
+        if (op2 != ~0u) (void)q_spin_zero(q.state + (size_t)m * q.nops + op2, 0xffffu, q.timed_out, left2);
+    }
 }
 
 // The next ready entry for this workgroup (its first wave calls it, all 64 lanes), or GPRN_Q_EMPTY when every entry
@@ -326,13 +395,15 @@ __global__ void k_queue_wait(QueueCtl q, unsigned op, int nbatch)
 //     long queue at different 64-slot windows, so that a burst is handed out in parallel rather than one
 //     compare-and-swap at a time.
 //   * head is a hint: every slot below it is TAKEN.  A worker that finds TAKEN slots at the head moves it (atomic max).
-__device__ __forceinline__ unsigned q_claim(const QueueCtl& q, unsigned wid)
+__device__ __forceinline__ unsigned q_claim(const QueueCtl& q, unsigned wid, unsigned long long* t_pass = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long budget = q.timed_out[1];
     const unsigned rot = (wid * 2654435761u) >> 26;                 // this worker's first lane, 0..63
+    unsigned seen_bell = q_load(q_bell(q));
     for (unsigned pass = 0;; ++pass) {
+        if (t_pass) *t_pass = __builtin_amdgcn_s_memrealtime();
         unsigned hv = 0;
         if (lane < GPRN_QCLASSES) hv = q_load(q_head(q, lane));
         else if (lane >= 8 && lane < 8 + GPRN_QCLASSES) hv = q_load(q_tail(q, lane - 8));
@@ -362,12 +433,27 @@ __device__ __forceinline__ unsigned q_claim(const QueueCtl& q, unsigned wid)
         }
         if (q_load(q_left(q)) == 0u) return GPRN_Q_EMPTY;
         if (q_load(q.timed_out)) return GPRN_Q_EMPTY;
-        if ((pass & 63u) == 63u && __builtin_amdgcn_s_memrealtime() - t0 > budget) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
             // nothing became ready for a whole budget: the producers are gone (a serialising tool, a lost launch)
             if (lane == 0) atomicExch(q.timed_out, 1u);
             return GPRN_Q_EMPTY;
         }
-        __builtin_amdgcn_s_sleep(2);
+        // Nothing for this workgroup: nap until the doorbell moves (or a while has passed -- entries that were being
+        // claimed by others when this pass looked may have been left).  Naps are long: what matters is the polling rate of
+        // ALL idle workgroups together (hundreds of them each reading a line every few microseconds slowed every kernel on
+        // the chip two- to threefold, MI355X_MICROARCH.md "polling-cost"), and with many asleep at different phases a new
+        // entry is still seen within a fraction of one nap.
+        if (pass < 2) { __builtin_amdgcn_s_sleep(16); continue; }
+        const unsigned bell = q_load(q_bell(q));
+        if (bell != seen_bell) { seen_bell = bell; continue; }
+        for (int nap = 0; nap < 8; ++nap) {
+            __builtin_amdgcn_s_sleep(127);                       // ~3.4 us
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+            __builtin_amdgcn_s_sleep(127);
+            const unsigned b2 = q_load(q_bell(q));
+            if (b2 != seen_bell) { seen_bell = b2; break; }
+        }
     }
 }
 
@@ -416,12 +502,31 @@ __device__ __forceinline__ Piece piece_of(const TileTask& t, int kind, int sub, 
     return p;
 }
 
-// All parts of one queue entry.  Out of line: inlined into the worker's loop the contraction's registers add to
-// everything the loop keeps live (150+ VGPRs; the same code needs 82 as a kernel of its own, k_tile_gemm).
-__device__ __attribute__((noinline)) void run_node(double* lds, const TileTask t, int kind, int flags, unsigned sub,
-                                                   double* g0, double* g1, double* g2, double* g3, int ld)
+// All parts of one queue entry.  (Tried out of line, to keep the contraction's registers apart from the loop's: the
+// arguments then travel in VGPRs, and even declared uniform again with readfirstlane the call cost ~25 us per entry.)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uni(int64_t v)
 {
-    double* const gp[GPRN_NBUF] = {g0, g1, g2, g3};
+    const unsigned lo = uni((unsigned)(uint64_t)v), hi = uni((unsigned)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <typename P>
+__device__ __forceinline__ P* uni(P* p) { return (P*)(uintptr_t)uni((int64_t)(uintptr_t)p); }
+
+__device__ __forceinline__ void run_node(double* lds_, const TileTask t_, int kind_, int flags_, unsigned sub_,
+                                                   double* g0, double* g1, double* g2, double* g3, int ld_)
+{
+    double* const lds = uni(lds_);
+    TileTask t;
+    t.c_off = uni(t_.c_off); t.a_off = uni(t_.a_off); t.b_off = uni(t_.b_off); t.klen = uni(t_.klen);
+    {
+        const unsigned packed = uni((unsigned)t_.c_buf | ((unsigned)t_.a_buf << 8) | ((unsigned)t_.b_buf << 16) | ((unsigned)t_.modes << 24));
+        t.c_buf = (uint8_t)packed; t.a_buf = (uint8_t)(packed >> 8); t.b_buf = (uint8_t)(packed >> 16); t.modes = (uint8_t)(packed >> 24);
+    }
+    const int kind = uni(kind_), flags = uni(flags_), ld = uni(ld_);
+    const unsigned sub = uni(sub_);
+    double* const gp[GPRN_NBUF] = {uni(g0), uni(g1), uni(g2), uni(g3)};
     const int c_mode = t.modes & 3, a_mode = (t.modes >> 2) & 1, b_mode = (t.modes >> 3) & 1;
     const int first = sub != GPRN_Q_WHOLE ? (int)sub : 0, end = sub != GPRN_Q_WHOLE ? (int)sub + 1 : (kind == QK_TILE ? 4 : 2);
     const int npass = kind == QK_TILE ? 1 : 2;
@@ -449,9 +554,14 @@ struct QExtra { double* p[GPRN_Q_EXTRA][GPRN_NBUF]; };
 // (four waves per SIMD as the register budget: 128 VGPRs without a spill -- at 96, which would let two of these
 // workgroups share a CU with a diagonal-block workgroup, the contraction spills; the launch leaves a few CUs with ONE
 // worker instead, see factor_invert_queue)
-__global__ __launch_bounds__(256, 4)
-void k_tile_queue(const QueueCtl* __restrict__ qp, double* const* __restrict__ ptrs, int nbatch, QExtra extra, int ld)
+// stats (GPRN_QUEUE_STATS=1, else null): per workgroup 8 words -- 100 MHz ticks spent looking for an entry, in the
+// acquire, in the contractions, in the completion; entries done; K summed over them / 16
+template <bool STATS>
+__global__ __launch_bounds__(256, 5)
+void k_tile_queue(const QueueCtl* __restrict__ qp, double* const* __restrict__ ptrs, int nbatch, QExtra extra, int ld,
+                  unsigned long long* __restrict__ stats_)
 {
+    unsigned long long* const stats = STATS ? stats_ : nullptr;     // (the counters cost ~20 VGPRs: a kernel of their own)
     // (the control block by reference: by value its sixteen pointers stay in SGPRs across the contraction, the kernel
     // runs out of them and the spills cost VGPRs)
     const QueueCtl& q = *qp;
@@ -460,9 +570,45 @@ void k_tile_queue(const QueueCtl* __restrict__ qp, double* const* __restrict__ p
     // whatever the launch bound says
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ unsigned s_entry;
+    // ---- placement (experiments; off unless GPRN_QUEUE_WG_PER_CU > 0).  The hardware decides where workgroups go;
+    // which of them STAY can be decided here: every workgroup registers on its CU (HW_ID / XCC_ID); the first
+    // `reserve_per_xcc` CUs of each XCD to be registered are vacated, everywhere else at most `per_cu` workgroups stay.
+    // Measured: vacated CUs do not help the chain -- its launches are dealt to a shader engine and wait for THAT one to
+    // have room (milliseconds, with every other CU of it full) instead of going to the empty CUs elsewhere.
+    if (q.per_cu > 0) {
+        if (threadIdx.x == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7u;
+            const unsigned key = xcc * 128u + ((hw >> 13) & 3u) * 32u + ((hw >> 12) & 1u) * 16u + ((hw >> 8) & 15u);
+            unsigned* const reg = q.ctr + QC_COUNT * GPRN_QCTR_STRIDE + key;
+            const unsigned n = __hip_atomic_fetch_add(reg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffu;
+            unsigned state;
+            if (n == 0) {
+                const unsigned r = __hip_atomic_fetch_add(q.ctr + QC_XCC * GPRN_QCTR_STRIDE + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                state = r < (unsigned)q.reserve_per_xcc ? 0x30000u : 0x10000u;
+                __hip_atomic_fetch_or(reg, state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                state = q_load(reg);
+                for (int spin = 0; spin < 200 && !(state & 0x10000u); ++spin) { __builtin_amdgcn_s_sleep(8); state = q_load(reg); }
+            }
+            s_entry = (state & 0x20000u) ? 0u : (n < (unsigned)q.per_cu ? 1u : 0u);
+        }
+        __syncthreads();
+        if (!s_entry) return;
+        __syncthreads();
+    }
+    unsigned long long st_idle = 0, st_claim = 0, st_acq = 0, st_desc = 0, st_run = 0, st_done = 0, st_n = 0, st_k = 0, tq = 0, t_found = 0, t_start = 0;
+#define Q_STAMP(acc) do { if (stats) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - tq; tq = now_; } } while (0)
+    if (stats) tq = __builtin_amdgcn_s_memrealtime();
     for (;;) {
         if (threadIdx.x < 64) {
-            const unsigned e = q_claim(q, blockIdx.x);
+            unsigned long long t_pass = 0;
+            const unsigned e = q_claim(q, blockIdx.x, stats ? &t_pass : nullptr);
+            if (stats) { st_idle += t_pass - tq; tq = t_pass; }
+            if (STATS && q.trace) t_found = __builtin_amdgcn_s_memrealtime();
+            Q_STAMP(st_claim);
             if (e != GPRN_Q_EMPTY) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -470,6 +616,7 @@ void k_tile_queue(const QueueCtl* __restrict__ qp, double* const* __restrict__ p
             if (threadIdx.x == 0) s_entry = e;
         }
         __syncthreads();
+        Q_STAMP(st_acq);
         const unsigned e = __builtin_amdgcn_readfirstlane(s_entry);   // in an SGPR: the node, its pointers and modes stay scalar
         if (e == GPRN_Q_EMPTY) break;
         const unsigned m = e >> 24, sub = (e >> 21) & 7u, op = e & 0x1fffffu;
@@ -480,15 +627,31 @@ void k_tile_queue(const QueueCtl* __restrict__ qp, double* const* __restrict__ p
 #pragma unroll
         for (int b2 = 0; b2 < GPRN_NBUF; ++b2)
             gp[b2] = m < (unsigned)nbatch ? ptrs[(size_t)m * GPRN_NBUF + b2] : extra.p[(m - nbatch) & (GPRN_Q_EXTRA - 1)][b2];
+        if (stats) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the node and its pointers have arrived)
+        Q_STAMP(st_desc);
+        if (STATS && q.trace) t_start = __builtin_amdgcn_s_memrealtime();
         run_node(lds, t, kind, flags, sub, gp[0], gp[1], gp[2], gp[3], ld);
+        Q_STAMP(st_run);
         q_complete(q, m, op, true);                        // (its barrier also covers s_entry and the LDS stages)
+        Q_STAMP(st_done);
+        if (STATS && q.trace && threadIdx.x == 0)
+            q_trace(q, (unsigned long long)e | ((unsigned long long)blockIdx.x << 32), t_found, t_start, __builtin_amdgcn_s_memrealtime());
+        st_n += 1; st_k += (unsigned)t.klen / 16 * (sub == GPRN_Q_WHOLE ? 4 : 1);
+    }
+#undef Q_STAMP
+    if (stats && threadIdx.x == 0) {
+        unsigned long long* o = stats + (size_t)blockIdx.x * 16;
+        o[0] += st_idle; o[1] += st_acq; o[2] += st_run; o[3] += st_done; o[4] += st_n; o[5] += st_k; o[6] += 1; o[7] += st_claim;
+        o[8] += st_desc;
     }
 }
 
 // ------------------------------------------------------------------ host side of a call
 int queue_enabled(gprn_ctx* c)
 {
-    if (c->queue_mode < 0) c->queue_mode = env_int("GPRN_QUEUE", 1) ? 1 : 0;
+    // opt-in (GPRN_QUEUE=1 or gprn_set_option "queue"): correct everywhere it was tried, but 45 % slower than the launch
+    // schedule at BASELINE config 3 -- DESIGN.md §8 has the measurements and what they say
+    if (c->queue_mode < 0) c->queue_mode = env_int("GPRN_QUEUE", 0) ? 1 : 0;
     return c->queue_mode == 1 && factor_use_flags(c) == 1;
 }
 
@@ -496,9 +659,31 @@ int queue_check_waits(gprn_ctx* c)
 {
     if (!c->d_qctr) return GPRN_OK;
     unsigned flag = 0;
-    unsigned* const tmo = c->d_qctr + (2 * GPRN_QCLASSES + 1) * GPRN_QCTR_STRIDE;
+    unsigned* const tmo = c->d_qctr + QC_TIMEOUT * GPRN_QCTR_STRIDE;
     HIP_TRY(c, hipMemcpy(&flag, tmo, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (flag) {
+        if (env_int("GPRN_QUEUE_DEBUG", 0)) {
+            // what the call looked like when it gave up: the counters and the CU registry
+            std::vector<unsigned> h(GPRN_QCTR_WORDS);
+            if (hipMemcpy(h.data(), c->d_qctr, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "[gprn] queue at time-out: left %u bell %u;", h[QC_LEFT * GPRN_QCTR_STRIDE], h[QC_BELL * GPRN_QCTR_STRIDE]);
+                for (int cl = 0; cl < GPRN_QCLASSES; ++cl)
+                    fprintf(stderr, " class %d head %u tail %u;", cl, h[(QC_HEAD + cl) * GPRN_QCTR_STRIDE], h[(QC_TAIL + cl) * GPRN_QCTR_STRIDE]);
+                fprintf(stderr, "\n[gprn] CUs registered per XCD:");
+                for (int x = 0; x < 8; ++x) fprintf(stderr, " %u", h[QC_XCC * GPRN_QCTR_STRIDE + x]);
+                int hist[8] = {0}, reserved = 0, cus = 0;
+                for (int k = 0; k < GPRN_QCU_WORDS; ++k) {
+                    const unsigned w = h[QC_COUNT * GPRN_QCTR_STRIDE + k];
+                    if (!w) continue;
+                    ++cus;
+                    if (w & 0x20000u) ++reserved;
+                    hist[std::min(7u, w & 0xffffu)] += 1;
+                }
+                fprintf(stderr, "; %d CUs seen, %d reserved; CUs by workgroups registered:", cus, reserved);
+                for (int i = 0; i < 8; ++i) fprintf(stderr, " %d:%d", i, hist[i]);
+                fprintf(stderr, "\n");
+            }
+        }
         hipMemset(tmo, 0, sizeof(unsigned));
         c->err = "factorisation: a wait of the dataflow schedule timed out";
         return GPRN_E_WAIT_TIMEOUT;
@@ -544,19 +729,32 @@ int factor_invert_queue(gprn_ctx* c, int nbatch, int set)
     if ((rc = grow(c, &c->d_qslots, &c->qslots_cap, total))) return rc;
     if (!c->d_qctr) {
         // counters, the time-out word and its budget, then an image of the control block for the workers
-        HIP_TRY(c, hipMalloc(&c->d_qctr, (2 * GPRN_QCLASSES + 2) * GPRN_QCTR_STRIDE * sizeof(unsigned) + sizeof(QueueCtl)));
-        HIP_TRY(c, hipMemset(c->d_qctr, 0, (2 * GPRN_QCLASSES + 2) * GPRN_QCTR_STRIDE * sizeof(unsigned) + sizeof(QueueCtl)));
+        HIP_TRY(c, hipMalloc(&c->d_qctr, GPRN_QCTR_WORDS * sizeof(unsigned) + sizeof(QueueCtl)));
+        HIP_TRY(c, hipMemset(c->d_qctr, 0, GPRN_QCTR_WORDS * sizeof(unsigned) + sizeof(QueueCtl)));
         c->q_budget_ms = -1;
     }
     if (!c->ev_qreset) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_qreset, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_qdone, hipEventDisableTiming));
     }
-    unsigned* const tmo = c->d_qctr + (2 * GPRN_QCLASSES + 1) * GPRN_QCTR_STRIDE;
+    unsigned* const tmo = c->d_qctr + QC_TIMEOUT * GPRN_QCTR_STRIDE;
     if (c->q_budget_ms != c->wait_budget_ms) {
         const unsigned ticks = (unsigned)std::min<long long>(0xffffffffll, (long long)c->wait_budget_ms * 100000ll);
         HIP_TRY(c, hipMemcpy(tmo + 1, &ticks, sizeof(unsigned), hipMemcpyHostToDevice));
         c->q_budget_ms = c->wait_budget_ms;
+    }
+    static int want_stats = -1;
+    if (want_stats < 0) want_stats = env_int("GPRN_QUEUE_STATS", 0);
+    if (want_stats && !c->d_qstats) {
+        HIP_TRY(c, hipMalloc(&c->d_qstats, (size_t)4096 * 16 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_qstats, 0, (size_t)4096 * 16 * sizeof(unsigned long long)));
+    }
+    static int want_trace = -1;
+    if (want_trace < 0) want_trace = env_int("GPRN_QUEUE_TRACE", 0);
+    if (want_trace > 0 && !c->d_qtrace) {
+        HIP_TRY(c, hipMalloc(&c->d_qtrace, ((size_t)want_trace * 4 + 1) * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_qtrace, 0, ((size_t)want_trace * 4 + 1) * sizeof(unsigned long long)));
+        c->qtrace_cap = want_trace;
     }
     // ---- the rows of the X^T X matrices travel as a kernel argument
     QExtra extra;
@@ -574,6 +772,9 @@ int factor_invert_queue(gprn_ctx* c, int nbatch, int set)
         for (int cl = 0; cl < GPRN_QCLASSES; ++cl) { q.slots[cl] = at; q.cap[cl] = (unsigned)cap[cl]; at += cap[cl] + 32; }
     }
     q.ctr = c->d_qctr; q.timed_out = tmo; q.nops = (int)nops;
+    q.trace = c->d_qtrace; q.trace_cap = c->qtrace_cap; q.call_id = c->q_calls++;
+    q.per_cu = env_int("GPRN_QUEUE_WG_PER_CU", 0);                 // > 0: placement by registration (experiments)
+    q.reserve_per_xcc = env_int("GPRN_QUEUE_RESERVE", 0);
     size_t left = 0;
     for (int cl = 0; cl < GPRN_QCLASSES; ++cl) left += cap[cl];
     hipStream_t s0 = c->stream, s1 = c->stream3;
@@ -584,7 +785,7 @@ int factor_invert_queue(gprn_ctx* c, int nbatch, int set)
         for (uint32_t v = P->n_main / 2; v < P->n_main && hold_op < 0; ++v)
             if (P->ops[v].kind != QK_CHAIN) hold_op = (int)v;
     // ---- reset on the chain stream, then the workers on the side stream
-    QueueCtl* const qimg = (QueueCtl*)(c->d_qctr + (2 * GPRN_QCLASSES + 2) * GPRN_QCTR_STRIDE);
+    QueueCtl* const qimg = (QueueCtl*)(c->d_qctr + GPRN_QCTR_WORDS);
     hipLaunchKernelGGL(k_queue_init, dim3(512), dim3(256), 0, s0, q, qimg, (const uint32_t*)P->d_init, (int)P->n_main, nbatch,
                        (int)P->lauum0, (int)P->n_lauum, n_extra, (unsigned)left, hold_op);
     HIP_TRY(c, hipGetLastError());
@@ -592,22 +793,22 @@ int factor_invert_queue(gprn_ctx* c, int nbatch, int set)
     HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_qreset, 0));
     static int n_cu = 0;
     if (!n_cu) { hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device); if (n_cu <= 0) n_cu = 256; }
-    // two workgroups per CU, not three: an LDS pad makes a third one not fit, so that every CU keeps room for a
-    // diagonal-block workgroup (46.6 KB, one wave per SIMD with ~290 VGPRs) beside them
-    const int per_cu = env_int("GPRN_QUEUE_WG_PER_CU", 2);
+    // TWO workgroups per CU, on every CU: at 96 VGPRs a worker wave leaves a diagonal-block workgroup (one wave per SIMD
+    // with 282 VGPRs, 46.6 KB of LDS) room on the same CU, so the chain's kernels can be dispatched ANYWHERE.  That matters:
+    // the dispatcher does not search the chip for a CU with room -- with CUs set aside for the chain (placement, below)
+    // the chain's launches waited milliseconds for the shader engine they had been dealt to, while the reserved CUs
+    // elsewhere stood empty.  An LDS pad keeps a third worker off a CU (2 x 54.9 + 46.6 KB fit the 160).
     const size_t static_lds = 2 * 16 * (64 + 64 + 32) * sizeof(double) + 64;      // (the stages are dynamic LDS: k_tile_queue)
-    size_t pad = 0;
-    if (per_cu >= 1 && per_cu <= 3) {
-        const size_t share = lds_limit(c->device) / (per_cu + 1) + 1024;       // more than a (per_cu + 1)-th of the CU's LDS
-        pad = share > static_lds ? share - static_lds : 0;
-        if (per_cu == 3) pad = 0;
-    }
-    // ... and a diagonal-block workgroup (one wave per SIMD with ~290 VGPRs, 46.6 KB) fits a CU beside ONE worker, not
-    // two: the launch is short of 2 per CU by `room` workgroups, so at least that many CUs keep a free half
-    const int room = env_int("GPRN_QUEUE_ROOM", std::max(8, 2 * nbatch));
-    const int nwg = std::max(1, env_int("GPRN_QUEUE_WORKERS", per_cu * n_cu - room));
+    const int wg_per_cu = std::min(3, std::max(1, env_int("GPRN_QUEUE_LAUNCH_PER_CU", 2)));
+    const size_t share = lds_limit(c->device) / (wg_per_cu + 1) + 1024;            // more than a (wg_per_cu + 1)-th of the CU's LDS
+    const size_t pad = wg_per_cu < 3 && share > static_lds ? share - static_lds : 0;
+    const int nwg = std::max(1, env_int("GPRN_QUEUE_WORKERS", wg_per_cu * n_cu));
+    if (nwg > 4096) { c->err = "queue schedule: too many workers"; return GPRN_E_ARG; }
     prof_begin(c, GPRN_T_UPDATE, s1);
-    hipLaunchKernelGGL(k_tile_queue, dim3(nwg), dim3(256), static_lds + pad, s1, (const QueueCtl*)qimg, (double* const*)c->d_ptrs, nbatch, extra, ld);
+    if (c->d_qstats || c->d_qtrace)
+        hipLaunchKernelGGL(k_tile_queue<true>, dim3(nwg), dim3(256), static_lds + pad, s1, (const QueueCtl*)qimg, (double* const*)c->d_ptrs, nbatch, extra, ld, c->d_qstats);
+    else
+        hipLaunchKernelGGL(k_tile_queue<false>, dim3(nwg), dim3(256), static_lds + pad, s1, (const QueueCtl*)qimg, (double* const*)c->d_ptrs, nbatch, extra, ld, c->d_qstats);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->ev_qdone, s1));
@@ -631,15 +832,108 @@ int factor_invert_queue(gprn_ctx* c, int nbatch, int set)
         if (k + 1 == T) break;
         const bool wait_kernel = nbatch > spin_max;
         if (wait_kernel) {
-            hipLaunchKernelGGL(k_queue_wait, dim3(1), dim3(64), 0, s0, q, P->l_op[k], nbatch);
+            hipLaunchKernelGGL(k_queue_wait, dim3(1), dim3(64), 0, s0, q, P->l_op[k], nbatch, P->u_op[k], 1u);
             HIP_TRY(c, hipGetLastError());
         }
         if ((rc = launch_tile_rows_q(c, k, c->d_ptrs, nbatch, ld, 0, s0, q, P->l_op[k], wait_kernel))) return rc;
-        if ((rc = launch_tile_rows_q(c, k, c->d_ptrs, nbatch, ld, 1, s0, q, P->u_op[k], false))) return rc;
+        if ((rc = launch_tile_rows_q(c, k, c->d_ptrs, nbatch, ld, 1, s0, q, P->u_op[k], wait_kernel))) return rc;
     }
     HIP_TRY(c, hipStreamWaitEvent(s0, c->ev_qdone, 0));
     c->q_lauum.n = 0;
     return GPRN_OK;
+}
+
+// Diagnostic (tests, probes): a list of INDEPENDENT tile tasks through the worker kernel -- every node ready from the
+// start, no chain -- timed with HIP events.  d_ptrs: one row of GPRN_NBUF pointers.  whole: one queue entry per node
+// instead of one per 64 x 64 quarter.
+int queue_run_independent(gprn_ctx* c, const std::vector<TileTask>& tasks, double** d_ptrs, int ld, bool whole, int reps, float* ms)
+{
+    const uint32_t n = (uint32_t)tasks.size();
+    std::vector<QOp> ops(n);
+    std::vector<uint32_t> init(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        memset(&ops[i], 0, sizeof(QOp));
+        ops[i].t = tasks[i];
+        ops[i].kind = QK_TILE;
+        ops[i].cls = GPRN_QCLASSES - 1;
+        ops[i].nent = whole ? 1 : 4;
+        init[i] = (uint32_t)ops[i].nent << 16;
+    }
+    QOp* d_ops = nullptr;
+    uint32_t* d_init = nullptr;
+    unsigned* d_slots = nullptr;
+    const size_t nslots = (size_t)n * (whole ? 1 : 4);
+    HIP_TRY(c, hipMalloc(&d_ops, n * sizeof(QOp)));
+    HIP_TRY(c, hipMalloc(&d_init, n * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&d_slots, (nslots + 64) * sizeof(unsigned)));
+    HIP_TRY(c, hipMemcpy(d_ops, ops.data(), n * sizeof(QOp), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_init, init.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<unsigned> hs(nslots);
+    for (uint32_t i = 0; i < n; ++i)
+        for (unsigned e = 0; e < (whole ? 1u : 4u); ++e) hs[(size_t)i * (whole ? 1 : 4) + e] = q_entry(0, whole ? GPRN_Q_WHOLE : e, i);
+    int rc;
+    if ((rc = grow(c, &c->d_qstate, &c->qstate_cap, (size_t)n))) return rc;
+    if (!c->d_qctr) {
+        HIP_TRY(c, hipMalloc(&c->d_qctr, GPRN_QCTR_WORDS * sizeof(unsigned) + sizeof(QueueCtl)));
+        HIP_TRY(c, hipMemset(c->d_qctr, 0, GPRN_QCTR_WORDS * sizeof(unsigned) + sizeof(QueueCtl)));
+        c->q_budget_ms = -1;
+    }
+    unsigned* const tmo = c->d_qctr + QC_TIMEOUT * GPRN_QCTR_STRIDE;
+    const unsigned ticks = 200000000u;
+    HIP_TRY(c, hipMemcpy(tmo + 1, &ticks, sizeof(unsigned), hipMemcpyHostToDevice));
+    c->q_budget_ms = -1;
+    QueueCtl q;
+    memset(&q, 0, sizeof(q));
+    q.ops = d_ops; q.succ = d_init /* unused: no successors */; q.state = c->d_qstate;
+    for (int cl = 0; cl < GPRN_QCLASSES; ++cl) { q.slots[cl] = d_slots; q.cap[cl] = cl == GPRN_QCLASSES - 1 ? (unsigned)nslots : 0u; }
+    q.ctr = c->d_qctr; q.timed_out = tmo; q.nops = (int)n;
+    q.per_cu = env_int("GPRN_QUEUE_WG_PER_CU", 0); q.reserve_per_xcc = 0;
+    QueueCtl* const qimg = (QueueCtl*)(c->d_qctr + GPRN_QCTR_WORDS);
+    HIP_TRY(c, hipMemcpy(qimg, &q, sizeof(q), hipMemcpyHostToDevice));
+    QExtra extra;
+    memset(&extra, 0, sizeof(extra));
+    static int n_cu = 0;
+    if (!n_cu) { hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device); if (n_cu <= 0) n_cu = 256; }
+    const size_t static_lds = 2 * 16 * (64 + 64 + 32) * sizeof(double) + 64;
+    const int wg_per_cu = std::min(3, std::max(1, env_int("GPRN_QUEUE_LAUNCH_PER_CU", 2)));
+    const size_t share = lds_limit(c->device) / (wg_per_cu + 1) + 1024;
+    const size_t pad = wg_per_cu < 3 && share > static_lds ? share - static_lds : 0;
+    const int nwg = std::max(1, env_int("GPRN_QUEUE_WORKERS", wg_per_cu * n_cu));
+    if (env_int("GPRN_QUEUE_STATS", 0) && !c->d_qstats) {
+        HIP_TRY(c, hipMalloc(&c->d_qstats, (size_t)4096 * 16 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_qstats, 0, (size_t)4096 * 16 * sizeof(unsigned long long)));
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    float total = 0.f;
+    for (int r = 0; r < reps + 1; ++r) {
+        HIP_TRY(c, hipMemcpy(c->d_qstate, init.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_slots, hs.data(), nslots * sizeof(unsigned), hipMemcpyHostToDevice));
+        std::vector<unsigned> ctr(GPRN_QCTR_WORDS, 0u);
+        ctr[(QC_TAIL + GPRN_QCLASSES - 1) * GPRN_QCTR_STRIDE] = (unsigned)nslots;      // tail of the last class
+        ctr[QC_LEFT * GPRN_QCTR_STRIDE] = (unsigned)nslots;
+        ctr[QC_TIMEOUT * GPRN_QCTR_STRIDE + 1] = ticks;
+        HIP_TRY(c, hipMemcpy(c->d_qctr, ctr.data(), ctr.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipEventRecord(e0, c->stream));
+        if (c->d_qstats)
+            hipLaunchKernelGGL(k_tile_queue<true>, dim3(nwg), dim3(256), static_lds + pad, c->stream, (const QueueCtl*)qimg,
+                               (double* const*)d_ptrs, 1, extra, ld, c->d_qstats);
+        else
+            hipLaunchKernelGGL(k_tile_queue<false>, dim3(nwg), dim3(256), static_lds + pad, c->stream, (const QueueCtl*)qimg,
+                               (double* const*)d_ptrs, 1, extra, ld, c->d_qstats);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(e1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(e1));
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, e0, e1));
+        if (r) total += t;
+    }
+    *ms = total / reps;
+    queue_print_stats(c);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_ops); (void)hipFree(d_init); (void)hipFree(d_slots);
+    return queue_check_waits(c);
 }
 
 // Host-only view of the graph for tests (tests/test_queue_plan.py): nodes and edges of the plan for T tile steps and

@@ -221,6 +221,10 @@ int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
  * 64x128, 128x64).  M, N multiples of 128; K multiple of 16. */
 int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
                    int c_mode, const double* A, const double* B, double* C);
+/* time (ms, average of reps) of C -= A.B^T, M x N x K on random device data, through the tile contraction: how 0 / 1 = one
+ * launch with 64 x 64 / 128 x 128 workgroups, 2 / 3 = as independent nodes of the dataflow schedule's worker kernel
+ * (csrc/queue.hip), one queue entry per 64 x 64 quarter / per 128 x 128 node */
+int gprn_test_gemm_rate(gprn_ctx* ctx, int M, int N, int K, int how, int reps, double* ms);
 /* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */
 int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
                             double* L, double* Linv);

@@ -342,12 +342,15 @@ def test_sharded_prediction(tag, world, user, tmp_path):
 
 
 @pytest.mark.parametrize('env', [{'GPRN_FLAGS': '0'}, {'GPRN_SCHED': '1'}, {'GPRN_SCHED': '2'},
-                                 {'GPRN_TRI': '0', 'GPRN_FILL_SYM': '0', 'GPRN_BULK_PAD_KB': '0'}],
+                                 {'GPRN_TRI': '0', 'GPRN_FILL_SYM': '0', 'GPRN_BULK_PAD_KB': '0'},
+                                 {'GPRN_QUEUE': '1'}],
                          ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
 def test_schedule_and_kernel_variants_agree(env, tmp_path):
     """The library's fallbacks (HIP events instead of device flags, the one- and three-stream
-    schedules without the lean panel boundary, full-matrix fill, no triangular skip, no LDS pad)
-    are switches read once per process: run each in its own process against the golden values."""
+    schedules without the lean panel boundary, full-matrix fill, no triangular skip, no LDS pad) and
+    the opt-in dataflow schedule (csrc/queue.hip: q = 2 nodes, so the previous phase's X^T X rides in
+    the weight phase's worker kernel) are switches read once per process: run each in its own
+    process against the golden values."""
     tag = 'mid_N512_p3q2'
     meta, d = _cases.load(tag)
     res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
