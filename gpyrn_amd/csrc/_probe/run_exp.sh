@@ -1,8 +1,15 @@
-export GPRN_QUEUE_DEBUG=1
-BUDGET_MS=500 timeout -k 10 100 python gpyrn_amd/csrc/_probe/probe_queue.py 2>&1 | tail -7
-timeout -k 10 200 python gpyrn_amd/csrc/_probe/probe_qrate2.py 2>&1 | grep TF
-for cfg in 3 2 4; do timeout -k 10 150 python bench.py --no-cpu --no-calc --blocks 3 --config $cfg > gpurun_out/r3_b15_c$cfg.json 2>gpurun_out/r3_b15_c$cfg.err; python -c "
+python -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -3
+python -m pytest tests/test_parity_gpu.py -x -q -k "forced_sweeps or trajectory_at_baseline or schedule_and" 2>&1 | tail -3
+for v in "" "GPRN_SPLIT_INNER=0" "GPRN_LOWER_DIAG=0" "GPRN_SPLIT_INNER=0 GPRN_LOWER_DIAG=0" "GPRN_SPLIT_INNER=2"; do
+env $v python bench.py --no-cpu --no-calc --blocks 3 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
 import json
-d=json.loads(open('gpurun_out/r3_b15_c$cfg.json').read().strip().splitlines()[-1]); print('cfg $cfg:', d['value'], d['elbo_last'])"; head -3 gpurun_out/r3_b15_c$cfg.err; done
-GPRN_QUEUE_TRACE=600000 GPRN_QUEUE_TRACE_FILE=gpurun_out/qt_c2.bin timeout -k 10 100 python profiles/queue_trace_run.py 2 > gpurun_out/qt_c2.log 2>&1
-GPRN_QUEUE_TRACE=600000 GPRN_QUEUE_TRACE_FILE=gpurun_out/qt_c3.bin timeout -k 10 100 python profiles/queue_trace_run.py 3 > gpurun_out/qt_c3.log 2>&1
+d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg3:', round(d['value'],2), d['elbo_last'])"
+done
+for v in "" "GPRN_SPLIT_INNER=0 GPRN_LOWER_DIAG=0"; do
+env $v python bench.py --no-cpu --no-calc --blocks 3 --config 2 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
+import json
+d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg2:', round(d['value'],2))"
+env $v python bench.py --no-cpu --no-calc --blocks 3 --config 4 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
+import json
+d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg4:', round(d['value'],2))"
+done

@@ -862,6 +862,8 @@ int ensure_tasks(gprn_ctx* c)
     if (c->tasks_T == T && c->d_tasks) return GPRN_OK;
     std::vector<TileTask>& v = c->h_tasks;
     v.clear();
+    static int lower_diag = -1;                    // GPRN_LOWER_DIAG=0: diagonal tiles updated in full, as in rounds 1-2
+    if (lower_diag < 0) { const char* e = getenv("GPRN_LOWER_DIAG"); lower_diag = e ? atoi(e) : 1; }
     static int outer_big = 0;                      // GPRN_OUTER_TILES overrides (experiments)
     if (!outer_big) { const char* e = getenv("GPRN_OUTER_TILES"); outer_big = e && atoi(e) > 0 ? atoi(e) : GPRN_OUTER; }
     for (int set = 0; set < 2; ++set) {
@@ -889,14 +891,19 @@ int ensure_tasks(gprn_ctx* c)
             // columns of the panel right of step k; and of the NEXT panel its diagonal and sub-diagonal tiles
             // (j,j), (j+1,j), k1 <= j < n1 -- the tiles the chain works on there: kept up to date step by
             // step (K = 128), so that the chain never waits for a K = 512 update of the outer panel
-            for (int j = k + 1; j < std::min(T, k1 + outer); ++j) {
-                for (int i = j; i < (j < k1 ? T : std::min(T, j + 2)); ++i) {
-                    v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
-                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
-                    // ... and the diagonal tile of column k+2, which the chain's update of step k+1 writes next
-                    if (j == k + 2 && i == j) s.ncol1 = v.size() - s.upd0;
-                }
-                if (j == k + 1) s.ncol1 = v.size() - s.upd0;
+            // Order: the chain's own update (k+1,k+1) first, then the two tiles the chain's NEXT step touches --
+            // (k+2,k+1), which becomes L_{k+2,k+1}, and (k+2,k+2), which its update writes -- then everything else: the
+            // first `ncol1` tasks are what has to be done before the chain may go on (factor_invert_split launches them
+            // on their own where the others must wait for an outer update).
+            auto is_crit = [&](int i, int j) { return (i == k + 1 && j == k + 1) || (i == k + 2 && (j == k + 1 || j == k + 2)); };
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int j = k + 1; j < std::min(T, k1 + outer); ++j)
+                    for (int i = j; i < (j < k1 ? T : std::min(T, j + 2)); ++i) {
+                        if (is_crit(i, j) != (pass == 0)) continue;
+                        v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                             BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0, lower_diag && i == j)});
+                    }
+                if (pass == 0) s.ncol1 = v.size() - s.upd0;
             }
             for (int i = k + 1; i < k1; ++i)
                 for (int cc = 0; cc <= k; ++cc)
@@ -929,7 +936,7 @@ int ensure_tasks(gprn_ctx* c)
                 for (int j = k1; j <= i; ++j) {
                     if (clsB(i, j) != pass) continue;
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k0, ld), toff(j, k0, ld), kw,
-                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
+                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0, lower_diag && i == j)});
                 }
                 if (clsR(i) != pass) continue;
                 for (int cc = 0; cc < k0; ++cc)
@@ -1386,29 +1393,31 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                     HIP_TRY(c, await(s1, k, F_MINIL));
                 }
             }
-            if (next_J >= 0) {                         // the other columns / rows of this panel
-                HIP_TRY(c, await(s1, next_J, F_NEXT));
-                next_J = -1;
-            }
             // (hundreds of workgroups: a fence + atomic in each would cost more than one stream write;
             // the flag goes up with stream3's next synchronisation kernel)
-            // Column k+1 and the diagonal tile (k+2,k+2) first, in a launch of its own that raises F_INNER itself: all
-            // the chain's next step reads (L_{k+2,k+1}) or writes (its update of B_{k+2,k+2}); the other columns and
-            // the inverse's rows are next touched by stream3 itself (GPRN_SPLIT_INNER=1).  OFF by default: with one launch
-            // the chain's L kernel spends 40-107 us of every loaded step polling for the launch's last workgroup (node
-            // half-sweep of config 3, profiles/r02_chain_timeline_cfg3.txt), but stream3 is itself a serial chain of
-            // launches and one more per step costs more than the earlier flag gains (95.7 vs 103.2 sweeps/s at config 3,
-            // 566 vs 647 at config 2).  Default: one launch, the flag raised by stream3's next synchronisation kernel.
+            // At the FIRST step of a panel the step's updates of the panel's other columns have to wait for the previous
+            // panel's outer update ("next"), but the two tiles the chain's next step needs do not: they are the next
+            // panel's eager tiles, kept up to date step by step and left out of the outer update (ensure_tasks).  Those two
+            // go first, in a launch of their own that raises F_INNER itself, BEFORE the wait for "next": with one launch the
+            // chain's L kernel sat 70-90 us at every panel boundary of a two-matrix phase waiting for an update it does not
+            // read (profiles/r02_chain_timeline_cfg3.txt; the dataflow schedule of queue.hip made the false dependency
+            // visible).  GPRN_SPLIT_INNER: 0 never, 1 (default) at panel boundaries, 2 at every step (one more launch per
+            // step on stream3, itself a serial chain of launches: slower, 95.7 vs 103.2 sweeps/s in round 2).
             static int split_inner = -1;
-            if (split_inner < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner = e ? atoi(e) : 0; }
-            const size_t ncol = s.ncol1 > 0 ? s.ncol1 - 1 : 0;
-            if (split_inner && ncol > 0) {
+            if (split_inner < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner = e ? atoi(e) : 1; }
+            const size_t ncrit = s.ncol1 > 0 ? s.ncol1 - 1 : 0;
+            const bool boundary = next_J >= 0;             // this step's other updates wait for an outer update
+            // (at panel boundaries only where the chain bounds the phase: one or two matrices -- config 2: +3 %; with six
+            // matrices the phase is bound by throughput and the extra launch costs 1 %)
+            static int split_max_batch = -1;
+            if (split_max_batch < 0) { const char* e = getenv("GPRN_SPLIT_INNER_MAX_BATCH"); split_max_batch = e ? atoi(e) : 2; }
+            if (use_flags && ncrit > 0 && (split_inner >= 2 || (split_inner == 1 && boundary && nbatch <= split_max_batch))) {
                 const bool skip = withheld(F_INNER);
-                if ((rc = tiles(s.upd0 + 1, ncol, s1, shape_upd(ncol), GPRN_T_PANEL,
-                                use_flags && !skip ? in_kernel(k, F_INNER) : nosig))) return rc;
-                if (!use_flags) HIP_TRY(c, hipEventRecord(events[F_INNER], s1));
-                if ((rc = tiles(s.upd0 + 1 + ncol, s.nupd - 1 - ncol, s1, shape_upd(s.nupd - 1 - ncol)))) return rc;
+                if ((rc = tiles(s.upd0 + 1, ncrit, s1, TS_64x64, GPRN_T_PANEL, skip ? nosig : in_kernel(k, F_INNER)))) return rc;
+                if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+                if ((rc = tiles(s.upd0 + 1 + ncrit, s.nupd - 1 - ncrit, s1, shape_upd(s.nupd - 1 - ncrit)))) return rc;
             } else {
+                if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
                 if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
                 if (use_flags) inner_k = k;                // raised by stream3's next synchronisation kernel
                 else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the

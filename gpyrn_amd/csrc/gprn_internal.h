@@ -40,10 +40,11 @@ struct TileTask {
     int64_t c_off, a_off, b_off;
     int32_t klen;
     uint8_t c_buf, a_buf, b_buf;
-    uint8_t modes;             // bits 0-1 c_mode, bit 2 a_mode, bit 3 b_mode
+    uint8_t modes;             // bits 0-1 c_mode, bit 2 a_mode, bit 3 b_mode, bit 4: symmetric update of a diagonal tile
+                               // (C -= A A^T, same operand twice): only the lower triangle of the result is ever read
 };
-static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode) {
-    return (uint8_t)((c_mode & 3) | ((a_mode & 1) << 2) | ((b_mode & 1) << 3));
+static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode, int lower_only = 0) {
+    return (uint8_t)((c_mode & 3) | ((a_mode & 1) << 2) | ((b_mode & 1) << 3) | ((lower_only & 1) << 4));
 }
 
 #define HIP_TRY(ctx, expr)                                                     \
@@ -234,7 +235,7 @@ struct gprn_ctx {
     unsigned long long* d_qtrace = nullptr;   // GPRN_QUEUE_TRACE=n: n records of what ran when (queue.hip)
     int qtrace_cap = 0, q_calls = 0;
     std::vector<TileTask> h_tasks;
-    struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: column k+1)
+    struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: the chain's own tile and the two its next step touches)
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
@@ -320,7 +321,11 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value,
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long budget = timed_out ? (unsigned long long)timed_out[1] : 200000000ull;
         for (;;) {
+#ifdef GPRN_SPIN_SLEEP
+            __builtin_amdgcn_s_sleep(GPRN_SPIN_SLEEP);
+#else
             __builtin_amdgcn_s_sleep(8);
+#endif
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) break;
             if (timed_out && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {

@@ -43,7 +43,10 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // branches, no registers for the blocks of other waves).  out_img (SYRK only): instead of storing the lower
 // blocks to C, leave them in LDS for the caller: block (P, Q), P >= Q, at out_img + (P (P + 1) / 2 + Q) * 256,
 // 16 x 16 row-major.
-template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1>
+// LOWER: the part lies on the diagonal of a symmetric update C -= A A^T of which only the lower triangle is ever read
+// (the factorisation's diagonal tiles): 16 x 16 blocks strictly above the diagonal (block column > block row inside the
+// 128 x 128 tile) are loaded and stored back unchanged, their MFMAs skipped.
+template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1, bool LOWER = false>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
                                          int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
                                          double* out_img = nullptr)
@@ -202,6 +205,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
                     if (TRI == 1 && c > nb16 + j) continue;     // wave-uniform
                     if (TRI == 2 && c > mb16 + i) continue;
                     if (SYRK && j > blk[i]) continue;
+                    if (LOWER && nb16 + j > mb16 + i) continue;   // wave-uniform
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
                 if (fetch) af[i] = frag(fb_off + a_fb[fb_ks] + arow_bytes(i));
