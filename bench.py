@@ -43,10 +43,11 @@ def update_flops(T, n_gp, outer=4, split=True):
     csrc/factor.hip::ensure_tasks builds them: the K = 512 `k_tile_gemm<64,64,...>` launches on the look-ahead
     stream ("rest" of each outer update: trailing SYRK tiles and inverse rows beyond the next panel; the
     diagonal and sub-diagonal tiles of the panel after next go with the next-panel launch instead).  Diagonal
-    SYRK tiles count their lower triangle only.  Returns (bulk, ahead): with `split` the tiles the next panel's
-    update writes again -- the columns / rows of the panel after next, the diagonal and sub-diagonal tiles of
-    the one after that -- are a launch of their own (family 'update_ahead', kernel tag TG_AHEAD)."""
-    bulk = ahead = 0.0
+    SYRK tiles count their lower triangle only.  Returns (bulk, ahead, next): with `split` the tiles the next
+    panel's update writes again -- the columns / rows of the panel after next, the diagonal and sub-diagonal tiles
+    of the one after that -- are a launch of their own (family 'update_ahead', kernel tag TG_AHEAD); `next` is the
+    part the next panel needs first (the "first" / "next" launches on the side streams, tag TG_NEXT)."""
+    bulk = ahead = nxt = 0.0
     for k0 in range(0, T, outer):
         k1 = min(T, k0 + outer)
         n1 = min(T, k1 + outer)
@@ -55,47 +56,64 @@ def update_flops(T, n_gp, outer=4, split=True):
         kw = (k1 - k0) * TILE
         for i in range(k1, T):
             for j in range(k1, i + 1):
-                if j < n1 or (j < n2 and i <= j + 1):
-                    continue                                       # first / next / kept up to date step by step
                 fl = 2.0 * (TILE * (TILE + 1) / 2 if i == j else TILE * TILE) * kw
+                if j < n1 and i <= j + 1:
+                    continue                                       # kept up to date step by step (K = 128)
+                if j < n1 or (j < n2 and i <= j + 1):
+                    nxt += fl                                      # "first" / "next" launches (TG_NEXT)
+                    continue
                 if split and (j < n2 or (j < n3 and i <= j + 1)):
                     ahead += fl
                 else:
                     bulk += fl
-            if i < n1:
-                continue
             fl = k0 * 2.0 * TILE * TILE * kw                       # R_ic, c < k0
             for c in range(k0, k1):
                 fl += 2.0 * TILE * TILE * (k1 - c) * TILE          # R_ic, first touch
+            if i < n1:
+                nxt += fl
+                continue
             if split and i < n2:
                 ahead += fl
             else:
                 bulk += fl
-    return bulk * n_gp, ahead * n_gp
+    return bulk * n_gp, ahead * n_gp, nxt * n_gp
 
 
 def pmc_traffic():
     """HBM bytes per bulk-update launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950).  Produced by profiles/summarize_pmc.py; None if absent."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_bulk_update.json')
-    try:
-        with open(path) as f:
-            return json.load(f)['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ('r03', 'r02'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_bulk_update.json')) as f:
+                return json.load(f)['hbm_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def pmc_mfma():
     """MFMA-pipe utilisation of the bulk-update launches from the committed rocprofv3 PMC pass
     (SQ_VALU_MFMA_BUSY_CYCLES against 1024 SIMDs x launch time x the clock GRBM_GUI_ACTIVE gives; kernels
     serialised by counter collection; profiles/summarize_r02.py)."""
+    for rnd in ('r03', 'r02'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_mfma_util.json')) as f:
+                d = json.load(f)
+            return {'mfma_pipe_busy_fraction': d['mfma_pipe_busy_fraction'], 'effective_clock_ghz': d['effective_clock_ghz'],
+                    'tflops_serialised': d['tflops_from_mfma_count'], 'fp64_mfma_per_launch': d.get('fp64_mfma_per_launch'),
+                    'source': 'profiles/%s_pmc_mfma_util.json' % rnd}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def k512_union():
+    """Union-time figures of the K = 512 launches from the committed kernel trace (profiles/summarize_r02.py union)."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_mfma_util.json')) as f:
-            d = json.load(f)
-        return {'mfma_pipe_busy_fraction': d['mfma_pipe_busy_fraction'], 'effective_clock_ghz': d['effective_clock_ghz'],
-                'tflops_serialised': d['tflops_from_mfma_count'], 'source': 'profiles/r02_pmc_mfma_util.json'}
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, 'profiles', 'r03_k512_union.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
 
 
@@ -117,33 +135,35 @@ def _blas_build():
 
 def cpu_baseline(N, p, q, kind):
     """The reference's formulation (oracle/cpu_ref.sweep_ref, 7 N^3 per latent GP) on this box's
-    host cores, on the configuration itself: one full sweep of all G latent GPs with the BLAS
-    threads the library picks (all cores), and -- bounded, because 7 G N^3 on one core takes
+    host cores, on the configuration itself: three consecutive sweeps of all G latent GPs (one set-up) with
+    the BLAS threads the library picks (all cores), and -- bounded, because 7 G N^3 on one core takes
     minutes -- one sweep of the p = q = 1 problem of the same N (2 of the G GPs) on ONE BLAS thread,
     scaled by G / 2 (every GP costs the same in that formulation)."""
     from oracle import cpu_ref
     G = q * (p + 1)
 
-    def one_sweep(pp, qq):
+    def sweeps(pp, qq, n):
         t, ys, es = synth.rv_series(N, pp)
         spec = synth.component_spec(pp, qq, kind)
         nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
         y = np.array(ys)
         Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, nodes, weights, means, jit, y)
-        mu, var = cpu_ref.init_mu_var(y, [n.pars[0] for n in nodes], [w.pars[0] for w in weights], jit)
+        mu, var = cpu_ref.init_mu_var(y, [n_.pars[0] for n_ in nodes], [w.pars[0] for w in weights], jit)
         t0 = time.time()
-        cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu, var)
+        for _ in range(n):
+            _, mu, var, _ = cpu_ref.sweep_ref(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu, var)
         return time.time() - t0
 
-    dt_all = one_sweep(p, q)
-    out = {'value': 1.0 / dt_all, 'unit': 'sweeps/s', 'cores': os.cpu_count(), 'kind': 'port',
-           'sample': f'one full reference-formulation sweep of the configuration (N={N}, p={p}, q={q}: all {G} '
+    n_all = int(os.environ.get('GPRN_CPU_SWEEPS', 3))            # SURVEY.md 8(d): at least three
+    dt_all = sweeps(p, q, n_all)
+    out = {'value': n_all / dt_all, 'unit': 'sweeps/s', 'cores': os.cpu_count(), 'kind': 'port',
+           'sample': f'{n_all} consecutive reference-formulation sweeps of the configuration (N={N}, p={p}, q={q}: all {G} '
                      f'latent GPs, {dt_all:.1f} s) with NumPy/SciPy LAPACK on all host cores',
            'blas': _blas_build()}
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
-            dt_1 = one_sweep(1, 1)
+            dt_1 = sweeps(1, 1, 1)
         out['one_thread'] = {'value': 1.0 / (dt_1 * G / 2), 'unit': 'sweeps/s', 'cores': 1,
                              'sample': f'one sweep at N={N}, p=1, q=1 (2 of {G} latent GPs, {dt_1:.1f} s) on one '
                                        f'BLAS thread, scaled by {G}/2'}
@@ -216,7 +236,7 @@ def main():
     ap.add_argument('--no-calc', action='store_true')
     ap.add_argument('--shape', default=None,
                     help='N,p,q of an ad-hoc problem (experiments; not a BASELINE config)')
-    ap.add_argument('--blocks', type=int, default=5, help='timed blocks of --steps sweeps each')
+    ap.add_argument('--blocks', type=int, default=20, help='timed blocks of --steps sweeps each')
     a = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
@@ -242,6 +262,10 @@ def main():
     g = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair], comm=comm)
     g.set_components(nodes, weights, means, jit)
 
+    # the CPU baseline FIRST (rank 0 of a one-rank run only; ~3 min at config 3): the timed GPU blocks are then the last
+    # thing the command does, where a utilisation sampler watching the run can see them
+    cpu = cpu_baseline(N, p, q, kind) if (world == 1 and rank == 0 and not a.no_cpu) else None
+
     t0 = time.time()
     ctx = g._setup_device(nodes, weights, means, jit)     # fill + chol(K): once per ELBOcalc
     ctx.barrier_max(0.0)
@@ -249,20 +273,6 @@ def main():
     ms_fill, n_fill = 0.0, 0
     mu0, var0 = g._initMuVar(nodes, weights, jit)
     ctx.set_muvar(mu0, var0)
-
-    if a.warmup > 0:
-        ctx.sweep(a.warmup, commit=True)
-    ctx.profile_enable(['update', 'update_ahead'])
-    block_s = []
-    for _ in range(max(1, a.blocks)):
-        ctx.barrier_max(0.0)                               # barrier + device sync
-        t0 = time.perf_counter()
-        elbo, parts, info = ctx.sweep(a.steps, commit=True)    # K sweeps, one host sync at the end
-        dt_local = time.perf_counter() - t0
-        block_s.append(ctx.barrier_max(dt_local))          # MAX over ranks
-    dt = float(np.median(block_s))
-    prof = ctx.profile_read()
-    ctx.profile_enable([])
 
     # secondary metric: full ELBOcalc with changed hyper-parameters, i.e. fused
     # fills + chol(K) + inverses + the reference's own trip count (discarded sweep + loop to the
@@ -315,6 +325,26 @@ def main():
         pool = {'elbocalc_per_s_all_ranks': world * reps / dt_pool, 'ms_per_elbocalc': 1e3 * dt_pool / reps,
                 'scaling': 'weak', 'note': 'one independent full ELBOcalc stream per rank'}
 
+    # ---- the headline: timed blocks of forced sweeps, last (the secondary metrics above changed the hyper-parameters:
+    # back to the configuration's own)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    g.set_components(nodes, weights, means, jit)
+    ctx = g._setup_device(nodes, weights, means, jit)
+    ctx.set_muvar(mu0, var0)
+    if a.warmup > 0:
+        ctx.sweep(a.warmup, commit=True)
+    ctx.profile_enable(['update', 'update_ahead'])
+    block_s = []
+    for _ in range(max(1, a.blocks)):
+        ctx.barrier_max(0.0)                               # barrier + device sync
+        t0 = time.perf_counter()
+        elbo, parts, info = ctx.sweep(a.steps, commit=True)    # K sweeps, one host sync at the end
+        dt_local = time.perf_counter() - t0
+        block_s.append(ctx.barrier_max(dt_local))          # MAX over ranks
+    dt = float(np.median(block_s))
+    prof = ctx.profile_read()
+    ctx.profile_enable([])
+
     if rank == 0:
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
         ms_upd, n_upd = prof['update']
@@ -322,7 +352,9 @@ def main():
         T = (N + TILE - 1) // TILE
         sr_env = os.environ.get('GPRN_SPLIT_REST', '1')           # csrc/factor.hip: two launches up to 64 tile steps
         split = sr_env not in ('0',) and (sr_env == '2' or T <= 64)
-        fl, fl_ahd = (x * a.steps * len(block_s) for x in update_flops(T, len(nodes_l) + len(weights_l), split=split))
+        per_sweep = update_flops(T, len(nodes_l) + len(weights_l), split=split)
+        fl, fl_ahd = (x * a.steps * len(block_s) for x in per_sweep[:2])
+        uni = k512_union() if world == 1 and a.config == 3 and not a.shape else None
         achieved = fl / (ms_upd * 1e-3) / 1e12 if ms_upd > 0 else None
         out = {
             'metric': 'ELBO iterations/sec (N=%d, P=%d, Q=%d)' % (N, p, q),
@@ -367,6 +399,15 @@ def main():
                 'traffic': pmc_traffic() if world == 1 and a.config == 3 and not a.shape else None,
                 'pmc': pmc_mfma() if world == 1 and a.config == 3 and not a.shape else None,
                 'measured_mfma_ceiling': ctx.mfma_peak(2, 4000),
+                # the whole sweep against the same peak (every kernel, wait and O(N^2) step included)
+                'sweep_frac': sweep_flops(N, p, q) * a.steps / dt / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                # rate of ALL K = 512 launches (next-panel + look-ahead + bulk) over the time at least one of them was
+                # open, from the committed kernel trace: a launch's own rate divides by the time it is open, during which
+                # up to three other streams' kernels share the CUs with it
+                'k512_union': ({'tflops': sum(per_sweep) / (uni['k512_union_us_per_sweep'] * 1e-6) / 1e12,
+                                'union_us_per_sweep': uni['k512_union_us_per_sweep'],
+                                'bulk_ahead_tflops': (per_sweep[0] + per_sweep[1]) / (uni['bulk_ahead_union_us_per_sweep'] * 1e-6) / 1e12,
+                                'source': 'profiles/r03_k512_union.json'} if uni else None),
                 'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
                 'flops_per_launch': (fl / n_upd) if n_upd else None,
                 # the look-ahead part of the same updates (own launches, k_tile_gemm<..., TG_AHEAD>: the tiles the
@@ -375,10 +416,7 @@ def main():
                                     'achieved': fl_ahd / (ms_ahd * 1e-3) / 1e12} if n_ahd else None),
             },
         }
-        if world == 1 and not a.no_cpu:
-            out['cpu_baseline'] = cpu_baseline(N, p, q, kind)
-        else:
-            out['cpu_baseline'] = None
+        out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if comm is not None:
         ctx.barrier_max(0.0)

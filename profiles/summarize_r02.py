@@ -62,6 +62,36 @@ def families(d):
                       'kernels': out}, indent=1))
 
 
+def union(d):
+    """Time during which at least one K = 512 launch (next-panel, look-ahead and bulk updates: tags 2, 5, 3) was open,
+    per sweep, and the same for the bulk + look-ahead launches alone: the per-launch rate of such a launch is flops over
+    the time the launch is OPEN, during which it shares the CUs with up to three other streams' kernels; the union-time
+    rate says what the K = 512 work got done at while any of it was running."""
+    rows = list(csv.DictReader(open(_one(d, '*kernel_trace.csv'))))
+    sweeps = sum(1 for r in rows if r['Kernel_Name'].startswith('k_elbo_final'))
+
+    def cover(tags):
+        iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in rows
+                    if (lambda m: m and m.group(5) in tags)(TILE.search(r['Kernel_Name'])))
+        tot, cur_a, cur_b = 0, None, None
+        for a, b in iv:
+            if cur_b is None or a > cur_b:
+                if cur_b is not None:
+                    tot += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        if cur_b is not None:
+            tot += cur_b - cur_a
+        return tot / 1e3, len(iv), sum(b - a for a, b in iv) / 1e3
+    k512 = cover({'2', '3', '5'})
+    bulk = cover({'3', '5'})
+    print(json.dumps({'source': 'rocprofv3 --kernel-trace of `python3 bench.py --no-cpu` (config 3, one MI355X)', 'sweeps': sweeps,
+                      'k512_launches': k512[1], 'k512_union_us_per_sweep': k512[0] / sweeps, 'k512_open_us_per_sweep': k512[2] / sweeps,
+                      'bulk_ahead_launches': bulk[1], 'bulk_ahead_union_us_per_sweep': bulk[0] / sweeps,
+                      'bulk_ahead_open_us_per_sweep': bulk[2] / sweeps}, indent=1))
+
+
 def _bulk(d, counter):
     vals = []
     for r in csv.DictReader(open(_one(d, '*counter_collection.csv'))):
@@ -112,4 +142,4 @@ def mfma(d):
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'families': families, 'traffic': traffic, 'mfma': mfma}[what](*sys.argv[2:])
+    {'families': families, 'traffic': traffic, 'mfma': mfma, 'union': union}[what](*sys.argv[2:])
