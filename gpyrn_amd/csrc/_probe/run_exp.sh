@@ -1,15 +1,8 @@
-python -m pytest tests/test_kernels_gpu.py -x -q 2>&1 | tail -3
-python -m pytest tests/test_parity_gpu.py -x -q -k "forced_sweeps or trajectory_at_baseline or schedule_and" 2>&1 | tail -3
-for v in "" "GPRN_SPLIT_INNER=0" "GPRN_LOWER_DIAG=0" "GPRN_SPLIT_INNER=0 GPRN_LOWER_DIAG=0" "GPRN_SPLIT_INNER=2"; do
-env $v python bench.py --no-cpu --no-calc --blocks 3 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
+for rep in 1 2; do
+for lib in "" "GPRN_HIP_LIB=$PWD/gpyrn_amd/csrc/_probe/libgprn_hip_noprio.so"; do
+for cfg in 3 2; do
+env $lib python bench.py --no-cpu --no-calc --blocks 5 --config $cfg > gpurun_out/r3_b19.json 2>gpurun_out/r3_b19.err; python -c "
 import json
-d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg3:', round(d['value'],2), d['elbo_last'])"
-done
-for v in "" "GPRN_SPLIT_INNER=0 GPRN_LOWER_DIAG=0"; do
-env $v python bench.py --no-cpu --no-calc --blocks 3 --config 2 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
-import json
-d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg2:', round(d['value'],2))"
-env $v python bench.py --no-cpu --no-calc --blocks 3 --config 4 > gpurun_out/r3_b17.json 2>gpurun_out/r3_b17.err; python -c "
-import json
-d=json.loads(open('gpurun_out/r3_b17.json').read().strip().splitlines()[-1]); print('[$v] cfg4:', round(d['value'],2))"
-done
+d=json.loads(open('gpurun_out/r3_b19.json').read().strip().splitlines()[-1]); print('[${lib:0:12}] cfg $cfg:', round(d['value'],2))"
+done; done; done
+timeout -k 10 300 python gpyrn_amd/csrc/_probe/probe_grad.py 2>&1 | grep -v "^ELBO=" | tail -40

@@ -632,6 +632,7 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
                   unsigned* wait_timed_out)
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    CHAIN_PRIO();
     await_flag(wait_flag, wait_value, wait_timed_out);
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
@@ -649,6 +650,7 @@ void k_diag_block_q(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kb
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
     const int slot = blockIdx.x;
+    CHAIN_PRIO();
     const unsigned long long t0 = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     q_await(q, slot, qop);
     const unsigned long long t1 = q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;

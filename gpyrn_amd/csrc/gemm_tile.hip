@@ -191,6 +191,7 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
     RW_STAMP(0);
+    CHAIN_PRIO();
     const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
@@ -314,6 +315,7 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
                QueueCtl q, unsigned qop, int q_skip_wait)
 {
     RW_STAMP(0);
+    CHAIN_PRIO();
     const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);

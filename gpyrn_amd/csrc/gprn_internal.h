@@ -310,6 +310,14 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
                 Await aw = Await{nullptr, 0, nullptr, nullptr, 0});
 
 #ifdef __HIPCC__
+// The latency chain's kernels (diagonal block, L_{k+1,k}, the B_{k+1,k+1} update) share their CUs with throughput
+// workgroups whose waves keep the SIMDs' issue slots and matrix pipes busy; with -DGPRN_CHAIN_PRIO=3 the chain's waves ask
+// for the highest issue priority (s_setprio).  Measured (round 3, two builds side by side): no difference -- 108.1 / 108.3
+// vs 108.3 / 108.3 sweeps/s at config 3, 680 / 684 vs 685 / 684 at config 2 -- so it is off.
+#ifndef GPRN_CHAIN_PRIO
+#define GPRN_CHAIN_PRIO 0
+#endif
+#define CHAIN_PRIO() do { if (GPRN_CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(GPRN_CHAIN_PRIO); } while (0)
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
 // timed_out[1] the budget of one wait in ticks of the 100 MHz constant clock (s_memrealtime): a wall-clock
 // bound, not a spin count -- on a shared device a legitimate wait can be long.  Once any wait of the call
