@@ -1285,7 +1285,7 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
             TRY(dev_alloc(c, &c->predWT[s], need));
         }
         c->pred_cap = need;
-        tab_forget(c, c->tab_pred);
+        if (c->tab_pred) tab_forget(c, c->tab_pred);       // (a null argument forgets EVERY table's host copy)
         dev_free(c->tab_pred); dev_free(c->d_slotgp_all);
         TRY(dev_alloc(c, &c->tab_pred, (size_t)c->nslot * GPRN_NBUF));
         TRY(dev_alloc(c, &c->d_slotgp_all, c->nslot));
