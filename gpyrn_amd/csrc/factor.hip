@@ -1277,8 +1277,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         if (o.nrest) {
             // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
             // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
-            static int bulk_shape = -1;
-            if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
+            static int bulk_shape_small = -1, bulk_shape_big = -1, bulk_big_batch = -1;
+            if (bulk_shape_small < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape_small = e ? atoi(e) : TS_64x64; }
+            // (experiments: another shape for phases of many matrices, which are bound by throughput, not by the chain)
+            if (bulk_shape_big < 0) { const char* e = getenv("GPRN_BULK_SHAPE_BIG"); bulk_shape_big = e ? atoi(e) : bulk_shape_small; }
+            if (bulk_big_batch < 0) { const char* e = getenv("GPRN_BULK_BIG_BATCH"); bulk_big_batch = e ? atoi(e) : 4; }
+            const int bulk_shape = nbatch >= bulk_big_batch ? bulk_shape_big : bulk_shape_small;
             if (sr) {
                 HIP_TRY(c, await(s2, (int)J, F_PANEL));
                 if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
