@@ -323,6 +323,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipEventCreateWithFlags(&c->ev_resta, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
         device_streams_release(c->shared);
         delete c;
@@ -363,6 +364,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         hipEventDestroy(c->ev_next);
         hipEventDestroy(c->ev_nodes);
         hipEventDestroy(c->ev_q1);
+        hipEventDestroy(c->ev_tail);
     }
     device_streams_release(c->shared);
     delete c;
@@ -1000,6 +1002,8 @@ static int factor_priors_impl(gprn_ctx* c)
 }
 
 // ------------------------------------------------------------------ sweep
+static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr);
+
 static int run_phase(gprn_ctx* c, bool weights)
 {
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
@@ -1012,11 +1016,30 @@ static int run_phase(gprn_ctx* c, bool weights)
     if (ns) {
         TRY(vec_prep(c, weights, slotgp, ns));
         TRY(vec_build_B(c, ns));
-        TRY(factor_invert(c, ns));
-        TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
-        TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o));
-        TRY(vec_colops(c, ns));
-        TRY(vec_finalize(c, slotgp, ns));
+        // The reductions over the rows of X = L^-1 (u = X z, column norms, X^T u: 8 N^2 bytes per matrix) run outer
+        // panel by outer panel as the rows become final (rows_final, called by the launch schedule on the bulk
+        // stream); behind the factorisation only the last panel's rows, the reduction over the partial sums and the
+        // new state are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
+        // GPRN_OVERLAP bits: 2 this, 4 the node phase's mu^T K^-1 mu beside the weight phase, 8 log det B in k_finalize.
+        static int overlap = -1;
+        if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 14; }
+        c->rows_done = 0;
+        if (overlap & 2) {
+            c->rows_final = [c, o, slotgp, ns](int r0, int r1, hipStream_t st) -> int {
+                TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, st, r0 * GPRN_TILE,
+                                     (r1 - r0) * GPRN_TILE));
+                return vec_colops_partial(c, ns, st, r0, r1 - r0);
+            };
+        }
+        const int rc_f = factor_invert(c, ns);
+        const int rd = c->rows_done;
+        c->rows_final = nullptr; c->rows_done = 0;
+        TRY(rc_f);
+        TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, nullptr, rd * GPRN_TILE, -1));
+        TRY(vec_colops_partial(c, ns, nullptr, rd, -1));
+        TRY(vec_colops_reduce(c, ns));
+        if (!(overlap & 8)) TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
+        TRY(vec_finalize(c, slotgp, ns, (overlap & 8) != 0));      // + log det B
         if (c->keep_sigma) {
             const size_t nn = (size_t)c->ld * c->ld;
             TRY(lauum_lower(c, ns));
@@ -1038,11 +1061,16 @@ static int run_phase(gprn_ctx* c, bool weights)
             HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
             const std::vector<int> node_gps = gps;
             double** const node_tab = c->d_ptrs;
-            c->chain_started = [c, n_inv, ns, node_gps, node_tab]() -> int {
+            const bool early_term = (overlap & 4) && !c->loc_weights.empty();
+            c->node_term_done = early_term;
+            c->chain_started = [c, n_inv, ns, node_gps, node_tab, early_term]() -> int {
                 double** const cur = c->d_ptrs;
-                c->d_ptrs = node_tab;
+                const int cur_slot0 = c->slot0;
                 HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
-                int rc = GPRN_OK;
+                // mu_f^T K_f^-1 mu_f needs the node phase's result only: HBM-bound work beside the MFMA-bound weight phase
+                int rc = early_term ? mu_k_mu(c, false, c->stream2) : GPRN_OK;
+                c->d_ptrs = node_tab;
+                c->slot0 = cur_slot0;
                 // (the dataflow schedule takes the product along as filler of its worker kernel: queue.hip)
                 if (n_inv && !c->keep_sigma && !c->q_lauum_in_queue) rc = lauum_lower(c, n_inv, c->stream2);
                 c->q_lauum.n = 0;
@@ -1079,7 +1107,7 @@ static int run_phase(gprn_ctx* c, bool weights)
     return exchange_rows(c, weights);
 }
 
-static int mu_k_mu(gprn_ctx* c, bool weights)
+static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream)
 {
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
     const int ns = (int)gps.size();
@@ -1089,8 +1117,8 @@ static int mu_k_mu(gprn_ctx* c, bool weights)
     // a = L_K^-1 m_g with m_g = state row g (nodes: mu_f[g]; weights: the raw-reshape row, quirk Q2)
     c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
     double* a = c->d_u + (size_t)c->slot0 * c->ld;
-    TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, a));
-    return vec_dot_self(c, slotgp, ns, a, c->d_muKmu);
+    TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, a, stream));
+    return vec_dot_self(c, slotgp, ns, a, c->d_muKmu, stream);
 }
 
 static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out, bool retry);
@@ -1126,13 +1154,14 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
     timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     for (int it = 0; it < n_sweeps; ++it) {
         HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), c->stream));
+        c->node_term_done = false;
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));
-        if (c->q1_pending) {                    // the Q1 traces computed behind the weight phase
+        if (c->q1_pending) {                    // the Q1 traces (and the node term) computed behind the weight phase
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_q1, 0));
             c->q1_pending = false;
         }
-        TRY(mu_k_mu(c, false));
+        if (!c->node_term_done) TRY(mu_k_mu(c, false));
         TRY(mu_k_mu(c, true));
         TRY(reduce_scalars(c));
         TRY(vec_elbo(c, c->d_out + 4 * (size_t)it));

@@ -19,6 +19,7 @@
 #include "gprn_internal.h"
 #include "dag.h"
 #include "tile_mma.h"
+#include "vecops.h"
 
 #include <math.h>
 #include <time.h>
@@ -1009,7 +1010,7 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
     if (wait_flag) spin_until(wait_flag, wait_value, timed_out);
 }
 
-#define GPRN_FLAG_KINDS 10          // flag kinds per tile step / outer panel (factor_invert_split)
+#define GPRN_FLAG_KINDS 11          // flag kinds per tile step / outer panel (factor_invert_split)
 
 // Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
 // beside them: every switch that serialises kernels or starves the hardware queues means events.
@@ -1113,7 +1114,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     const int use_flags = factor_use_flags(c);
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_RESTA, F_KINDS };
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_RESTA, F_TAIL, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
@@ -1131,7 +1132,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         c->sig_budget_ms = c->wait_budget_ms;
     }
     const unsigned epoch = ++c->epoch;
-    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr, nullptr, c->ev_resta};
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, nullptr, nullptr, c->ev_resta, c->ev_tail};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself
         return use_flags ? Signal{slot(idx, kind), epoch} : Signal{nullptr, 0};
@@ -1245,6 +1246,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         f.swap(c->chain_started);
         if ((rc = f())) return rc;
     }
+    bool tail_on_s2 = false;                       // rows_final ran on the bulk stream: joined at the end
     int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
@@ -1292,7 +1294,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             HIP_TRY(c, raise(s2, (int)J, F_REST));
             rest_J = (int)J;
         }
-            return GPRN_OK;
+        // rows [k0, k1) of X are final once stream3 is through with the panel: their share of the phase's O(N^2)
+        // reductions goes behind the panel's bulk update on the bulk stream (run_phase, api.hip)
+        if (c->rows_final && !use_chain && !persist) {
+            if (!(o.nrest && sr) && sn != s2) HIP_TRY(c, await(s2, (int)J, F_PANEL));
+            if ((rc = c->rows_final(o.k0, o.k1, s2))) return rc;
+            c->rows_done = o.k1;
+            tail_on_s2 = true;
+        }
+        return GPRN_OK;
     };
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
         const gprn_ctx::OuterRange& o = c->outers[set][J];
@@ -1441,6 +1451,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
+    if (tail_on_s2) {
+        HIP_TRY(c, raise(s2, 0, F_TAIL));
+        HIP_TRY(c, await(s0, 0, F_TAIL));
+    }
     return GPRN_OK;
 }
 
@@ -1503,6 +1517,7 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (rc) return rc;
     static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
+    if (!(split_sched() && !(queue_enabled(c) && c->T > 1))) c->rows_final = nullptr;   // only the launch schedule calls it
     if (split_sched() && queue_enabled(c) && c->T > 1) {
         rc = factor_invert_queue(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
         if (rc) {

@@ -132,6 +132,14 @@ struct gprn_ctx {
                                      // kernels wait for each other in-kernel; 0: one stream; -1: not probed yet
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr, ev_resta = nullptr;
     hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
+    // head / tail of a phase beside its factorisation (run_phase, api.hip; factor_invert_split, factor.hip)
+    hipEvent_t ev_tail = nullptr;
+    bool node_term_done = false;     // the node phase's mu^T K^-1 mu went to the bulk stream beside the weight phase (run_phase)
+    // run_phase: called (by schedules that know) once tile rows [r0, r1) of X are final in `stream` order -- the O(N^2)
+    // reductions over X's rows (X z, column norms, X^T u) then run beside the rest of the factorisation instead of
+    // behind it; rows_done: first tile row the caller still has to do itself
+    std::function<int(int r0, int r1, hipStream_t stream)> rows_final;
+    int rows_done = 0;
     hipStream_t prof_stream = nullptr;
     std::string err;
     int info_gp = -1;

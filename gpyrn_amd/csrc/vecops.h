@@ -3,15 +3,20 @@
 #include "gprn_internal.h"
 
 int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots);
-int vec_build_B(gprn_ctx* c, int nslots);
+// part 0: all of B; 1 / 2: what the first outer panel (`outer` tiles) touches before its trailing update / the rest
+int vec_build_B(gprn_ctx* c, int nslots, hipStream_t stream = nullptr, int part = 0, int outer = 0);
 int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* out);
+// rows [row0, row0 + nrows) of the product (nrows < 0: to the last row)
 int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, int vin_by_gp,
-                     const int* d_slot_gp, int nslots, double* out);
-int vec_colops(gprn_ctx* c, int nslots);
-int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots);
+                     const int* d_slot_gp, int nslots, double* out, hipStream_t stream = nullptr,
+                     int row0 = 0, int nrows = -1);
+int vec_colops(gprn_ctx* c, int nslots);                 // partial sums of every tile row + the reduction
+int vec_colops_partial(gprn_ctx* c, int nslots, hipStream_t stream, int ch0, int nch);   // tile rows [ch0, ch0 + nch)
+int vec_colops_reduce(gprn_ctx* c, int nslots);
+int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet = false);   // with_logdet: log det B from BUF_B too
 int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
            double* scratch, double* out_scalar, hipStream_t stream);
-int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out);
+int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out, hipStream_t stream = nullptr);
 int vec_elbo(gprn_ctx* c, double* out4);
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);
 int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,

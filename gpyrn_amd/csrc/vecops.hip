@@ -16,6 +16,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 typedef double v2d __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -100,11 +102,18 @@ void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q
 }
 
 // B = I + D^1/2 K D^1/2 on the lower tiles (diagonal tiles in full); identity padding
+// part 0: every lower tile; part 1: what the factorisation's first outer panel touches before its K = outer * 128
+// update (tile columns < outer, and of the next `outer` columns the diagonal and sub-diagonal tiles, which the in-panel
+// lists keep up to date step by step: ensure_tasks, factor.hip); part 2: the others (built beside the first tile steps)
 __global__ __launch_bounds__(256)
-void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __restrict__ s)
+void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __restrict__ s, int part, int outer)
 {
     const int tj = blockIdx.x, ti = blockIdx.y, slot = blockIdx.z;
     if (tj > ti) return;
+    if (part) {
+        const bool early = tj < outer || (tj < 2 * outer && ti <= tj + 1);
+        if (early != (part == 1)) return;
+    }
     const double* K = ptrs[(size_t)slot * GPRN_NBUF + BUF_K];
     double* B = ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     const double* sv = s + (size_t)slot * ld;
@@ -150,14 +159,14 @@ void k_logdet(double* const* __restrict__ ptrs, int buf, int N, int ld,
 }
 
 // out[slot][i] = sum_{c<=i} M[i][c] v[c]   (i < N), M = ptrs[slot][buf];
-// v = vin + (vin_by_gp ? slot_gp[slot] : slot) * vstride
+// v = vin + (vin_by_gp ? slot_gp[slot] : slot) * vstride; rows row0 + 4 * blockIdx.x .. of the matrix
 __global__ __launch_bounds__(256)
 void k_lower_matvec(double* const* __restrict__ ptrs, int buf, int N, int ld,
                     const double* __restrict__ vin, size_t vstride, int vin_by_gp,
-                    const int* __restrict__ slot_gp, double* __restrict__ out)
+                    const int* __restrict__ slot_gp, double* __restrict__ out, int row0)
 {
     const int slot = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= ld) return;
     const double* M = ptrs[(size_t)slot * GPRN_NBUF + buf] + (size_t)i * ld;
     const double* v = vin + (size_t)(vin_by_gp ? slot_gp[slot] : slot) * vstride;
@@ -177,10 +186,10 @@ void k_lower_matvec(double* const* __restrict__ ptrs, int buf, int N, int ld,
 // grid (ld/64, T, nslots); tiles above the diagonal are skipped (and not read later)
 __global__ __launch_bounds__(256)
 void k_colops_partial(double* const* __restrict__ ptrs, int ld, int T,
-                      const double* __restrict__ u, double* __restrict__ part)
+                      const double* __restrict__ u, double* __restrict__ part, int ch0)
 {
     __shared__ double shs[4][64], sht[4][64];
-    const int c0 = blockIdx.x * 64, ch = blockIdx.y, slot = blockIdx.z;
+    const int c0 = blockIdx.x * 64, ch = ch0 + blockIdx.y, slot = blockIdx.z;
     if (ch < (c0 >> 7)) return;
     const double* X = ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
     const double* uv = u + (size_t)slot * ld;
@@ -233,23 +242,31 @@ __global__ __launch_bounds__(256)
 void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                 const double* __restrict__ d, const double* __restrict__ s,
                 const double* __restrict__ z, const double* __restrict__ cs, const double* __restrict__ ct,
-                double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv)
+                double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv,
+                double* const* __restrict__ ptrs, double* __restrict__ logdetB)
 {
     __shared__ double sh[4];
     const int slot = blockIdx.x, gp = slot_gp[slot];
     size_t row;
     if (gp < q) row = gp;
     else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
-    double tr = 0.0;
+    // log det B = 2 sum log diag(L) in the same pass (k_logdet's sum, same order: one launch less on the phase's tail)
+    const double* Lm = ptrs ? ptrs[(size_t)slot * GPRN_NBUF + BUF_B] : nullptr;
+    double tr = 0.0, ld_acc = 0.0;
     for (int n = threadIdx.x; n < N; n += 256) {
         const size_t o = (size_t)slot * ld + n;
         const double binv = cs[o];
         tr += binv;
         mu[row * N + n] = (z[o] - ct[o]) / s[o];
         var[row * N + n] = (1.0 - binv) / d[o];
+        if (Lm) ld_acc += log(Lm[(size_t)n * ld + n]);
     }
     tr = block_sum(tr, sh);
     if (threadIdx.x == 0) trBinv[gp] = tr;
+    if (Lm) {
+        ld_acc = block_sum(ld_acc, sh);
+        if (threadIdx.x == 0) logdetB[gp] = 2.0 * ld_acc;
+    }
 }
 
 // rowsum[m] = sum_{n<=m} w(m,n) Kinv[m][n] (delta_mn - Binv[m][n]) / (s_m s_n), w = 2 off-diagonal
@@ -383,12 +400,13 @@ int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots)
     LAUNCH_END(c);
 }
 
-int vec_build_B(gprn_ctx* c, int nslots)
+int vec_build_B(gprn_ctx* c, int nslots, hipStream_t stream, int part, int outer)
 {
     if (!nslots) return GPRN_OK;
-    prof_begin(c, GPRN_T_BUILD_B);
-    hipLaunchKernelGGL(k_build_B, dim3(c->T, c->T, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld);
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_BUILD_B, stream);
+    hipLaunchKernelGGL(k_build_B, dim3(c->T, c->T, nslots), dim3(256), 0, stream,
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld, part, outer);
     LAUNCH_END(c);
 }
 
@@ -402,36 +420,59 @@ int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* o
 }
 
 int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, int vin_by_gp,
-                     const int* d_slot_gp, int nslots, double* out)
+                     const int* d_slot_gp, int nslots, double* out, hipStream_t stream, int row0, int nrows)
 {
     if (!nslots) return GPRN_OK;
-    prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_lower_matvec, dim3(c->ld / 4, nslots), dim3(256), 0, c->stream,
+    if (!stream) stream = c->stream;
+    if (nrows < 0) nrows = c->ld - row0;
+    if (nrows <= 0) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_lower_matvec, dim3((nrows + 3) / 4, nslots), dim3(256), 0, stream,
                        (double* const*)c->d_ptrs, buf, c->N, c->ld, vin, vstride, vin_by_gp,
-                       d_slot_gp, out);
+                       d_slot_gp, out, row0);
     LAUNCH_END(c);
 }
 
-int vec_colops(gprn_ctx* c, int nslots)
+// partial column sums of tile rows [ch0, ch0 + nch) (nch < 0: to the last); columns right of tile row ch0 + nch - 1
+// hold nothing of these rows
+int vec_colops_partial(gprn_ctx* c, int nslots, hipStream_t stream, int ch0, int nch)
+{
+    if (!nslots) return GPRN_OK;
+    if (!stream) stream = c->stream;
+    if (nch < 0) nch = c->T - ch0;
+    if (nch <= 0) return GPRN_OK;
+    prof_begin(c, GPRN_T_VEC, stream);
+    const size_t o = (size_t)c->slot0 * c->ld, po = (size_t)c->slot0 * c->T * 2 * c->ld;
+    const int ncol64 = std::min(c->ld / 64, 2 * (ch0 + nch));
+    hipLaunchKernelGGL(k_colops_partial, dim3(ncol64, nch, nslots), dim3(256), 0, stream,
+                       (double* const*)c->d_ptrs, c->ld, c->T, c->d_u + o, c->d_part + po, ch0);
+    LAUNCH_END(c);
+}
+
+int vec_colops_reduce(gprn_ctx* c, int nslots)
 {
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
     const size_t o = (size_t)c->slot0 * c->ld, po = (size_t)c->slot0 * c->T * 2 * c->ld;
-    hipLaunchKernelGGL(k_colops_partial, dim3(c->ld / 64, c->T, nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, c->ld, c->T, c->d_u + o, c->d_part + po);
     hipLaunchKernelGGL(k_colops_reduce, dim3((c->ld + 255) / 256, nslots), dim3(256), 0,
                        c->stream, c->ld, c->T, c->d_part + po, c->d_cs + o, c->d_ct + o);
     LAUNCH_END(c);
 }
 
-int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots)
+int vec_colops(gprn_ctx* c, int nslots)
+{
+    int rc = vec_colops_partial(c, nslots, nullptr, 0, -1);
+    return rc ? rc : vec_colops_reduce(c, nslots);
+}
+
+int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet)
 {
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
     const size_t o = (size_t)c->slot0 * c->ld;
     hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                        c->p, c->q, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
-                       c->d_trBinv);
+                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB);
     LAUNCH_END(c);
 }
 
@@ -445,11 +486,12 @@ int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double
     LAUNCH_END(c);
 }
 
-int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out)
+int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out, hipStream_t stream)
 {
     if (!nslots) return GPRN_OK;
-    prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_dot_self, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_dot_self, dim3(nslots), dim3(256), 0, stream, d_slot_gp, c->N, c->ld,
                        a, out);
     LAUNCH_END(c);
 }
