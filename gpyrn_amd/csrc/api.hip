@@ -170,6 +170,8 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //                    not fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG
 //   "queue"          1/0: the factorisation as a task graph run by a persistent worker kernel (queue.hip; needs "flags"), or
 //                    the launch-per-step schedule of factor.hip
+//   "block_sched"    1/0: the block schedule of the factorisation where it applies (factor_invert_blocks, factor.hip) or the
+//                    step-synchronous launch schedule everywhere; -1: the environment's GPRN_BLOCK_SCHED / the default (1)
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -180,6 +182,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "queue")) { queue_enabled(c); field = &c->queue_mode; }
+    else if (!strcmp(name, "block_sched")) field = &c->block_sched;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "chain_pad_kb")) field = &c->chain_pad_kb_opt;
@@ -324,6 +327,7 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_xw, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
         device_streams_release(c->shared);
         delete c;
@@ -365,6 +369,7 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         hipEventDestroy(c->ev_nodes);
         hipEventDestroy(c->ev_q1);
         hipEventDestroy(c->ev_tail);
+        hipEventDestroy(c->ev_xw);
     }
     device_streams_release(c->shared);
     delete c;
@@ -1031,7 +1036,9 @@ static int run_phase(gprn_ctx* c, bool weights)
                 return vec_colops_partial(c, ns, st, r0, r1 - r0);
             };
         }
+        c->fast_factor = true;                       // X's lower tiles and diag(L) are all the phase reads
         const int rc_f = factor_invert(c, ns);
+        c->fast_factor = false;
         const int rd = c->rows_done;
         c->rows_final = nullptr; c->rows_done = 0;
         TRY(rc_f);

@@ -976,6 +976,115 @@ int ensure_tasks(gprn_ctx* c)
         outers.push_back(o);
     }
     }   // set
+    // ---- block schedule (factor_invert_blocks).  Outer panel [k0, k1) of GPRN_OUTER tiles; D = its diagonal block.
+    //   per tile step k: in-block panel   L_ik = B_ik X_kk^T (k < i < k1),   X_kc = X_kk R_kc (k0 <= c < k)
+    //                    in-block update  B_ij -= L_ik L_jk^T (k < j <= i < k1),   R_ic (-)= L_ik X_kc (k < i < k1, k0 <= c <= k)
+    //   -> L_D and X_D = L_D^-1 (the diagonal block of X IS the inverse of the diagonal block of L)
+    //   once per panel:  L[i, panel] = B[i, panel] X_D^T (i >= k1),   X[panel, c] = X_D R[panel, c] (c < k0)
+    // as plain products with K = 128 (j' + 1) for column / row tile j' of the panel (X_D is lower triangular).  Both
+    // would overwrite their own inputs tile by tile, so they go to MIRRORS, transposed, in the unused strictly upper
+    // tiles of the OTHER buffer's ... of a buffer:  L[i, k0+j']^T -> BUF_X tile (k0+j', i),  X[k0+j', c]^T -> BUF_B tile
+    // (c, k0+j').  Transposed, the four tiles of a panel row are contiguous in k for the trailing update, which reads
+    // its operands from the mirrors (modes 1/1 for L L^T, 1/0 for L X).  X's rows are copied back into place (the
+    // phase's reductions read them); L's only for callers that ask (fast_factor = false).
+    {
+        const int outer = outer_big;
+        c->bsteps.assign(T, gprn_ctx::BlkStep{0, 0, 0, 0, 0});
+        c->bpanels.clear();
+        for (int k0 = 0; k0 < T; k0 += outer) {
+            const int k1 = std::min(T, k0 + outer), n1 = std::min(T, k1 + outer), n2 = std::min(T, n1 + outer);
+            for (int k = k0; k < k1; ++k) {
+                gprn_ctx::BlkStep& b = c->bsteps[k];
+                b.l0 = v.size();
+                for (int i = k + 1; i < k1; ++i)
+                    v.push_back(TileTask{toff(i, k, ld), toff(i, k, ld), toff(k, k, ld), GPRN_TILE,
+                                         BUF_B, BUF_B, BUF_X, tile_modes(CM_SET, 0, 0)});
+                b.nl_l = v.size() - b.l0;
+                for (int cc = k0; cc < k; ++cc)
+                    v.push_back(TileTask{toff(k, cc, ld), toff(k, k, ld), toff(k, cc, ld), GPRN_TILE,
+                                         BUF_X, BUF_X, BUF_X, tile_modes(CM_SET, 0, 1)});
+                b.nl = v.size() - b.l0;
+                b.u0 = v.size();
+                for (int j = k + 1; j < k1; ++j)           // the next diagonal tile first
+                    for (int i = j; i < k1; ++i)
+                        v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                             BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0, lower_diag && i == j)});
+                for (int i = k + 1; i < k1; ++i)
+                    for (int cc = k0; cc <= k; ++cc)
+                        v.push_back(TileTask{toff(i, cc, ld), toff(i, k, ld), toff(k, cc, ld), GPRN_TILE,
+                                             BUF_X, BUF_B, BUF_X, tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
+                b.nu = v.size() - b.u0;
+            }
+            gprn_ctx::BlkPanel bp{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const int kw = (k1 - k0) * GPRN_TILE;
+            // L side: C = X_D[j', 0..j'] B[i, k0..k0+j']^T, tile (k0+j', i) of BUF_X
+            bp.tl0 = v.size();
+            for (int i = k1; i < T; ++i) {
+                for (int jp = 0; jp < k1 - k0; ++jp)
+                    v.push_back(TileTask{toff(k0 + jp, i, ld), toff(k0 + jp, k0, ld), toff(i, k0, ld), (jp + 1) * GPRN_TILE,
+                                         BUF_X, BUF_X, BUF_B, tile_modes(CM_SET, 0, 0)});
+                if (i == n1 - 1) bp.ntl_early = v.size() - bp.tl0;
+            }
+            bp.ntl = v.size() - bp.tl0;
+            // X side: C = R[panel, c]^T X_D[j', 0..j']^T, tile (c, k0+j') of BUF_B
+            bp.tx0 = v.size();
+            for (int cc = 0; cc < k0; ++cc)
+                for (int jp = 0; jp < k1 - k0; ++jp)
+                    v.push_back(TileTask{toff(cc, k0 + jp, ld), toff(k0, cc, ld), toff(k0 + jp, k0, ld), (jp + 1) * GPRN_TILE,
+                                         BUF_B, BUF_X, BUF_X, tile_modes(CM_SET, 1, 0)});
+            bp.ntx = v.size() - bp.tx0;
+            // copies (k_tile_tcopy: C = A^T): X rows back into place; L far tiles into place (on request)
+            bp.cbx0 = v.size();
+            for (int cc = 0; cc < k0; ++cc)
+                for (int jp = 0; jp < k1 - k0; ++jp)
+                    v.push_back(TileTask{toff(k0 + jp, cc, ld), toff(cc, k0 + jp, ld), 0, 0, BUF_X, BUF_B, BUF_B, 0});
+            bp.cbl0 = v.size();
+            for (int i = k1; i < T; ++i)
+                for (int jp = 0; jp < k1 - k0; ++jp)
+                    v.push_back(TileTask{toff(i, k0 + jp, ld), toff(k0 + jp, i, ld), 0, 0, BUF_B, BUF_X, BUF_X, 1 /* clear the mirror */});
+            // trailing update from the mirrors.  Classes: 0 the next panel's diagonal block (the chain's own launch),
+            // 1 the rest of the next panel's columns of B and its rows of R, 2 the panel after next's, 3 beyond.
+            // (the DIAGONAL blocks of the panels after that move up one class each -- the one after next with "next",
+            // the third with "ahead": the chain's update of a diagonal block then follows launches that ran a whole
+            // panel earlier, not the previous panel's "ahead" part, which queues behind a long "bulk" launch)
+            const int n3 = std::min(T, n2 + outer);
+            auto clsB = [&](int i, int j) {
+                if (j < n1) return i < n1 ? 0 : 1;
+                if (j < n2) return i < n2 ? 1 : 2;
+                if (j < n3) return i < n3 ? 2 : 3;
+                return 3;
+            };
+            auto clsR = [&](int i) { return i < n1 ? 1 : (i < n2 ? 2 : 3); };
+            for (int pass = 0; pass < 4; ++pass) {
+                const size_t begin = v.size();
+                for (int i = k1; i < T; ++i) {
+                    for (int j = k1; j <= i; ++j) {
+                        if (clsB(i, j) != pass) continue;
+                        v.push_back(TileTask{toff(i, j, ld), toff(k0, i, ld), toff(k0, j, ld), kw,
+                                             BUF_B, BUF_X, BUF_X, tile_modes(CM_SUB, 1, 1, lower_diag && i == j)});
+                    }
+                    if (clsR(i) != pass) continue;
+                    for (int cc = 0; cc < k0; ++cc)
+                        v.push_back(TileTask{toff(i, cc, ld), toff(k0, i, ld), toff(cc, k0, ld), kw,
+                                             BUF_X, BUF_X, BUF_B, tile_modes(CM_SUB, 1, 0)});
+                    for (int cc = k0; cc < k1; ++cc)
+                        v.push_back(TileTask{toff(i, cc, ld), toff(cc, i, ld), toff(cc, cc, ld), (k1 - cc) * GPRN_TILE,
+                                             BUF_X, BUF_X, BUF_X, tile_modes(CM_SETNEG, 1, 1)});
+                }
+                auto by_klen = [](const TileTask& a, const TileTask& b) { return a.klen < b.klen; };
+                if (pass == 0) { bp.dn0 = begin; bp.ndn = v.size() - begin; }
+                else if (pass == 1) { bp.next0 = begin; bp.nnext = v.size() - begin; }
+                else if (pass == 2) {
+                    std::stable_sort(v.begin() + begin, v.end(), by_klen);
+                    bp.rest0 = begin; bp.nrestA = v.size() - begin;
+                } else {
+                    std::stable_sort(v.begin() + begin, v.end(), by_klen);
+                    bp.nrest = v.size() - bp.rest0;
+                }
+            }
+            c->bpanels.push_back(bp);
+        }
+    }
     // lower(X^T X) -> BUF_B: tile (a,b), a >= b, sums over rows a*128 .. ld of X
     // (short contractions first: a launch of these runs beside the next phase's factorisation, whose diagonal
     // block needs a whole free CU -- the CUs that got the short tasks come free within tens of microseconds)
@@ -1232,11 +1341,16 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (persist) {
         prof_begin(c, GPRN_T_DIAG, s0);
         PtrArgs pa;
+        // GPRN_DIAG_EXCL_KB (experiments): unused dynamic LDS on top of the kernel's 46.6 KB -- with enough of it no
+        // other workgroup that uses LDS shares the persistent workgroup's CU (no co-resident MFMA waves on its SIMDs)
+        static int excl_kb = -1;
+        if (excl_kb < 0) { const char* e = getenv("GPRN_DIAG_EXCL_KB"); excl_kb = e ? atoi(e) : 0; }
+        const size_t dyn_excl = std::min<size_t>((size_t)excl_kb * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
         if (tab_rows(c, c->d_ptrs, nbatch, &pa))
-            hipLaunchKernelGGL(k_diag_chain<true>, dim3(nbatch), dim3(256), 0, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
+            hipLaunchKernelGGL(k_diag_chain<true>, dim3(nbatch), dim3(256), dyn_excl, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
                                c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_U, epoch, timed_out);
         else
-            hipLaunchKernelGGL(k_diag_chain<false>, dim3(nbatch), dim3(256), 0, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
+            hipLaunchKernelGGL(k_diag_chain<false>, dim3(nbatch), dim3(256), dyn_excl, s0, (double* const*)c->d_ptrs, pa, c->ld, c->T,
                                c->d_info_cur, c->d_sig, (int)F_KINDS, (int)F_DIAG, (int)F_U, epoch, timed_out);
         prof_end(c);
         HIP_TRY(c, hipGetLastError());
@@ -1458,6 +1572,178 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     return GPRN_OK;
 }
 
+// Block schedule.  The latency chain factors and inverts the 512 x 512 diagonal block D of an outer panel
+// entirely on its own stream -- per tile step the diagonal tile, the in-block panel and the in-block update, nothing of
+// which waits for another stream -- and the rest of the panel is not done step by step at all:
+//     L[i, panel] = B[i, panel] X_D^T  (i >= k1)       X[panel, c] = X_D R[panel, c]  (c < k0)
+// are ONE launch each per panel (K <= 512, into transposed mirrors, see ensure_tasks), followed by the K = 512 trailing
+// update in four classes: the next panel's diagonal block (the chain's own launch: its next input), the rest of the next
+// panel's columns / rows, the panel after next's, everything beyond.  Against factor_invert_split: no step-synchronous
+// side stream (its three dependent launches per tile step were what the chain waited for when one or two matrices are
+// factored), a tenth of the launches and stream operations, and the in-panel tiles are read and written once per panel
+// instead of up to three times with K = 128.
+//   chain   : per step  diag(k) -> in-block panel -> in-block update;  per panel  [X_D complete: F_PANEL] ... wait F_FIRST
+//             -> update of the next diagonal block
+//   stream3 : wait F_PANEL(P), F_NEXT(P-1);  L mirrors of the next block's rows [F_FIRST], of the other rows [F_MINIL]
+//   stream4 : wait F_PANEL(P), F_NEXT(P-1);  X mirrors + copy back [F_XW];  wait F_MINIL(P), F_RESTA(P-1);  "next" [F_NEXT]
+//   bulk    : wait F_MINIL(P), F_XW(P);  "ahead" [F_RESTA], "bulk" [F_REST], the phase's row reductions (rows_final)
+static int factor_invert_blocks(gprn_ctx* c, int nbatch)
+{
+    int rc;
+    hipStream_t s0 = c->stream, s1 = c->stream3, s2 = c->stream2, s4 = c->stream4;
+    const int use_flags = factor_use_flags(c);
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_RESTA, F_TAIL, F_KINDS };
+    static_assert(F_KINDS == GPRN_FLAG_KINDS, "flag kinds");
+    if (use_flags && c->sig_T < c->T) {
+        if (c->d_sig) hipFree(c->d_sig);
+        c->d_sig = nullptr;
+        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
+        c->sig_T = c->T;
+        c->epoch = 0;
+        c->sig_budget_ms = -1;
+    }
+    if (use_flags && c->sig_budget_ms != c->wait_budget_ms) {
+        const unsigned ticks = (unsigned)std::min<long long>(0xffffffffll, (long long)c->wait_budget_ms * 100000ll);
+        HIP_TRY(c, hipMemcpy(c->d_sig + (size_t)c->sig_T * F_KINDS * 2 + 1, &ticks, sizeof(unsigned), hipMemcpyHostToDevice));
+        c->sig_budget_ms = c->wait_budget_ms;
+    }
+    const unsigned epoch = ++c->epoch;
+    hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first, c->ev_xw, nullptr, c->ev_resta, c->ev_tail};
+    auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
+    unsigned* timed_out = c->d_sig ? c->d_sig + (size_t)c->sig_T * F_KINDS * 2 : nullptr;
+    auto raise = [&](hipStream_t st, int idx, int kind) {
+        return use_flags ? hipStreamWriteValue32(st, slot(idx, kind) + 1, epoch, 0) : hipEventRecord(events[kind], st);
+    };
+    auto await = [&](hipStream_t st, int idx, int kind) {
+        return use_flags ? hipStreamWaitValue32(st, slot(idx, kind) + 1, epoch, hipStreamWaitValueGte, 0xffffffffu)
+                         : hipStreamWaitEvent(st, events[kind], 0);
+    };
+    auto in_kernel = [&](int idx, int kind) {      // the launch raises the flag itself (flag schedule)
+        return use_flags ? Signal{slot(idx, kind), epoch, nullptr, 0, timed_out} : Signal{nullptr, 0, nullptr, 0, nullptr};
+    };
+    // the chain waits through a one-thread kernel (bounded by the wait budget) instead of a stream wait
+    auto chain_wait = [&](int idx, int kind) -> int {
+        if (!use_flags) { HIP_TRY(c, hipStreamWaitEvent(s0, events[kind], 0)); return GPRN_OK; }
+        hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, s0, (unsigned*)nullptr, 0u,
+                           (const unsigned*)(slot(idx, kind) + 1), epoch, timed_out);
+        HIP_TRY(c, hipGetLastError());
+        return GPRN_OK;
+    };
+    const Await noaw{nullptr, 0, nullptr, nullptr, 0};
+    const Signal nosig{nullptr, 0, nullptr, 0, nullptr};
+    static size_t big = 0;                         // tasks x batch above which 128x128 workgroups pay
+    if (!big) { const char* e = getenv("GPRN_FEW_TASKS"); big = e && atoi(e) > 0 ? (size_t)atoi(e) : 4000; }
+    auto shape_for = [&](size_t n) { return n * (size_t)nbatch > big ? TS_128x128 : TS_64x64; };
+    auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam, int tag, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr}) {
+        return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, Await{nullptr, 0, nullptr, nullptr, 0}, tag);
+    };
+    static int bulk_shape = -1;
+    if (bulk_shape < 0) { const char* e = getenv("GPRN_BULK_SHAPE"); bulk_shape = e ? atoi(e) : TS_64x64; }
+    int first_raises = 0;
+    auto withheld = [&]() {                        // test hook (gprn_set_option "withhold_inner"): the n-th F_FIRST signal
+        return use_flags && c->withhold_inner > 0 && ++first_raises == c->withhold_inner;
+    };
+    if (!use_flags && c->chain_started) {          // event schedule: nothing to gate it on
+        std::function<int()> f;
+        f.swap(c->chain_started);
+        if ((rc = f())) return rc;
+    }
+    const int NP = (int)c->bpanels.size();
+    bool tail_on_s2 = false;
+    int last_next = -1, last_rest = -1, last_x = -1;
+    for (int P = 0; P < NP; ++P) {
+        const gprn_ctx::BlkPanel& bp = c->bpanels[P];
+        // ---- the chain: the diagonal block of the panel
+        for (int k = bp.k0; k < bp.k1; ++k) {
+            const gprn_ctx::BlkStep& b = c->bsteps[k];
+            const bool hook = use_flags && k == 0 && (bool)c->chain_started;
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, hook ? in_kernel(0, F_DIAG) : nosig, noaw))) return rc;
+            if (hook) {
+                // work handed over by the caller for the bulk stream goes behind the FIRST diagonal block (see factor_invert_split)
+                HIP_TRY(c, await(s2, 0, F_DIAG));
+                std::function<int()> f;
+                f.swap(c->chain_started);
+                if ((rc = f())) return rc;
+            }
+            // in-block panel: L_ik (k < i < k1), X_kc (k0 <= c < k); the last step of the panel completes X_D
+            if (b.nl && (rc = launch_panel_rows(c, c->d_tasks + b.l0, b.nl_l, b.nl - b.nl_l, c->d_ptrs, nbatch, c->ld, s0, nosig, noaw))) return rc;
+            // (GPRN_BLK_U=0: the throughput kernel for the in-block updates, experiments)
+            static int blk_u = -1;
+            if (blk_u < 0) { const char* e = getenv("GPRN_BLK_U"); blk_u = e ? atoi(e) : 1; }
+            if (b.nu && blk_u && (rc = launch_blk_update(c, c->d_tasks + b.u0, b.nu, c->d_ptrs, nbatch, c->ld, s0, nosig, noaw))) return rc;
+            if (b.nu && !blk_u && (rc = tiles(b.u0, b.nu, s0, TS_64x64, GPRN_T_PANEL, TG_INNER))) return rc;
+        }
+        HIP_TRY(c, raise(s0, P, F_PANEL));                           // L_D, X_D are complete
+        if (bp.ntl) {
+            // ---- the chain goes on with the L mirrors of the next block's rows and the update of the next diagonal
+            // block.  B[i, panel] and that block were last written by the previous panel's "next" update.
+            if (last_next >= 0 && (rc = chain_wait(last_next, F_NEXT))) return rc;
+            // test hook ("withhold_inner" = n): the chain's n-th boundary waits for a flag nobody raises -- the in-kernel
+            // wait gives up at its budget and the call is re-run on events (F_U is not used by this schedule)
+            if (withheld() && (rc = chain_wait(0, F_U))) return rc;
+            if (use_flags) {
+                if ((rc = tiles(bp.tl0, bp.ntl_early, s0, TS_64x64, GPRN_T_PANEL, TG_TRMM, in_kernel(P, F_FIRST)))) return rc;
+            } else {
+                if ((rc = tiles(bp.tl0, bp.ntl_early, s0, TS_64x64, GPRN_T_PANEL, TG_TRMM))) return rc;
+                HIP_TRY(c, raise(s0, P, F_FIRST));
+            }
+            if ((rc = tiles(bp.dn0, bp.ndn, s0, TS_64x64, GPRN_T_PANEL, TG_NEXT))) return rc;
+            // ---- stream3: the L mirrors of the other rows
+            HIP_TRY(c, await(s1, P, F_PANEL));
+            if (last_next >= 0) HIP_TRY(c, await(s1, last_next, F_NEXT));
+            if ((rc = tiles(bp.tl0 + bp.ntl_early, bp.ntl - bp.ntl_early, s1, shape_for(bp.ntl - bp.ntl_early), GPRN_T_PANEL, TG_TRMM))) return rc;
+            HIP_TRY(c, raise(s1, P, F_MINIL));
+        }
+        // ---- stream4: the X mirrors and their copy back; then the "next" part of the update
+        HIP_TRY(c, await(s4, P, F_PANEL));
+        if (last_next >= 0 && last_next != P - 1) HIP_TRY(c, await(s4, last_next, F_NEXT));   // (its own "next" is in order)
+        if (bp.ntx) {
+            if ((rc = tiles(bp.tx0, bp.ntx, s4, shape_for(bp.ntx), GPRN_T_PANEL, TG_TRMM))) return rc;
+            if ((rc = launch_tcopy(c, c->d_tasks + bp.cbx0, bp.ntx, c->d_ptrs, nbatch, c->ld, s4))) return rc;
+        }
+        HIP_TRY(c, raise(s4, P, F_XW));
+        last_x = P;
+        if (bp.ntl) {
+            // ---- "next" on stream4, "ahead" / "bulk" on the bulk stream
+            HIP_TRY(c, await(s4, P, F_MINIL));
+            HIP_TRY(c, await(s4, P, F_FIRST));
+            if (last_rest >= 0) HIP_TRY(c, await(s4, last_rest, F_RESTA));
+            if ((rc = tiles(bp.next0, bp.nnext, s4, shape_for(bp.nnext), GPRN_T_PANEL, TG_NEXT))) return rc;
+            HIP_TRY(c, raise(s4, P, F_NEXT));
+            last_next = P;
+            HIP_TRY(c, await(s2, P, F_MINIL));
+            HIP_TRY(c, await(s2, P, F_XW));
+            if ((rc = tiles(bp.rest0, bp.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, TG_AHEAD))) return rc;
+            HIP_TRY(c, raise(s2, P, F_RESTA));
+            if ((rc = tiles(bp.rest0 + bp.nrestA, bp.nrest - bp.nrestA, s2, bulk_shape, GPRN_T_UPDATE, TG_BULK))) return rc;
+            HIP_TRY(c, raise(s2, P, F_REST));
+            last_rest = P;
+            // rows [k0, k1) of X are final (in-block tiles by the chain, the others copied back): their share of the
+            // phase's O(N^2) reductions, behind the panel's bulk update
+            if (c->rows_final) {
+                if ((rc = c->rows_final(bp.k0, bp.k1, s2))) return rc;
+                c->rows_done = bp.k1;
+                tail_on_s2 = true;
+            }
+        }
+    }
+    // ---- joins; callers that want L itself (and clean upper triangles) get the mirrors copied into place
+    if (last_x >= 0) HIP_TRY(c, await(s0, last_x, F_XW));
+    if (last_next >= 0) HIP_TRY(c, await(s0, last_next, F_NEXT));
+    if (last_rest >= 0) HIP_TRY(c, await(s0, last_rest, F_REST));
+    if (tail_on_s2) {
+        HIP_TRY(c, raise(s2, 0, F_TAIL));
+        HIP_TRY(c, await(s0, 0, F_TAIL));
+    }
+    if (!c->fast_factor)
+        for (int P = 0; P < NP; ++P) {
+            const gprn_ctx::BlkPanel& bp = c->bpanels[P];
+            if ((rc = launch_tcopy(c, c->d_tasks + bp.cbl0, bp.ntl, c->d_ptrs, nbatch, c->ld, s0))) return rc;
+        }
+    return GPRN_OK;
+}
+
 // a dependency wait inside a chain kernel gave up (see Await): the results of that call are void
 int factor_check_waits(gprn_ctx* c)
 {
@@ -1535,8 +1821,27 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
         }
         return rc;
     }
-    if (split_sched()) {
+    // GPRN_BLOCK_SCHED / option "block_sched": 1 = the block schedule where it applies (throughput set, at least three
+    // outer panels), 0 (default) = the step-synchronous launch schedule everywhere.  Measured at config 3: 103.7-104.5
+    // sweeps/s with it in both phases, 107-108.5 in the weight phase only, against 110 without
+    static int blk_env = -1;
+    if (blk_env < 0) { const char* e = getenv("GPRN_BLOCK_SCHED"); blk_env = e ? atoi(e) : 0; }
+    const int blk = c->block_sched >= 0 ? c->block_sched : blk_env;
+    static int blk_min = -1, blk_max = -1;         // GPRN_BLOCK_MIN_BATCH / GPRN_BLOCK_MAX_BATCH (experiments): batches it applies to
+    if (blk_min < 0) { const char* e = getenv("GPRN_BLOCK_MIN_BATCH"); blk_min = e ? atoi(e) : 0; }
+    if (blk_max < 0) { const char* e = getenv("GPRN_BLOCK_MAX_BATCH"); blk_max = e ? atoi(e) : 1 << 30; }
+    const bool blocks = split_sched() && blk && !(nbatch * c->T <= lat_max) && c->bpanels.size() >= 3 && c->stream4 &&
+                        nbatch >= blk_min && nbatch <= blk_max;
+    if (blocks) {
+        static int side_pad = -1;                  // GPRN_BLK_SIDE_PAD=0: no LDS pad on the side streams' launches
+        if (side_pad < 0) { const char* e = getenv("GPRN_BLK_SIDE_PAD"); side_pad = e ? atoi(e) : 1; }
+        c->pad_side_now = side_pad != 0;
+        rc = factor_invert_blocks(c, nbatch);
+        c->pad_side_now = false;
+    } else if (split_sched()) {
         rc = factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
+    }
+    if (split_sched()) {
         if (rc && c->d_sig && c->use_flags == 1) {
             // The enqueue broke off half-way: stream waits already queued on the device's shared streams would
             // wait for flags nobody will raise (they have no time-out).  Put every flag of this call up so that

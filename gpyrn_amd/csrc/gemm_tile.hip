@@ -136,7 +136,7 @@ void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __
 
 __global__ void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
                              unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                             unsigned* wait_timed_out);     // the same panel at 16-row / 16-column granularity, below
+                             unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value);     // the same panel at 16-row / 16-column granularity, below
 
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                  hipStream_t stream, Signal sig)
@@ -150,10 +150,25 @@ int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, d
     prof_begin(c, GPRN_T_PANEL, stream);
     if (panel_rows)
         hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)(8 * (n_l + n_x)), (unsigned)nbatch), dim3(512), 0, stream, d_tasks, (int)n_l,
-                           (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
+                           (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out,
+                           (const unsigned*)nullptr, 0u);
     else
     hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
                        (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// the in-block panel of a tile step of the block schedule (factor.hip): k_panel_rows on the chain stream
+int launch_panel_rows(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
+                      hipStream_t stream, Signal sig, Await aw)
+{
+    if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig, aw);
+    prof_begin(c, GPRN_T_PANEL, stream);
+    hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)(8 * (n_l + n_x)), (unsigned)nbatch), dim3(512), 0, stream, d_tasks, (int)n_l,
+                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                       aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -252,9 +267,11 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
 __global__ __launch_bounds__(512)
 void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                  unsigned* wait_timed_out)
+                  unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value)
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
+    CHAIN_PRIO();
+    await_flag(wait_flag, wait_value, wait_timed_out);
     const int ti = blockIdx.x >> 3, blk = blockIdx.x & 7;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -359,6 +376,66 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     RW_STAMP(6);
 }
 
+// The block schedule's in-block updates (factor.hip): a LIST of 128 x 128 tile tasks at the same granularity -- one
+// single-wave workgroup per 16 x 16 block of the output, operands straight from global memory into MFMA operand
+// registers, 128 of K at a time (32 MFMAs).  Every operand / output mode of TileTask; a diagonal tile of a symmetric
+// update (modes bit 4) computes its lower blocks only.  Latency kernel: no LDS, no staging pipeline, a few microseconds
+// beside whatever fills the CUs (the throughput kernel needs 17-34 us for the same tasks on a loaded device).
+__global__ __launch_bounds__(64)
+void k_blk_update(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
+                  unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
+                  unsigned* wait_timed_out)
+{
+    CHAIN_PRIO();
+    await_flag(wait_flag, wait_value, wait_timed_out);
+    const TileTask t = tasks[blockIdx.x >> 6];
+    const int P = (blockIdx.x >> 3) & 7, Q = blockIdx.x & 7;
+    const int c_mode = t.modes & 3, a_mode = (t.modes >> 2) & 1, b_mode = (t.modes >> 3) & 1;
+    if (!(((t.modes >> 4) & 1) && Q > P)) {           // (uniform)
+        double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+        const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
+        // K index of a lane: load j brings k = 8 j + 2 fk and 8 j + 2 fk + 1 (the same split for both operands)
+        const double* A = gp[t.a_buf] + t.a_off + (a_mode ? (size_t)(2 * fk) * ld + 16 * P + fr : (size_t)(16 * P + fr) * ld + 2 * fk);
+        const double* B = gp[t.b_buf] + t.b_off + (b_mode ? (size_t)(2 * fk) * ld + 16 * Q + fr : (size_t)(16 * Q + fr) * ld + 2 * fk);
+        gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
+        const size_t a_step = a_mode ? (size_t)8 * ld : 8, b_step = b_mode ? (size_t)8 * ld : 8;
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (c_mode == CM_SUB) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
+        }
+        const bool neg = c_mode != CM_SET;
+        for (int k0 = 0; k0 < t.klen; k0 += GPRN_TILE) {
+            double a[32], b[32];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (a_mode) { a[2 * j] = A[j * a_step]; a[2 * j + 1] = A[j * a_step + ld]; }
+                else { const double2 v = *(const double2*)(A + j * a_step); a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+                if (b_mode) { b[2 * j] = B[j * b_step]; b[2 * j + 1] = B[j * b_step + ld]; }
+                else { const double2 v = *(const double2*)(B + j * b_step); b[2 * j] = v.x; b[2 * j + 1] = v.y; }
+            }
+            A += 16 * a_step; B += 16 * b_step;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a[j] : a[j], b[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
+    }
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+}
+
+int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld,
+                      hipStream_t stream, Signal sig, Await aw)
+{
+    if (ntasks == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_64x64, sig, aw);
+    prof_begin(c, GPRN_T_PANEL, stream);
+    hipLaunchKernelGGL(k_blk_update, dim3((unsigned)(64 * ntasks), (unsigned)nbatch), dim3(64), 0, stream, d_tasks,
+                       (double* const*)d_ptrs, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
 // mode 0 / 1 as above, for tile step k: the operands are tiles (k+1, k), (k, k) [of X] resp. (k+1, k+1), (k+1, k) --
 // the first panel and the first update task of the step (ensure_tasks, factor.hip)
 int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
@@ -411,6 +488,43 @@ int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, 
     else { if (args) GO_UQ(true); else GO_UQ(false); }
 #undef GO_LQ
 #undef GO_UQ
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// C = A^T for a list of 128 x 128 tiles (block schedule, factor.hip: the mirrors of a panel back into place), one
+// workgroup per 64 x 64 quarter; modes bit 0: clear A afterwards
+__global__ __launch_bounds__(256)
+void k_tile_tcopy(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld)
+{
+    __shared__ double t[64][65];
+    const TileTask tk = tasks[blockIdx.x >> 2];
+    const int q = blockIdx.x & 3, qr = q >> 1, qc = q & 1;          // quarter of the source tile
+    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
+    double* const A = gp[tk.a_buf] + tk.a_off + (size_t)qr * 64 * ld + qc * 64;
+    double* const C = gp[tk.c_buf] + tk.c_off + (size_t)qc * 64 * ld + qr * 64;
+    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = r0 + 4 * it;
+        t[r][col] = A[(size_t)r * ld + col];
+        if (tk.modes & 1) A[(size_t)r * ld + col] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int r = r0 + 4 * it;
+        C[(size_t)r * ld + col] = t[col][r];
+    }
+}
+
+int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld, hipStream_t stream)
+{
+    if (ntasks == 0 || nbatch == 0) return GPRN_OK;
+    prof_begin(c, GPRN_T_PANEL, stream);
+    hipLaunchKernelGGL(k_tile_tcopy, dim3((unsigned)(4 * ntasks), (unsigned)nbatch), dim3(256), 0, stream, d_tasks,
+                       (double* const*)d_ptrs, ld);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -503,6 +617,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     const int kb = nbatch <= pad_small_batch ? (c->pad_small_kb_opt >= 0 ? c->pad_small_kb_opt : pad_small_kb)
                                              : (c->pad_kb_opt >= 0 ? c->pad_kb_opt : pad_kb);
     size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
+    // the block schedule's side launches (panel products with the block inverse, "next"): the same pad, so that every CU
+    // keeps a diagonal-block kernel's worth of LDS and registers free whatever mix of them it runs
+    if (c->pad_side_now && stream != c->stream) dyn = (size_t)kb * 1024;
     // The chain's own tile launches (one task: L_{k+1,k}, the B_{k+1,k+1} update) can ask for unused LDS too: with
     // enough of it they only land on CUs that run no bulk workgroup and are not slowed by MFMA-saturating
     // neighbours (GPRN_CHAIN_PAD_KB, experiments).
@@ -532,6 +649,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // ... its look-ahead part (what the next panel's outer update writes again), a launch of its own
     case TS_64x64 * 8 + TG_AHEAD: GO(64, 64, 0, TG_AHEAD); break;
     case TS_128x128 * 8 + TG_AHEAD: GO(128, 128, 0, TG_AHEAD); break;
+    // block schedule: a panel's products with the inverse of its diagonal block, K <= 512
+    case TS_64x64 * 8 + TG_TRMM: GO(64, 64, 0, TG_TRMM); break;
+    case TS_128x128 * 8 + TG_TRMM: GO(128, 128, 0, TG_TRMM); break;
     // X^T X, prediction products, diagnostics
     case TS_128x128 * 8 + TG_MISC: GO(128, 128, 0, TG_MISC); break;
     case TS_64x64 * 8 + TG_MISC: GO(64, 64, 0, TG_MISC); break;

@@ -131,7 +131,7 @@ struct gprn_ctx {
     int chain_streams = -1;          // 1: the chain runs on two streams (diagonal blocks | tile launches) whose
                                      // kernels wait for each other in-kernel; 0: one stream; -1: not probed yet
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr, ev_resta = nullptr;
-    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr, ev_xw = nullptr;
     // head / tail of a phase beside its factorisation (run_phase, api.hip; factor_invert_split, factor.hip)
     hipEvent_t ev_tail = nullptr;
     bool node_term_done = false;     // the node phase's mu^T K^-1 mu went to the bulk stream beside the weight phase (run_phase)
@@ -251,6 +251,21 @@ struct gprn_ctx {
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
+    // ---- block schedule (factor_invert_blocks, factor.hip): the latency chain factors and inverts the 512 x 512
+    // diagonal block of an outer panel on its own; everything else of the panel is ONE triangular product per side
+    // with the block's inverse (K <= 512) and the K = 512 trailing update
+    struct BlkStep { size_t l0, nl_l, nl, u0, nu; };           // in-block: L tiles then X tiles of the step; its updates
+    struct BlkPanel { int k0, k1;
+                      size_t tl0, ntl, ntl_early;              // L[i, panel]^T -> mirror (BUF_X upper), rows of the next block first
+                      size_t tx0, ntx, cbx0;                   // X[panel, c]^T -> mirror (BUF_B upper); copy back into X (ntx tasks)
+                      size_t cbl0;                             // L mirror -> B lower (ntl tasks; callers that want L in place)
+                      size_t dn0, ndn, next0, nnext, rest0, nrest, nrestA; };
+    std::vector<BlkStep> bsteps;
+    std::vector<BlkPanel> bpanels;
+    bool pad_side_now = false;       // launch_tiles: LDS pad on every launch off the chain stream (block schedule)
+    bool fast_factor = false;        // run_phase: the caller reads X's lower tiles and diag(L) only -- far tiles of L may
+                                     // stay in their mirror, the strictly upper tiles of both buffers are scratch
+    int block_sched = -1;            // gprn_set_option "block_sched": 1 block schedule where it applies, 0 never, -1 environment
 };
 
 struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)
@@ -273,7 +288,8 @@ enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
 // launch family of a tile launch: a template tag of k_tile_gemm, so that a kernel trace reports every
 // family under its own kernel name (panel products, in-panel K=128 updates, next-panel K=512 updates,
 // bulk K=512 updates, everything else)
-enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4, TG_AHEAD = 5 };
+enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4, TG_AHEAD = 5,
+       TG_TRMM = 6 };   // block schedule: a panel's products with the inverse of its diagonal block (K <= 512)
 // Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
@@ -301,6 +317,12 @@ int launch_grad_fd(gprn_ctx* c, const KernelSpec& ks, const double* Kinv, const 
 // the L part (n_l tasks) and the X part (n_x tasks) of a tile step's panel in one launch (gemm_tile.hip)
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                  hipStream_t stream, Signal sig);
+// block schedule: the in-block panel of a tile step at 16-row / 16-column granularity; C = A^T over a list of tiles
+int launch_panel_rows(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
+                      hipStream_t stream, Signal sig, Await aw);
+int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld,
+                      hipStream_t stream, Signal sig, Await aw);   // a list of tile tasks, one wave per 16 x 16 block
+int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld, hipStream_t stream);
 // BUF_B and BUF_X of up to GPRN_ARG_SLOTS matrices as a kernel argument
 #define GPRN_ARG_SLOTS 16
 struct PtrArgs { double* p[GPRN_ARG_SLOTS][2]; };
