@@ -819,11 +819,22 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
     PtrArgs pa;
+    // Little work in total (batch x tiles <= GPRN_DIAG_PAD_MAX, the latency schedule's problems): most CUs are idle, and
+    // with GPRN_DIAG_PAD_KB of unused dynamic LDS (default: all a workgroup may have) the workgroup only lands on a CU
+    // that runs nothing else which uses LDS -- no co-resident MFMA waves of the side stream's tile kernels on its SIMDs.
+    // Config 2 (N = 2048, one matrix per phase): 686 -> 741 sweeps/s.  On a loaded device it waits for such a CU as long
+    // as the neighbours would have cost (config 3 with the pad in the node phase: 109.8 vs 110.1), hence the limit.
+    static int diag_pad_kb = -1, diag_pad_max = -1;
+    if (diag_pad_kb < 0) { const char* e = getenv("GPRN_DIAG_PAD_KB"); diag_pad_kb = e ? atoi(e) : 113; }
+    if (diag_pad_max < 0) { const char* e = getenv("GPRN_DIAG_PAD_MAX"); diag_pad_max = e ? atoi(e) : 32; }
+    size_t dyn = 0;
+    if (diag_pad_kb > 0 && nbatch * c->T <= diag_pad_max)
+        dyn = std::min<size_t>((size_t)diag_pad_kb * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
     if (tab_rows(c, d_ptrs, nbatch, &pa))
-        hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk,
+        hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
                            d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     else
-        hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk,
+        hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
                            d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
