@@ -226,7 +226,7 @@ static void free_problem(gprn_ctx* c)
     dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
     dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
     dev_free(c->d_cs); dev_free(c->d_ct); dev_free(c->d_part);
-    dev_free(c->d_scal); dev_free(c->d_out); dev_free(c->d_info);
+    dev_free(c->d_scal_base); c->d_scal = nullptr; dev_free(c->d_elbo_part); dev_free(c->d_out); dev_free(c->d_info);
     c->d_ptrs = nullptr;
     c->nslot = 0; c->out_cap = 0;
     c->factored = c->have_yres = c->have_jit = c->have_muvar = false;
@@ -408,7 +408,9 @@ extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* tim
     TRY(dev_alloc(c, &c->d_mu_save, dn));
     TRY(dev_alloc(c, &c->d_var_save, dn));
     TRY(dev_alloc(c, &c->d_logdetK, c->G));
-    TRY(dev_alloc(c, &c->d_scal, 3 * c->G + q * q));
+    TRY(dev_alloc(c, &c->d_scal_base, 2 * (size_t)(3 * c->G + q * q)));
+    TRY(dev_alloc(c, &c->d_elbo_part, 2 * (size_t)GPRN_ELBO_PART_DOUBLES));
+    c->d_scal = c->d_scal_base;
     c->d_logdetB = c->d_scal;
     c->d_trBinv = c->d_scal + c->G;
     c->d_muKmu = c->d_scal + 2 * c->G;
@@ -1007,7 +1009,7 @@ static int factor_priors_impl(gprn_ctx* c)
 }
 
 // ------------------------------------------------------------------ sweep
-static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr);
+static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr, double* out = nullptr);
 
 static int run_phase(gprn_ctx* c, bool weights)
 {
@@ -1020,15 +1022,19 @@ static int run_phase(gprn_ctx* c, bool weights)
     const size_t o = (size_t)c->slot0 * c->ld;
     if (ns) {
         TRY(vec_prep(c, weights, slotgp, ns));
-        TRY(vec_build_B(c, ns));
+        // B = I + D^1/2 K D^1/2: built by factor_invert -- under the launch schedule only the tiles its first outer panel's
+        // tile steps touch; the others are formed from K inside that panel's K = 512 update (GPRN_OVERLAP bit 1)
         // The reductions over the rows of X = L^-1 (u = X z, column norms, X^T u: 8 N^2 bytes per matrix) run outer
         // panel by outer panel as the rows become final (rows_final, called by the launch schedule on the bulk
         // stream); behind the factorisation only the last panel's rows, the reduction over the partial sums and the
         // new state are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
-        // GPRN_OVERLAP bits: 2 this, 4 the node phase's mu^T K^-1 mu beside the weight phase, 8 log det B in k_finalize.
+        // GPRN_OVERLAP bits: 1 B formed inside the first update, 2 this, 4 the node phase's mu^T K^-1 mu beside the weight
+        // phase, 8 log det B in k_finalize.
         static int overlap = -1;
-        if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 14; }
+        if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 15; }
         c->rows_done = 0;
+        c->build_pending = ns;
+        c->ft_s_phase = (overlap & 1) ? c->d_s + o : nullptr;
         if (overlap & 2) {
             c->rows_final = [c, o, slotgp, ns](int r0, int r1, hipStream_t st) -> int {
                 TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, st, r0 * GPRN_TILE,
@@ -1039,6 +1045,7 @@ static int run_phase(gprn_ctx* c, bool weights)
         c->fast_factor = true;                       // X's lower tiles and diag(L) are all the phase reads
         const int rc_f = factor_invert(c, ns);
         c->fast_factor = false;
+        c->ft_s_phase = nullptr; c->build_pending = 0;
         const int rd = c->rows_done;
         c->rows_final = nullptr; c->rows_done = 0;
         TRY(rc_f);
@@ -1114,7 +1121,7 @@ static int run_phase(gprn_ctx* c, bool weights)
     return exchange_rows(c, weights);
 }
 
-static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream)
+static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream, double* out)
 {
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
     const int ns = (int)gps.size();
@@ -1125,7 +1132,7 @@ static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream)
     c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
     double* a = c->d_u + (size_t)c->slot0 * c->ld;
     TRY(vec_lower_matvec(c, BUF_KLINV, c->d_mu, c->N, 1, slotgp, ns, a, stream));
-    return vec_dot_self(c, slotgp, ns, a, c->d_muKmu, stream);
+    return vec_dot_self(c, slotgp, ns, a, out ? out : c->d_muKmu, stream);
 }
 
 static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out, bool retry);
@@ -1159,19 +1166,55 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
     }
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
     timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
+    // The end of a sweep -- mu_w^T K_w^-1 mu_w (one pass over the six L_K^-1), the ELBO assembly and the wait for the
+    // Q1 traces, some 150 us on the chain stream -- reads only what the sweep has left behind, and the next sweep's node
+    // phase reads none of its results: inside a call of several sweeps it runs beside that phase, on the bulk stream,
+    // handed to its factorisation like the X^T X product (chain_started: behind the first diagonal block, i.e. after
+    // everything this sweep enqueued on the chain stream; the bulk stream is in order, so the Q1 traces are there too).
+    // The per-GP scalars live in two copies for it.  Single-rank calls under the flag schedule only (no collective may
+    // move; GPRN_OVERLAP bit 16); the last sweep of a call is assembled in line.
+    static int overlap = -1;
+    if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 31; }
+    const size_t nscal = 3 * (size_t)c->G + (size_t)c->q * c->q;
+    // (the node phase's factorisation must be one that joins the bulk stream at its end: an outer panel with a "rest")
+    c->chain_started = nullptr;
+    TRY(ensure_tasks(c));
+    const int node_set = (int)c->loc_nodes.size() * c->T <= 32 ? 1 : 0;
+    const bool node_joins = !c->outers[node_set].empty() && c->outers[node_set][0].nrest > 0;
+    const bool may_defer = (overlap & 16) && !comm_active(c) && factor_use_flags(c) == 1 && !queue_enabled(c) &&
+                           !c->loc_nodes.empty() && !c->loc_weights.empty() && !c->keep_sigma && node_joins;
     for (int it = 0; it < n_sweeps; ++it) {
-        HIP_TRY(c, hipMemsetAsync(c->d_scal, 0, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), c->stream));
+        double* const scal = c->d_scal_base + (size_t)(it & 1) * nscal;
+        double* const part = c->d_elbo_part + (size_t)(it & 1) * GPRN_ELBO_PART_DOUBLES;
+        c->d_scal = scal;
+        c->d_logdetB = scal; c->d_trBinv = scal + c->G; c->d_muKmu = scal + 2 * (size_t)c->G; c->d_q1 = scal + 3 * (size_t)c->G;
+        HIP_TRY(c, hipMemsetAsync(scal, 0, nscal * sizeof(double), c->stream));
         c->node_term_done = false;
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));
-        if (c->q1_pending) {                    // the Q1 traces (and the node term) computed behind the weight phase
+        const bool defer = may_defer && it + 1 < n_sweeps;
+        if (c->q1_pending && !defer) {          // the Q1 traces (and the node term) computed behind the weight phase
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_q1, 0));
-            c->q1_pending = false;
         }
-        if (!c->node_term_done) TRY(mu_k_mu(c, false));
+        c->q1_pending = false;
+        const bool node_term = !c->node_term_done;
+        double* const out4 = c->d_out + 4 * (size_t)it;
+        if (defer) {
+            c->chain_started = [c, scal, part, out4, node_term]() -> int {
+                double** const cur = c->d_ptrs;
+                const int cur_slot0 = c->slot0;
+                int rc = node_term ? mu_k_mu(c, false, c->stream2, scal + 2 * (size_t)c->G) : GPRN_OK;
+                if (!rc) rc = mu_k_mu(c, true, c->stream2, scal + 2 * (size_t)c->G);
+                if (!rc) rc = vec_elbo(c, out4, scal, part, c->stream2);
+                c->d_ptrs = cur; c->slot0 = cur_slot0;
+                return rc;
+            };
+            continue;
+        }
+        if (node_term) TRY(mu_k_mu(c, false));
         TRY(mu_k_mu(c, true));
         TRY(reduce_scalars(c));
-        TRY(vec_elbo(c, c->d_out + 4 * (size_t)it));
+        TRY(vec_elbo(c, out4, scal, part));
     }
     if (!commit) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));

@@ -949,8 +949,10 @@ int ensure_tasks(gprn_ctx* c)
             for (int i = k1; i < T; ++i) {
                 for (int j = k1; j <= i; ++j) {
                     if (clsB(i, j) != pass) continue;
+                    // (bit 5: the first outer panel's update is the first K = 512 update of every tile it touches)
                     v.push_back(TileTask{toff(i, j, ld), toff(i, k0, ld), toff(j, k0, ld), kw,
-                                         BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0, lower_diag && i == j)});
+                                         BUF_B, BUF_B, BUF_B,
+                                         (uint8_t)(tile_modes(CM_SUB, 0, 0, lower_diag && i == j) | (k0 == 0 ? 32 : 0))});
                 }
                 if (clsR(i) != pass) continue;
                 for (int cc = 0; cc < k0; ++cc)
@@ -1224,8 +1226,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // tag: TG_PANEL for the panel products (the only users of the 64x128 / 128x64 shapes), else as given
     auto tiles = [&](size_t first, size_t n, hipStream_t st, int shape, int fam = GPRN_T_PANEL,
                      Signal sig = Signal{nullptr, 0}, Await aw = Await{nullptr, 0, nullptr}, int tag = TG_INNER) {
-        if (shape == TS_64x128 || shape == TS_128x64) tag = TG_PANEL;
-        if (tri) shape = shape == TS_64x128 ? TS_64x128_BTRI : (shape == TS_128x64 ? TS_128x64_ATRI : shape);
+        if ((shape == TS_64x128 || shape == TS_128x64) && tag == TG_INNER) {   // (the panel products' calls leave the tag alone)
+            tag = TG_PANEL;
+            if (tri) shape = shape == TS_64x128 ? TS_64x128_BTRI : TS_128x64_ATRI;
+        }
         return launch_tiles(c, c->d_tasks + first, n, c->d_ptrs, nbatch, c->ld, fam, st, shape, sig, aw, tag);
     };
     // Cross-stream dependencies travel through 32-bit flags in device memory instead of events:
@@ -1372,6 +1376,23 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         if ((rc = f())) return rc;
     }
     bool tail_on_s2 = false;                       // rows_final ran on the bulk stream: joined at the end
+    // B is still to be built (run_phase): only what the first outer panel's tile steps touch; its K = 512 update forms
+    // the other tiles from K on the way in (bit 5 of their tasks; tile_mma ft_K) -- 16 N^2 bytes of HBM traffic per
+    // matrix and three quarters of k_build_B's time at the head of the phase less
+    bool ft_fused = false;
+    if (c->build_pending) {
+        const int pend = c->build_pending;
+        c->build_pending = 0;
+        const int outer = c->outers[set][0].k1 - c->outers[set][0].k0;
+        // (the 64 x 64 tile kernel only: every launch of the first panel's update must use that shape)
+        const gprn_ctx::OuterRange& o0 = c->outers[set][0];
+        const char* bs = getenv("GPRN_BULK_SHAPE");
+        const char* bsb = getenv("GPRN_BULK_SHAPE_BIG");
+        const bool small_shapes = shape_upd(o0.nfirst) == TS_64x64 && shape_upd(o0.nnext) == TS_64x64 &&
+                                  (!bs || atoi(bs) == TS_64x64) && (!bsb || atoi(bsb) == TS_64x64);
+        ft_fused = c->ft_s_phase && pend == nbatch && !use_chain && c->T > outer && small_shapes;
+        if ((rc = vec_build_B(c, pend, s0, ft_fused ? 1 : 0, outer))) return rc;
+    }
     int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
@@ -1393,6 +1414,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         hipStream_t sn = sr ? c->stream4 : s2;
         if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
         if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+        // the first panel's update forms the tiles of B it touches from K (run_phase built only the others)
+        struct FtScope { gprn_ctx* c; ~FtScope() { c->ft_s_now = nullptr; } } ft_scope{c};
+        c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
         if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, raise(s1, (int)J, F_FIRST));
         if (o.nfirst > 0) first_J = (int)J;
@@ -1815,7 +1839,15 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
     if (!(split_sched() && !(queue_enabled(c) && c->T > 1))) c->rows_final = nullptr;   // only the launch schedule calls it
+    // B still to be built (run_phase): the launch schedule builds what its first panel touches and forms the rest inside
+    // that panel's update (factor_invert_split); every other schedule gets all of it now
+    auto build_all_now = [&]() -> int {
+        const int pend = c->build_pending;
+        c->build_pending = 0;
+        return pend ? vec_build_B(c, pend) : GPRN_OK;
+    };
     if (split_sched() && queue_enabled(c) && c->T > 1) {
+        if ((rc = build_all_now())) return rc;
         rc = factor_invert_queue(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
         if (rc) {
             // an enqueue that broke off half-way leaves kernels polling for nodes nobody will finish: end their waits
@@ -1843,6 +1875,9 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (blk_max < 0) { const char* e = getenv("GPRN_BLOCK_MAX_BATCH"); blk_max = e ? atoi(e) : 1 << 30; }
     const bool blocks = split_sched() && blk && !(nbatch * c->T <= lat_max) && c->bpanels.size() >= 3 && c->stream4 &&
                         nbatch >= blk_min && nbatch <= blk_max;
+    static int chain_env_b = -1;                   // (the persistent chain kernels start before anything else is enqueued)
+    if (chain_env_b < 0) { const char* e = getenv("GPRN_CHAIN"); chain_env_b = e ? atoi(e) : 0; }
+    if ((blocks || !split_sched() || chain_env_b != 0) && (rc = build_all_now())) return rc;
     if (blocks) {
         static int side_pad = -1;                  // GPRN_BLK_SIDE_PAD=0: no LDS pad on the side streams' launches
         if (side_pad < 0) { const char* e = getenv("GPRN_BLK_SIDE_PAD"); side_pad = e ? atoi(e) : 1; }

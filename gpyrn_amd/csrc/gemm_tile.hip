@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map,
-                 const unsigned* wait_flag2, unsigned wait_value2)
+                 const unsigned* wait_flag2, unsigned wait_value2, const double* ft_s, int ft_n)
 {
     await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
     constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
@@ -94,13 +94,27 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     // triangle would be 36).  Round 2 measured 13 % more MFMAs in the bulk launches than the algorithm needs.
     constexpr bool CAN_LOWER = BM == 64 && BN == 64 && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
     const bool lower = CAN_LOWER && ((t.modes >> 4) & 1);
+    // First touch (modes bit 5, the first outer panel's K = 512 update when the caller hands over s = sqrt(d)): the tile
+    // of B = I + D^1/2 K D^1/2 is formed from K on the way in instead of being read -- k_build_B then writes only what the
+    // first panel's tile steps touch, a quarter of the matrix (run_phase, api.hip).
+    // (64 x 64 workgroups only: the 8-wave 128 x 128 form sits at its 128-register budget and would spill)
+    constexpr bool CAN_FT = BM == 64 && BN == 64 && TRI == 0 && (TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
+    const double* ft_K = nullptr;
+    const double* ft_sv = nullptr;
+    int ft_row = 0, ft_col = 0;
+    if (CAN_FT && ft_s && ((t.modes >> 5) & 1)) {
+        ft_K = pick(BUF_K) + t.c_off + (size_t)sr * BM * ld + sc * BN;
+        ft_sv = ft_s + (size_t)by * ld;
+        ft_row = (int)(t.c_off / ld) + sr * BM;
+        ft_col = (int)(t.c_off % ld) + sc * BN;
+    }
     if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
     else if (CAN_LOWER && lower && sr == sc)
         tile_mma<BM, BN, WM, WN, TRI, false, -1, CAN_LOWER>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                                            (sr * BM) >> 4, (sc * BN) >> 4);
+                                                            (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
     else
         tile_mma<BM, BN, WM, WN, TRI, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                             (sr * BM) >> 4, (sc * BN) >> 4);
+                                             (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
@@ -572,7 +586,7 @@ static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doub
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
                        sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map(),
-                       aw.flag2, aw.value2);
+                       aw.flag2, aw.value2, c->ft_s_now, c->N);
     return true;
 }
 
@@ -646,6 +660,11 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // bulk of an outer update, K = 512
     case TS_64x64 * 8 + TG_BULK: GO(64, 64, 0, TG_BULK); break;
     case TS_128x128 * 8 + TG_BULK: GO(128, 128, 0, TG_BULK); break;
+    // (experiments, GPRN_BULK_SHAPE=2/3: the 4-wave 64 x 128 / 128 x 64 forms for the bulk)
+    case TS_64x128 * 8 + TG_BULK: GO(64, 128, 0, TG_BULK); break;
+    case TS_128x64 * 8 + TG_BULK: GO(128, 64, 0, TG_BULK); break;
+    case TS_64x128 * 8 + TG_AHEAD: GO(64, 128, 0, TG_AHEAD); break;
+    case TS_128x64 * 8 + TG_AHEAD: GO(128, 64, 0, TG_AHEAD); break;
     // ... its look-ahead part (what the next panel's outer update writes again), a launch of its own
     case TS_64x64 * 8 + TG_AHEAD: GO(64, 64, 0, TG_AHEAD); break;
     case TS_128x128 * 8 + TG_AHEAD: GO(128, 128, 0, TG_AHEAD); break;

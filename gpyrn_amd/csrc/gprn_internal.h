@@ -41,7 +41,8 @@ struct TileTask {
     int32_t klen;
     uint8_t c_buf, a_buf, b_buf;
     uint8_t modes;             // bits 0-1 c_mode, bit 2 a_mode, bit 3 b_mode, bit 4: symmetric update of a diagonal tile
-                               // (C -= A A^T, same operand twice): only the lower triangle of the result is ever read
+                               // (C -= A A^T, same operand twice): only the lower triangle of the result is ever read;
+                               // bit 5: the first K = 512 update of a tile of B (first outer panel): may form it from K
 };
 static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode, int lower_only = 0) {
     return (uint8_t)((c_mode & 3) | ((a_mode & 1) << 2) | ((b_mode & 1) << 3) | ((lower_only & 1) << 4));
@@ -191,7 +192,9 @@ struct gprn_ctx {
     double* d_part = nullptr;        // partial column sums scratch [nslot][T][2][ld]
     // per-GP scalars of the running sweep, one allocation (all-reduced as one message):
     // logdetB[G], trBinv[G], muKmu[G], Q1 traces [q*q]
-    double* d_scal = nullptr;
+    double* d_scal = nullptr;        // (two copies: a sweep's ELBO assembly may run beside the next sweep, sweep_impl)
+    double* d_scal_base = nullptr;
+    double* d_elbo_part = nullptr;   // scratch of the ELBO assembly, two copies
     double *d_logdetB = nullptr, *d_trBinv = nullptr, *d_muKmu = nullptr, *d_q1 = nullptr;
     double* d_out = nullptr;         // per sweep: elbo, logl, logp, ent
     int out_cap = 0;
@@ -262,6 +265,12 @@ struct gprn_ctx {
                       size_t dn0, ndn, next0, nnext, rest0, nrest, nrestA; };
     std::vector<BlkStep> bsteps;
     std::vector<BlkPanel> bpanels;
+    // run_phase -> factor_invert_split: s = sqrt(d) of the phase's slots when B's tiles beyond the first outer panel are
+    // still to be formed -- by the first panel's K = 512 update, on the way in (tile_mma ft_K); ft_s_now: what launch_tiles
+    // passes to the kernel right now (set around that update's launches only)
+    int build_pending = 0;           // run_phase: B of this many slots is still to be built by the next factor_invert
+    const double* ft_s_phase = nullptr;
+    const double* ft_s_now = nullptr;
     bool pad_side_now = false;       // launch_tiles: LDS pad on every launch off the chain stream (block schedule)
     bool fast_factor = false;        // run_phase: the caller reads X's lower tiles and diag(L) only -- far tiles of L may
                                      // stay in their mirror, the strictly upper tiles of both buffers are scratch

@@ -46,10 +46,15 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // LOWER: the part lies on the diagonal of a symmetric update C -= A A^T of which only the lower triangle is ever read
 // (the factorisation's diagonal tiles): 16 x 16 blocks strictly above the diagonal (block column > block row inside the
 // 128 x 128 tile) are loaded and stored back unchanged, their MFMAs skipped.
+// ft_K (first touch of a tile of B = I + D^1/2 K D^1/2, CM_SUB only): the incoming C values are not read from C but
+// formed from K (same offsets as C) and s = sqrt(d): delta + (s_row s_col) K, zero outside the n x n problem -- what
+// k_build_B would have written there (same expression, same rounding).  ft_row / ft_col: the part's first row / column
+// inside the matrix.
 template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1, bool LOWER = false>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
                                          int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
-                                         double* out_img = nullptr)
+                                         double* out_img = nullptr, const double* ft_K = nullptr,
+                                         const double* ft_s = nullptr, int ft_row = 0, int ft_col = 0, int ft_n = 0)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,7 +148,27 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     // LDS staging below waits only for the chunk, and the first MFMA of each accumulator only for
     // its own four values -- most of the tile streams in behind the first MFMAs.
     __builtin_amdgcn_sched_barrier(0);
-    if (c_mode == CM_SUB) {                      // one uniform branch around all the loads
+    if (c_mode == CM_SUB && ft_K) {              // first touch: the tile of B is built here
+        gcptr_t Kw = (gcptr_t)ft_K + (size_t)(row0 + fk) * ld + wc * TN + fr;
+        double sc[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) sc[j] = ft_s[ft_col + wc * TN + fr + 16 * j];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = ft_row + row0 + fk + (int)crow(i) + 4 * r;
+                const double sm = m < ft_n ? ft_s[m] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int n = ft_col + wc * TN + fr + 16 * j;
+                    const double kv = (m < ft_n && n < ft_n) ? Kw[(crow(i) + 4 * r) * ld + j * 16] : 0.0;
+                    double v = (n < ft_n) ? sm * sc[j] * kv : 0.0;
+                    if (m == n) v += 1.0;
+                    acc[i][j][r] = -v;
+                }
+            }
+    } else if (c_mode == CM_SUB) {               // one uniform branch around all the loads
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll

@@ -17,7 +17,8 @@ int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet
 int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
            double* scratch, double* out_scalar, hipStream_t stream);
 int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out, hipStream_t stream = nullptr);
-int vec_elbo(gprn_ctx* c, double* out4);
+int vec_elbo(gprn_ctx* c, double* out4, const double* scal, double* part, hipStream_t stream = nullptr);
+#define GPRN_ELBO_PART_DOUBLES (3 * 32)
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);
 int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,
                   double* mean, double* var);

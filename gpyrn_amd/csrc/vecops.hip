@@ -496,13 +496,15 @@ int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a,
     LAUNCH_END(c);
 }
 
-int vec_elbo(gprn_ctx* c, double* out4)
+// scal: the sweep's per-GP scalars (logdetB | trBinv | muKmu | q1); part: 3 * ELBO_BLOCKS doubles of scratch
+int vec_elbo(gprn_ctx* c, double* out4, const double* scal, double* part, hipStream_t stream)
 {
-    prof_begin(c, GPRN_T_VEC);
-    hipLaunchKernelGGL(k_loglike_partial, dim3(ELBO_BLOCKS), dim3(256), 0, c->stream, c->N, c->p, c->q,
-                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, c->d_part /* free here */);
-    hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(64), 0, c->stream, c->N, c->p, c->q, c->d_part,
-                       c->d_logdetK, c->d_logdetB, c->d_trBinv, c->d_muKmu, c->d_q1, out4);
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_loglike_partial, dim3(ELBO_BLOCKS), dim3(256), 0, stream, c->N, c->p, c->q,
+                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, part);
+    hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(64), 0, stream, c->N, c->p, c->q, part,
+                       c->d_logdetK, scal, scal + c->G, scal + 2 * (size_t)c->G, scal + 3 * (size_t)c->G, out4);
     LAUNCH_END(c);
 }
 
