@@ -215,6 +215,11 @@ static void free_problem(gprn_ctx* c)
     for (auto& p : c->Sig) dev_free(p);
     for (auto& p : c->wsB) dev_free(p);
     for (auto& p : c->wsX) dev_free(p);
+    for (auto& p : c->wsB2) dev_free(p);
+    for (auto& p : c->wsX2) dev_free(p);
+    c->wsB2.clear(); c->wsX2.clear();
+    if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
+    dev_free(c->d_s_keep);
     c->K.clear(); c->KLinv.clear(); c->Kinv.clear(); c->Sig.clear(); c->wsB.clear(); c->wsX.clear();
     dev_free(c->d_logdetK);
     for (auto& p : c->predKs) dev_free(p);
@@ -843,6 +848,12 @@ static int upload_table(gprn_ctx* c, double** d_tab, const std::vector<double*>&
 static int build_tables(gprn_ctx* c)
 {
     if (c->tables_ready) return GPRN_OK;
+    // (the second set of node workspaces and its table are rebuilt on demand: sweep_impl)
+    for (auto& p : c->wsB2) dev_free(p);
+    for (auto& p : c->wsX2) dev_free(p);
+    c->wsB2.clear(); c->wsX2.clear();
+    if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
+    dev_free(c->d_s_keep);
     c->loc_nodes.clear(); c->loc_weights.clear();
     for (int g = 0; g < c->q; ++g) if (c->owner[g] == c->rank) c->loc_nodes.push_back(g);
     for (int g = c->q; g < c->G; ++g) if (c->owner[g] == c->rank) c->loc_weights.push_back(g);
@@ -1016,7 +1027,11 @@ static int run_phase(gprn_ctx* c, bool weights)
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
     const int ns = (int)gps.size();
     const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
-    c->d_ptrs = weights ? c->tab_weight : c->tab_node;
+    // (node_alt: the node phase works in the second set of node workspaces, so that the previous sweep's X stays intact
+    // for its X^T X product, which then runs beside THIS node phase: sweep_impl)
+    const bool alt = !weights && c->node_alt;
+    c->d_ptrs = weights ? c->tab_weight : (alt ? c->tab_node2 : c->tab_node);
+    std::vector<double*>& nodeB = alt ? c->wsB2 : c->wsB;
     c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
     c->d_info_cur = c->d_info + (weights ? 2 : 1) * (size_t)c->nslot;
     const size_t o = (size_t)c->slot0 * c->ld;
@@ -1072,41 +1087,63 @@ static int run_phase(gprn_ctx* c, bool weights)
             // phase's factorisation, which enqueues it once its chain kernel holds its CUs (a launch of
             // 528 long-running workgroups just before would keep the chain waiting for a free CU).
             const int n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
-            HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
             const std::vector<int> node_gps = gps;
             double** const node_tab = c->d_ptrs;
-            const bool early_term = (overlap & 4) && !c->loc_weights.empty();
-            c->node_term_done = early_term;
-            c->chain_started = [c, n_inv, ns, node_gps, node_tab, early_term]() -> int {
+            const std::vector<double*> node_B(nodeB.begin(), nodeB.begin() + ns);
+            double* const q1_out = c->d_q1;
+            // the product and the traces, on the bulk stream (s = sqrt(d) of the node slots: overwritten by the next
+            // node phase's k_prep_nodes only -- the deferred form below runs behind that phase's first diagonal block, so it
+            // keeps a copy)
+            c->q1_work = [c, n_inv, ns, node_gps, node_tab, node_B, q1_out](const double* s_nodes) -> int {
                 double** const cur = c->d_ptrs;
-                const int cur_slot0 = c->slot0;
-                HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
-                // mu_f^T K_f^-1 mu_f needs the node phase's result only: HBM-bound work beside the MFMA-bound weight phase
-                int rc = early_term ? mu_k_mu(c, false, c->stream2) : GPRN_OK;
                 c->d_ptrs = node_tab;
-                c->slot0 = cur_slot0;
+                int rc = GPRN_OK;
                 // (the dataflow schedule takes the product along as filler of its worker kernel: queue.hip)
                 if (n_inv && !c->keep_sigma && !c->q_lauum_in_queue) rc = lauum_lower(c, n_inv, c->stream2);
                 c->q_lauum.n = 0;
                 for (int s = 0; s < ns && !rc; ++s) {
                     const int k = node_gps[s];
                     for (int j = k + 1; j < c->q && !rc; ++j)
-                        rc = vec_q1(c, c->Kinv[j], c->wsB[s], c->d_s + (size_t)s * c->ld, c->d_u,
-                                    c->d_q1 + (size_t)j * c->q + k, c->stream2);
+                        rc = vec_q1(c, c->Kinv[j], node_B[s], s_nodes + (size_t)s * c->ld, c->d_u,
+                                    q1_out + (size_t)j * c->q + k, c->stream2);
                 }
                 c->d_ptrs = cur;
+                return rc;
+            };
+            if (c->defer_sweep_end) {
+                // sweep_impl runs it with the rest of the sweep's end beside the NEXT sweep's node phase, where the chain
+                // bounds the time and the tile kernels have room -- not beside this sweep's weight phase, which is bound
+                // by their throughput
+                HIP_TRY(c, hipMemcpyAsync(c->d_s_keep, c->d_s, (size_t)ns * c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+                c->q1_pending = false;
+            } else {
+            HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
+            const bool early_term = (overlap & 4) && !c->loc_weights.empty();
+            c->node_term_done = early_term;
+            c->chain_started = [c, early_term]() -> int {
+                double** const cur = c->d_ptrs;
+                const int cur_slot0 = c->slot0;
+                HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
+                // mu_f^T K_f^-1 mu_f needs the node phase's result only: HBM-bound work beside the MFMA-bound weight phase
+                int rc = early_term ? mu_k_mu(c, false, c->stream2) : GPRN_OK;
+                c->d_ptrs = cur;
+                c->slot0 = cur_slot0;
+                std::function<int(const double*)> w;
+                w.swap(c->q1_work);
+                if (!rc && w) rc = w(c->d_s);
                 if (rc) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev_q1, c->stream2));
                 return GPRN_OK;
             };
             c->q1_pending = true;
+            }
             // offer the product to the next factorisation's worker kernel (taken when the dataflow schedule runs it)
             c->q_lauum.n = 0;
             if (n_inv && !c->keep_sigma && n_inv <= 16) {
                 c->q_lauum.rows.assign((size_t)n_inv * GPRN_NBUF, nullptr);
                 for (int s = 0; s < n_inv; ++s) {
-                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_B] = c->wsB[s];
-                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_X] = c->wsX[s];
+                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_B] = (alt ? c->wsB2 : c->wsB)[s];
+                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_X] = (alt ? c->wsX2 : c->wsX)[s];
                 }
                 c->q_lauum.n = n_inv;
             }
@@ -1183,7 +1220,35 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
     const bool node_joins = !c->outers[node_set].empty() && c->outers[node_set][0].nrest > 0;
     const bool may_defer = (overlap & 16) && !comm_active(c) && factor_use_flags(c) == 1 && !queue_enabled(c) &&
                            !c->loc_nodes.empty() && !c->loc_weights.empty() && !c->keep_sigma && node_joins;
+    // With q > 1 the deferred end of a sweep includes the X^T X product of quirk Q1 (N^3/3 per node but the last): the
+    // node phases then alternate between two sets of node workspaces (the last sweep of a call uses the first set, which
+    // is what the read-back entry points look at).
+    // (GPRN_OVERLAP bit 32, off by default: measured 108.4 against 111.3 sweeps/s at config 3 -- the node phase is bound by
+    // its latency chain, and the product's workgroups on every CU slow the chain's kernels by more than the weight phase gains)
+    const bool alt_ok = may_defer && (overlap & 32) && c->q > 1 && n_sweeps > 1;
+    if (alt_ok && c->wsB2.size() != c->loc_nodes.size()) {
+        const size_t nn2 = (size_t)c->ld * c->ld, nnod = c->loc_nodes.size();
+        for (auto& p : c->wsB2) dev_free(p);
+        for (auto& p : c->wsX2) dev_free(p);
+        c->wsB2.assign(nnod, nullptr); c->wsX2.assign(nnod, nullptr);
+        for (size_t sidx = 0; sidx < nnod; ++sidx) { TRY(dev_alloc(c, &c->wsB2[sidx], nn2)); TRY(dev_alloc(c, &c->wsX2[sidx], nn2)); }
+        if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
+        dev_free(c->d_s_keep);
+        TRY(dev_alloc(c, &c->tab_node2, (size_t)c->nslot * GPRN_NBUF));
+        TRY(dev_alloc(c, &c->d_s_keep, nnod * (size_t)c->ld));
+        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
+        for (size_t sidx = 0; sidx < nnod; ++sidx) {
+            rows[sidx * GPRN_NBUF + BUF_B] = c->wsB2[sidx];
+            rows[sidx * GPRN_NBUF + BUF_X] = c->wsX2[sidx];
+            rows[sidx * GPRN_NBUF + BUF_K] = c->K[c->loc_nodes[sidx]];
+            rows[sidx * GPRN_NBUF + BUF_KLINV] = c->KLinv[c->loc_nodes[sidx]];
+        }
+        TRY(upload_table(c, c->tab_node2, rows));
+    }
+    c->q1_work = nullptr;
     for (int it = 0; it < n_sweeps; ++it) {
+        c->node_alt = alt_ok && (((n_sweeps - 1 - it) & 1) != 0);
+        c->defer_sweep_end = alt_ok && it + 1 < n_sweeps;
         double* const scal = c->d_scal_base + (size_t)(it & 1) * nscal;
         double* const part = c->d_elbo_part + (size_t)(it & 1) * GPRN_ELBO_PART_DOUBLES;
         c->d_scal = scal;
@@ -1200,10 +1265,13 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         const bool node_term = !c->node_term_done;
         double* const out4 = c->d_out + 4 * (size_t)it;
         if (defer) {
-            c->chain_started = [c, scal, part, out4, node_term]() -> int {
+            std::function<int(const double*)> q1w;
+            q1w.swap(c->q1_work);
+            c->chain_started = [c, scal, part, out4, node_term, q1w]() -> int {
                 double** const cur = c->d_ptrs;
                 const int cur_slot0 = c->slot0;
-                int rc = node_term ? mu_k_mu(c, false, c->stream2, scal + 2 * (size_t)c->G) : GPRN_OK;
+                int rc = q1w ? q1w(c->d_s_keep) : GPRN_OK;
+                if (!rc && node_term) rc = mu_k_mu(c, false, c->stream2, scal + 2 * (size_t)c->G);
                 if (!rc) rc = mu_k_mu(c, true, c->stream2, scal + 2 * (size_t)c->G);
                 if (!rc) rc = vec_elbo(c, out4, scal, part, c->stream2);
                 c->d_ptrs = cur; c->slot0 = cur_slot0;
@@ -1216,6 +1284,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         TRY(reduce_scalars(c));
         TRY(vec_elbo(c, out4, scal, part));
     }
+    c->node_alt = false; c->defer_sweep_end = false; c->q1_work = nullptr;
     if (!commit) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));

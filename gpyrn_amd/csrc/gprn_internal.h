@@ -135,6 +135,12 @@ struct gprn_ctx {
     hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr, ev_xw = nullptr;
     // head / tail of a phase beside its factorisation (run_phase, api.hip; factor_invert_split, factor.hip)
     hipEvent_t ev_tail = nullptr;
+    // second set of node workspaces + table (sweep_impl: a sweep's X^T X beside the next sweep's node phase)
+    std::vector<double*> wsB2, wsX2;
+    double** tab_node2 = nullptr;
+    double* d_s_keep = nullptr;      // copy of the node slots' s = sqrt(d) for the deferred Q1 traces
+    bool node_alt = false, defer_sweep_end = false;
+    std::function<int(const double* s_nodes)> q1_work;   // run_phase(nodes) -> whoever runs the Q1 product and traces
     bool node_term_done = false;     // the node phase's mu^T K^-1 mu went to the bulk stream beside the weight phase (run_phase)
     // run_phase: called (by schedules that know) once tile rows [r0, r1) of X are final in `stream` order -- the O(N^2)
     // reductions over X's rows (X z, column norms, X^T u) then run beside the rest of the factorisation instead of
