@@ -172,6 +172,11 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //                    the launch-per-step schedule of factor.hip
 //   "block_sched"    1/0: the block schedule of the factorisation where it applies (factor_invert_blocks, factor.hip) or the
 //                    step-synchronous launch schedule everywhere; -1: the environment's GPRN_BLOCK_SCHED / the default (1)
+//   "overlap"        bit mask of what runs beside the factorisations instead of before / behind them (overlap_mask below:
+//                    1 B formed inside the first update, 2 row reductions panel by panel, 4 node term beside the weight
+//                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep, 32 ... with its X^T X);
+//                    0 = everything in sequence as in rounds 1-2; -1: GPRN_OVERLAP / the default (31).  Results are
+//                    bit-identical for every value
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -183,6 +188,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "queue")) { queue_enabled(c); field = &c->queue_mode; }
     else if (!strcmp(name, "block_sched")) field = &c->block_sched;
+    else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "chain_pad_kb")) field = &c->chain_pad_kb_opt;
@@ -1020,6 +1026,16 @@ static int factor_priors_impl(gprn_ctx* c)
 }
 
 // ------------------------------------------------------------------ sweep
+// What of a phase's head and tail runs beside a factorisation (bits; option "overlap", else GPRN_OVERLAP, else all but 32):
+//   1 B formed inside the first panel's update   2 row reductions over X panel by panel   4 node term beside the weight phase
+//   8 log det B in k_finalize   16 the end of a sweep beside the next sweep's node phase   32 ... with the Q1 product
+static int overlap_mask(const gprn_ctx* c)
+{
+    static int env = -1;
+    if (env < 0) { const char* e = getenv("GPRN_OVERLAP"); env = e ? atoi(e) : 31; }
+    return c->overlap_opt >= 0 ? c->overlap_opt : env;
+}
+
 static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr, double* out = nullptr);
 
 static int run_phase(gprn_ctx* c, bool weights)
@@ -1045,8 +1061,7 @@ static int run_phase(gprn_ctx* c, bool weights)
         // new state are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
         // GPRN_OVERLAP bits: 1 B formed inside the first update, 2 this, 4 the node phase's mu^T K^-1 mu beside the weight
         // phase, 8 log det B in k_finalize.
-        static int overlap = -1;
-        if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 15; }
+        const int overlap = overlap_mask(c);
         c->rows_done = 0;
         c->build_pending = ns;
         c->ft_s_phase = (overlap & 1) ? c->d_s + o : nullptr;
@@ -1210,8 +1225,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
     // everything this sweep enqueued on the chain stream; the bulk stream is in order, so the Q1 traces are there too).
     // The per-GP scalars live in two copies for it.  Single-rank calls under the flag schedule only (no collective may
     // move; GPRN_OVERLAP bit 16); the last sweep of a call is assembled in line.
-    static int overlap = -1;
-    if (overlap < 0) { const char* e = getenv("GPRN_OVERLAP"); overlap = e ? atoi(e) : 31; }
+    const int overlap = overlap_mask(c);
     const size_t nscal = 3 * (size_t)c->G + (size_t)c->q * c->q;
     // (the node phase's factorisation must be one that joins the bulk stream at its end: an outer panel with a "rest")
     c->chain_started = nullptr;

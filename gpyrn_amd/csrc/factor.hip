@@ -1885,7 +1885,13 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
         rc = factor_invert_blocks(c, nbatch);
         c->pad_side_now = false;
     } else if (split_sched()) {
+        // GPRN_SIDE_PAD_MAX_BATCH (experiments): up to that many matrices every launch off the chain stream carries the
+        // small-batch LDS pad (one tile workgroup per CU), not only the bulk
+        static int side_pad_max = -1;
+        if (side_pad_max < 0) { const char* e = getenv("GPRN_SIDE_PAD_MAX_BATCH"); side_pad_max = e ? atoi(e) : 0; }
+        c->pad_side_now = nbatch <= side_pad_max;
         rc = factor_invert_split(c, nbatch, nbatch * c->T <= lat_max ? 1 : 0);
+        c->pad_side_now = false;
     }
     if (split_sched()) {
         if (rc && c->d_sig && c->use_flags == 1) {

@@ -280,6 +280,7 @@ struct gprn_ctx {
     bool pad_side_now = false;       // launch_tiles: LDS pad on every launch off the chain stream (block schedule)
     bool fast_factor = false;        // run_phase: the caller reads X's lower tiles and diag(L) only -- far tiles of L may
                                      // stay in their mirror, the strictly upper tiles of both buffers are scratch
+    int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: environment / default
     int block_sched = -1;            // gprn_set_option "block_sched": 1 block schedule where it applies, 0 never, -1 environment
 };
 

@@ -278,3 +278,48 @@ def test_live_contexts_share_the_device_streams():
     finally:
         for c in live:
             c.close()
+
+
+@pytest.mark.parametrize('n,batch', [(2048, 3), (4096, 2), (4096, 6)])
+def test_factor_invert_block_schedule(ctx, n, batch):
+    # The opt-in block schedule (csrc/factor.hip factor_invert_blocks, option "block_sched"): the chain factors and inverts
+    # the 512 x 512 diagonal block of an outer panel on its own, the rest of the panel is one product with the block's
+    # inverse per side (into transposed mirrors in the unused upper triangles), the trailing update reads the mirrors;
+    # callers that want L itself get the mirrors copied into place and X's upper triangle cleared.  Same factors as LAPACK.
+    old = ctx.option('block_sched', 1)
+    try:
+        rng = np.random.RandomState(120 + batch)
+        A = np.array([_spd(n, rng, 1.0 + 0.25 * b) for b in range(batch)])
+        before = ctx.option('fallbacks')
+        L, X, info = ctx.test_factor_invert(A)
+        assert info == 0 and ctx.option('fallbacks') == before
+        for b in range(batch):
+            np.testing.assert_allclose(np.tril(L[b]), np.linalg.cholesky(A[b]), rtol=0, atol=2e-11)
+            assert not np.any(np.triu(X[b], 1))            # the mirrors are gone
+            _check_factor_by_probes(A[b], L[b], X[b], rng, 1e-10)
+    finally:
+        ctx.option('block_sched', max(old, 0))
+
+
+def test_block_schedule_time_out_falls_back(ctx, capfd):
+    # the chain's wait at a panel boundary never ends (test hook): it gives up after the budget and the call is run again
+    # on HIP events, through the same schedule
+    if not ctx.option('flags'):
+        pytest.skip('device-side waits are off for this context')
+    rng = np.random.RandomState(131)
+    A = np.array([_spd(2048, rng, 1.0 + 0.5 * b) for b in range(3)])
+    old = ctx.option('block_sched', 1)
+    before = ctx.option('fallbacks')
+    ctx.option('wait_budget_ms', 20)
+    ctx.option('withhold_inner', 2)
+    try:
+        L, X, info = ctx.test_factor_invert(A)
+    finally:
+        ctx.option('withhold_inner', 0)
+        ctx.option('wait_budget_ms', 2000)
+        ctx.option('block_sched', max(old, 0))
+    assert info == 0 and ctx.option('fallbacks') == before + 1 and ctx.option('flags') == 0
+    for b in range(3):
+        np.testing.assert_allclose(np.tril(L[b]), np.linalg.cholesky(A[b]), rtol=0, atol=1e-11)
+    assert 'timed out' in capfd.readouterr().err
+    ctx.option('flags', 1)

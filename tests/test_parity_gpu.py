@@ -187,6 +187,42 @@ def test_cfg3_properties_full_size():
         np.testing.assert_allclose(e_a[:2], dd['elbo_sweeps'], rtol=RTOL)
 
 
+def test_overlap_modes_are_bit_identical():
+    """What runs beside the factorisations instead of before / behind them (option "overlap": B formed inside the first
+    panel's update, the row reductions over X panel by panel, the node term beside the weight phase, log det B inside
+    k_finalize, a sweep's end -- and its X^T X -- beside the next sweep's node phase) changes WHEN kernels run, never a
+    rounding: four forced sweeps of an N = 4096, q = 2 problem (two outer-panel schedules per sweep, T = 32) give the same
+    bits for every mask.  The block schedule (option "block_sched") orders the additions differently: 1e-10."""
+    N, p, q = 4096, 1, 2
+    t, ys, es = synth.rv_series(N, p)
+    spec = synth.component_spec(p, q, 'QuasiPeriodic')
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+    ctx = g._setup_device(nodes, weights, means, jit)
+    mu0, var0 = g._initMuVar(nodes, weights, jit)
+    out = {}
+    try:
+        for mask in (0, 1, 2, 4 | 8, 16, 31, 63):
+            ctx.option('overlap', mask)
+            ctx.set_muvar(mu0, var0)
+            e, parts, info = ctx.sweep(4, commit=True)
+            assert info == 0 and np.all(np.isfinite(e))
+            out[mask] = (e, parts) + ctx.get_muvar()
+        for mask, res in out.items():
+            for a, b in zip(res, out[0]):
+                assert np.array_equal(a, b), mask
+        ctx.option('block_sched', 1)
+        ctx.set_muvar(mu0, var0)
+        e, parts, info = ctx.sweep(4, commit=True)
+        assert info == 0
+        np.testing.assert_allclose(e, out[0][0], rtol=1e-10)
+        np.testing.assert_allclose(ctx.get_muvar()[0], out[0][2], rtol=1e-7, atol=1e-9)
+    finally:
+        ctx.option('overlap', 31)
+        ctx.option('block_sched', 0)
+
+
 def test_cfg5_size_factorisation_against_lapack():
     """BASELINE config 5's matrix size (N=16384: 128 tiles, 2.1 GB per matrix, offsets beyond
     2^31 bytes) on one node + one weight GP.  No reference value exists at this size, so the
