@@ -1351,7 +1351,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // and operand latency, not its dispatch); default: one stream
     static int cs_env = -1;
     if (cs_env < 0) { const char* e = getenv("GPRN_CHAIN_STREAMS"); cs_env = e ? atoi(e) : 0; }
-    const bool persist = use_flags && chain_env == 2 && c->T > 1 && factor_probe_streams(c) == 1;
+    static int persist_max = -1;                   // GPRN_CHAIN2_MAX_BATCH (experiments): only for batches up to that
+    if (persist_max < 0) { const char* e = getenv("GPRN_CHAIN2_MAX_BATCH"); persist_max = e ? atoi(e) : 1 << 30; }
+    const bool persist = use_flags && chain_env == 2 && c->T > 1 && nbatch <= persist_max && factor_probe_streams(c) == 1;
     const bool two_streams = use_flags && !use_chain && (cs_env || persist) && factor_probe_streams(c) == 1;
     if (persist) {
         prof_begin(c, GPRN_T_DIAG, s0);

@@ -23,6 +23,9 @@ struct FillProgram {
 };
 
 #define PI_D 3.141592653589793
+#ifndef GPRN_FILL_SINPI
+#define GPRN_FILL_SINPI 1
+#endif
 
 __device__ __forceinline__ void harmonic_terms(double Nh, double P, double t, double& s, double& u)
 {
@@ -48,14 +51,16 @@ __device__ __forceinline__ double eval_kernel(int kid, const double* __restrict_
         const double inv = 1.0 / (q[1] * q[1]);
         return q[0] * q[0] * exp(-0.5 * (r * r) * inv);
     }
+    // (sin(pi |r| / P) as sinpi(|r| / P): the argument reduction of sinpi is a `fract`, that of sin on an argument of
+    // several hundred periods a multi-word product -- GPRN_FILL_SINPI=0 at build time keeps sin)
     case GPRN_K_PERIODIC: {
         const double w = PI_D / q[1], inv = 1.0 / (q[2] * q[2]);
-        const double s = sin(w * fabs(r));
+        const double s = GPRN_FILL_SINPI ? sinpi(fabs(r) * (1.0 / q[1])) : sin(w * fabs(r));
         return q[0] * q[0] * exp(-2 * (s * s) * inv);
     }
     case GPRN_K_QP: {
         const double w = PI_D / q[2], invp = 1.0 / (q[3] * q[3]), inve = 1.0 / (2 * (q[1] * q[1]));
-        const double s = sin(w * fabs(r));
+        const double s = GPRN_FILL_SINPI ? sinpi(fabs(r) * (1.0 / q[2])) : sin(w * fabs(r));
         const double per = -2 * (s * s) * invp;
         const double dec = (r * r) * inve;
         return q[0] * q[0] * exp(per - dec);
