@@ -634,6 +634,16 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // the block schedule's side launches (panel products with the block inverse, "next"): the same pad, so that every CU
     // keeps a diagonal-block kernel's worth of LDS and registers free whatever mix of them it runs
     if (c->pad_side_now && stream != c->stream) dyn = (size_t)kb * 1024;
+    // The next-panel part of an outer update ("first" / "next", K = 512 on the side streams) starts at a panel boundary,
+    // when the chain's next diagonal block is about to be dispatched: without a pad its workgroups fill every CU three
+    // deep and the block waits for a CU to drain (GPRN_PAD_NEXT_KB / GPRN_PAD_NEXT_SMALL_KB, KiB; -1: none)
+    static int pad_next_kb = -2, pad_next_small_kb = -2;
+    if (pad_next_kb == -2) { const char* e = getenv("GPRN_PAD_NEXT_KB"); pad_next_kb = e ? atoi(e) : -1; }
+    if (pad_next_small_kb == -2) { const char* e = getenv("GPRN_PAD_NEXT_SMALL_KB"); pad_next_small_kb = e ? atoi(e) : -1; }
+    if (tag == TG_NEXT && stream != c->stream) {
+        const int nk = nbatch <= pad_small_batch ? pad_next_small_kb : pad_next_kb;
+        if (nk >= 0) dyn = (size_t)nk * 1024;
+    }
     // The chain's own tile launches (one task: L_{k+1,k}, the B_{k+1,k+1} update) can ask for unused LDS too: with
     // enough of it they only land on CUs that run no bulk workgroup and are not slowed by MFMA-saturating
     // neighbours (GPRN_CHAIN_PAD_KB, experiments).
