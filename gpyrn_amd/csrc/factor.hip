@@ -926,7 +926,50 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
             s.nupd = v.size() - s.upd0;
         }
-        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        // ---- the same steps' updates in left-looking form (throughput set).  Step k, behind its panel products:
+        //   column k+1 of the panel:  B_{i,k+1} -= L[i, k0..k] L[k+1, k0..k]^T   (i >= k+3),  K = 128 (k + 1 - k0)
+        //   row k+1 of the inverse's right-hand side:  R_{k+1,c} (-)= L[k+1, ..k] X[..k, c]
+        //   the diagonal and sub-diagonal tiles to the right (this panel's and the next one's): column k alone, as before.
+        // Every in-panel tile is read and written once per panel instead of up to three times, with K up to 384 instead of
+        // 128 -- and the panel's columns are needed ONE PER STEP: the previous panel's K = 512 update of column k+1 has to be
+        // there at step k, not all of them at the panel's first step ("next" in groups: grp0 / ngrp below).
+        if (set == 0) {
+            if (c->lsteps.size() != (size_t)T) c->lsteps.assign(T, gprn_ctx::LStep{0, 0, 0});
+            for (int k = k0; k < k1; ++k) {
+                gprn_ctx::LStep& ls = c->lsteps[k];
+                ls.u0 = v.size();
+                const int jc = k + 1, kl = (k + 1 - k0) * GPRN_TILE;
+                auto is_crit = [&](int i, int j) { return i == k + 2 && (j == k + 1 || j == k + 2); };
+                // the band next to the diagonal -- (j,j), (j+1,j) -- stays right-looking, column k alone (K = 128) at every
+                // step, inside the panel as in the next one: the two tiles the chain's next step touches are among them, and
+                // with the whole panel's K they took three times as long at the panel's third step (107.6 vs 110.6 sweeps/s)
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int j = k + 1; j < std::min(T, k1 + outer); ++j)
+                        for (int i = j; i < std::min(T, j + 2); ++i) {
+                            if (i == k + 1 && j == k + 1) continue;            // the chain's own update of this step
+                            if (is_crit(i, j) != (pass == 0)) continue;
+                            v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                                 BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0, lower_diag && i == j)});
+                        }
+                    if (pass == 0) ls.ncrit = v.size() - ls.u0;
+                }
+                // below the band: column k+1 with all of the panel so far
+                if (jc < k1)
+                    for (int i = jc + 2; i < T; ++i)
+                        v.push_back(TileTask{toff(i, jc, ld), toff(i, k0, ld), toff(jc, k0, ld), kl,
+                                             BUF_B, BUF_B, BUF_B, tile_modes(CM_SUB, 0, 0)});
+                if (jc < k1) {
+                    for (int cc = 0; cc < k0; ++cc)
+                        v.push_back(TileTask{toff(jc, cc, ld), toff(jc, k0, ld), toff(k0, cc, ld), kl,
+                                             BUF_X, BUF_B, BUF_X, tile_modes(CM_SUB, 0, 1)});
+                    for (int cc = k0; cc <= k; ++cc)
+                        v.push_back(TileTask{toff(jc, cc, ld), toff(jc, cc, ld), toff(cc, cc, ld), (k + 1 - cc) * GPRN_TILE,
+                                             BUF_X, BUF_B, BUF_X, tile_modes(CM_SETNEG, 0, 1)});
+                }
+                ls.nu = v.size() - ls.u0;
+            }
+        }
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0}, {0}};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
         // pass 0 ("first"): the next panel's first column of B / first row of R -- what stream3's half of
@@ -964,7 +1007,25 @@ int ensure_tasks(gprn_ctx* c)
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
             if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
-            else if (pass == 1) { o.next0 = begin; o.nnext = v.size() - begin; }
+            else if (pass == 1) {
+                o.next0 = begin; o.nnext = v.size() - begin;
+                if (outer <= GPRN_OUTER) {
+                    // by the column of B / the row of R inside the next panel (the left-looking steps need them one per step);
+                    // the panel after next's diagonal and sub-diagonal tiles go with the first group
+                    auto grp = [&](const TileTask& t) {
+                        const int i = (int)(t.c_off / ((int64_t)GPRN_TILE * ld)), j = (int)((t.c_off % ld) / GPRN_TILE);
+                        const int g = t.c_buf == BUF_B ? (j < n1 ? j - k1 : 1) : i - k1;
+                        return std::min(std::max(g, 1), outer - 1);
+                    };
+                    std::stable_sort(v.begin() + begin, v.end(), [&](const TileTask& a, const TileTask& b) { return grp(a) < grp(b); });
+                    size_t at = begin;
+                    for (int g = 1; g < outer; ++g) {
+                        o.grp0[g] = at;
+                        while (at < v.size() && grp(v[at]) == g) ++at;
+                        o.ngrp[g] = at - o.grp0[g];
+                    }
+                }
+            }
             else {
                 // "rest" in two parts: A = what the NEXT panel's outer update writes again (the columns / rows of the
                 // panel after next, and of the one after that its diagonal and sub-diagonal tiles), B = the others.
@@ -1395,6 +1456,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         ft_fused = c->ft_s_phase && pend == nbatch && !use_chain && c->T > outer && small_shapes;
         if ((rc = vec_build_B(c, pend, s0, ft_fused ? 1 : 0, outer))) return rc;
     }
+    // GPRN_LEFT=1 (opt-in): the steps' updates in left-looking form below the diagonal band and the "next" part of an outer
+    // update in groups, one per column / row of the next panel (ensure_tasks); throughput set, default chain kernels.
+    // Bit-identical results (the same additions in the same order); measured equal to the right-looking form: 110.3-110.6
+    // vs 110.4-111.0 sweeps/s at config 3, 59.8-60.6 vs 59.3-60.4 at config 4 (with the band left-looking too: 107.6)
+    static int left_env = -1;
+    if (left_env < 0) { const char* e = getenv("GPRN_LEFT"); left_env = e ? atoi(e) : 0; }
+    const bool left = left_env && set == 0 && !use_chain && !persist && c->lsteps.size() == (size_t)c->T;
+    std::vector<char> grp_pending(c->T + 1, 0);    // [tile column]: its group of "next" is still to be waited for by stream3
+    int last_grp = -1;
     int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
@@ -1424,9 +1494,18 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         if (o.nfirst > 0) first_J = (int)J;
         HIP_TRY(c, await(sn, (int)J, F_PANEL));
         if (sr && rest_J >= 0) HIP_TRY(c, await(sn, rest_J, F_RESTA));
+        if (left) {
+            for (int g = 1; g < o.k1 - o.k0 && o.k1 + g < c->T; ++g) {
+                if ((rc = tiles(o.grp0[g], o.ngrp[g], sn, shape_upd(o.ngrp[g]), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+                HIP_TRY(c, raise(sn, o.k1 + g, F_NEXT));
+                grp_pending[o.k1 + g] = 1;
+                last_grp = o.k1 + g;
+            }
+        } else {
         if ((rc = tiles(o.next0, o.nnext, sn, shape_upd(o.nnext), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, raise(sn, (int)J, F_NEXT));
         if (o.nnext > 0) next_J = (int)J;
+        }
         if (o.nrest) {
             // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
             // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
@@ -1572,6 +1651,27 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // step on stream3, itself a serial chain of launches: slower, 95.7 vs 103.2 sweeps/s in round 2).
             static int split_inner = -1;
             if (split_inner < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner = e ? atoi(e) : 1; }
+            if (left) {
+                // left-looking: column k+1 of the panel (and row k+1 of the right-hand side) with everything the panel has
+                // produced so far; the previous panel's K = 512 update of THAT column / row is all that has to be there
+                const gprn_ctx::LStep& ls = c->lsteps[k];
+                const bool wait_grp = k + 1 < c->T && grp_pending[k + 1];
+                static int split_inner_l = -1, split_max_l = -1;
+                if (split_inner_l < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner_l = e ? atoi(e) : 1; }
+                if (split_max_l < 0) { const char* e = getenv("GPRN_SPLIT_INNER_MAX_BATCH"); split_max_l = e ? atoi(e) : 2; }
+                if (use_flags && ls.ncrit > 0 && (split_inner_l >= 2 || (split_inner_l == 1 && wait_grp && k == o.k0 && nbatch <= split_max_l))) {
+                    const bool skip = withheld(F_INNER);
+                    if ((rc = tiles(ls.u0, ls.ncrit, s1, TS_64x64, GPRN_T_PANEL, skip ? nosig : in_kernel(k, F_INNER)))) return rc;
+                    if (wait_grp) { HIP_TRY(c, await(s1, k + 1, F_NEXT)); grp_pending[k + 1] = 0; }
+                    if ((rc = tiles(ls.u0 + ls.ncrit, ls.nu - ls.ncrit, s1, shape_upd(ls.nu - ls.ncrit)))) return rc;
+                } else {
+                    if (wait_grp) { HIP_TRY(c, await(s1, k + 1, F_NEXT)); grp_pending[k + 1] = 0; }
+                    if ((rc = tiles(ls.u0, ls.nu, s1, shape_upd(ls.nu)))) return rc;
+                    if (use_flags) inner_k = k;
+                    else HIP_TRY(c, raise(s1, k, F_INNER));
+                }
+                continue;
+            }
             const size_t ncrit = s.ncol1 > 0 ? s.ncol1 - 1 : 0;
             const bool boundary = next_J >= 0;             // this step's other updates wait for an outer update
             // (at panel boundaries only where the chain bounds the phase: one or two matrices -- config 2: +3 %; with six
@@ -1601,6 +1701,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;
     if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
+    if (left && last_grp >= 0) HIP_TRY(c, await(s0, last_grp, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
     if (tail_on_s2) {
         HIP_TRY(c, raise(s2, 0, F_TAIL));

@@ -256,7 +256,12 @@ struct gprn_ctx {
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
-    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA; };  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
+    // left-looking form of a step's updates (throughput set only; ensure_tasks): column k+1 of the panel with everything
+    // the panel has produced so far (K = 128 (k + 1 - k0)) instead of every remaining column with column k alone
+    struct LStep { size_t u0, nu, ncrit; };
+    std::vector<LStep> lsteps;
+    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA;
+                        size_t grp0[GPRN_OUTER], ngrp[GPRN_OUTER]; };   // "next" by column / row of the next panel (1 .. GPRN_OUTER - 1)  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
