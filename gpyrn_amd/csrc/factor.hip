@@ -634,12 +634,15 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
     CHAIN_PRIO();
+    if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
     await_flag(wait_flag, wait_value, wait_timed_out);
+    if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
     diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
+    if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
 }
 
@@ -669,6 +672,7 @@ int launch_diag_q(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, in
 {
     prof_begin(c, GPRN_T_DIAG, stream);
     PtrArgs pa;
+    pa.stamps = nullptr;
     if (tab_rows(c, d_ptrs, nbatch, &pa))
         hipLaunchKernelGGL(k_diag_block_q<true>, dim3(nbatch), dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info, q, op);
     else
@@ -813,12 +817,22 @@ void k_diag_chain(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int T, i
     }
 }
 
+// GPRN_STEP_STAMPS: where chain kernel `which` (0 diag, 1 L, 2 U) of tile step k of the running factorisation puts its
+// three clock stamps, or null
+unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which)
+{
+    if (!c->d_step_stamps || c->step_stamps_n < 1 || k >= c->step_stamps_T) return nullptr;
+    const int ph = (c->step_stamps_n - 1) & 7;
+    return c->d_step_stamps + (((size_t)ph * c->step_stamps_T + k) * 3 + which) * 3;
+}
+
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
                 Signal sig, Await aw)
 {
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
     PtrArgs pa;
+    pa.stamps = nullptr;
     // Little work in total (batch x tiles <= GPRN_DIAG_PAD_MAX, the latency schedule's problems): most CUs are idle, and
     // with GPRN_DIAG_PAD_KB of unused dynamic LDS (default: all a workgroup may have) the workgroup only lands on a CU
     // that runs nothing else which uses LDS -- no co-resident MFMA waves of the side stream's tile kernels on its SIMDs.
@@ -830,6 +844,7 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     size_t dyn = 0;
     if (diag_pad_kb > 0 && nbatch * c->T <= diag_pad_max)
         dyn = std::min<size_t>((size_t)diag_pad_kb * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
+    pa.stamps = step_stamp_ptr(c, kblk, 0);
     if (tab_rows(c, d_ptrs, nbatch, &pa))
         hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
                            d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
@@ -969,7 +984,7 @@ int ensure_tasks(gprn_ctx* c)
                 ls.nu = v.size() - ls.u0;
             }
         }
-        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0}, {0}};
+        gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0}, {0}, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
         // pass 0 ("first"): the next panel's first column of B / first row of R -- what stream3's half of
@@ -1006,7 +1021,40 @@ int ensure_tasks(gprn_ctx* c)
                                          (k1 - cc) * GPRN_TILE, BUF_X, BUF_B, BUF_X,
                                          tile_modes(CM_SETNEG, 0, 1)});
             }
-            if (pass == 0) { o.first0 = begin; o.nfirst = v.size() - begin; }
+            if (pass == 0) {
+                o.first0 = begin; o.nfirst = v.size() - begin;
+                // The same update in two parts (factor_invert_split, GPRN_SPLIT_FIRST): what the panel's columns but the
+                // last contribute -- everything it needs exists once the panel's last-but-one step has its panel products,
+                // and stream3 has nothing to do while the last diagonal block runs -- and the last column's share (K = 128),
+                // all that is left at the panel boundary, where the chain's next step waits for it.  The additions keep their
+                // order (k ascending), so the result is the same to the last bit.
+                if (k1 - k0 >= 2 && o.nfirst > 0) {
+                    const size_t nf = o.nfirst;
+                    const int ka = (k1 - 1 - k0) * GPRN_TILE;                 // K of part a
+                    o.fa0 = v.size();
+                    for (size_t t = 0; t < nf; ++t) {
+                        TileTask a = v[o.first0 + t];
+                        const int cm = a.modes & 3;
+                        if (cm == CM_SUB) a.klen = ka;                      // operands start at the panel's first column
+                        else a.klen -= GPRN_TILE;                           // first touch of R_ic: columns c .. k1-2 (none for c = k1-1)
+                        if (a.klen > 0) v.push_back(a);
+                    }
+                    o.nfa = v.size() - o.fa0;
+                    o.fb0 = v.size();
+                    for (size_t t = 0; t < nf; ++t) {
+                        TileTask b = v[o.first0 + t];
+                        const int cm = b.modes & 3;
+                        const bool touched = cm == CM_SUB || b.klen > GPRN_TILE;     // part a has written the tile
+                        const int64_t skip = cm == CM_SUB ? ka : b.klen - GPRN_TILE; // K already done
+                        b.a_off += skip;                                              // a_mode 0: k contiguous
+                        b.b_off += ((b.modes >> 3) & 1) ? (int64_t)skip * ld : skip;  // b_mode 1: k along rows
+                        b.klen = GPRN_TILE;
+                        if (touched) b.modes = (uint8_t)((b.modes & ~(3 | 32)) | CM_SUB);
+                        v.push_back(b);
+                    }
+                    o.nfb = v.size() - o.fb0;
+                }
+            }
             else if (pass == 1) {
                 o.next0 = begin; o.nnext = v.size() - begin;
                 if (outer <= GPRN_OUTER) {
@@ -1419,6 +1467,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (persist) {
         prof_begin(c, GPRN_T_DIAG, s0);
         PtrArgs pa;
+    pa.stamps = nullptr;
         // GPRN_DIAG_EXCL_KB (experiments): unused dynamic LDS on top of the kernel's 46.6 KB -- with enough of it no
         // other workgroup that uses LDS shares the persistent workgroup's CU (no co-resident MFMA waves on its SIMDs)
         static int excl_kb = -1;
@@ -1465,6 +1514,18 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     const bool left = left_env && set == 0 && !use_chain && !persist && c->lsteps.size() == (size_t)c->T;
     std::vector<char> grp_pending(c->T + 1, 0);    // [tile column]: its group of "next" is still to be waited for by stream3
     int last_grp = -1;
+    static int split_rest = -1;
+    if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
+    const bool sr_all = split_rest && c->stream4 && !two_streams && (split_rest >= 2 || c->T <= 64);
+    // GPRN_SPLIT_FIRST=1 (opt-in): the "first" part of a panel's outer update in two launches (ensure_tasks fa0 / fb0): the
+    // share of the panel's columns but the last goes out behind the last-but-one step's updates, while the last diagonal
+    // block of the panel runs and stream3 would idle; at the boundary only the last column's share (K = 128) is left.
+    // Bit-identical; slower: 108.6 vs 110.5 sweeps/s at config 3, 58.2 vs 59.3 at config 4 -- the in-kernel stamps
+    // (GPRN_STEP_STAMPS) show the chain's wait at a panel's second step unchanged (35-65 us with two matrices) and a new
+    // one at its first: what the chain waits for there is not the "first" launch
+    static int split_first = -1;
+    if (split_first < 0) { const char* e = getenv("GPRN_SPLIT_FIRST"); split_first = e ? atoi(e) : 0; }
+    int first_a_done = -1;
     int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
@@ -1478,18 +1539,18 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // GPRN_SPLIT_REST=1 (default): the previous panel's "rest" went out as two launches and only the first (A: the
         // tiles this panel's outer update writes again) is waited for here; "next" runs on a stream of its own instead
         // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
-        static int split_rest = -1;
-        if (split_rest < 0) { const char* e = getenv("GPRN_SPLIT_REST"); split_rest = e ? atoi(e) : 1; }
         // (measured +2.1 % sweeps/s at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to
         // 64 tile steps by default, GPRN_SPLIT_REST=2 forces it)
-        const bool sr = split_rest && c->stream4 && !two_streams && (split_rest >= 2 || c->T <= 64);
+        const bool sr = sr_all;
         hipStream_t sn = sr ? c->stream4 : s2;
         if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
         if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
         // the first panel's update forms the tiles of B it touches from K (run_phase built only the others)
         struct FtScope { gprn_ctx* c; ~FtScope() { c->ft_s_now = nullptr; } } ft_scope{c};
         c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
-        if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        if (first_a_done == (int)J) {
+            if ((rc = tiles(o.fb0, o.nfb, s1, shape_upd(o.nfb), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        } else if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         HIP_TRY(c, raise(s1, (int)J, F_FIRST));
         if (o.nfirst > 0) first_J = (int)J;
         HIP_TRY(c, await(sn, (int)J, F_PANEL));
@@ -1532,6 +1593,21 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             c->rows_done = o.k1;
             tail_on_s2 = true;
         }
+        return GPRN_OK;
+    };
+    // behind the updates of the panel's last-but-one step: the early part of the panel's "first" outer update
+    auto after_inner = [&](size_t J, int k) -> int {
+        const gprn_ctx::OuterRange& o = c->outers[set][J];
+        if (!split_first || use_chain || persist || k != o.k1 - 2 || o.nfa == 0 || o.nfirst == 0) return GPRN_OK;
+        int r;
+        if ((r = flush_inner())) return r;             // the chain's flag first: the launch below takes a while
+        if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr_all ? F_RESTA : F_REST));   // same tiles as the previous panel's rest
+        if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+        c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
+        r = tiles(o.fa0, o.nfa, s1, shape_upd(o.nfa), GPRN_T_PANEL, nosig, noaw, TG_NEXT);
+        c->ft_s_now = nullptr;
+        if (r) return r;
+        first_a_done = (int)J;
         return GPRN_OK;
     };
     for (size_t J = 0; J < c->outers[set].size(); ++J) {
@@ -1670,6 +1746,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                     if (use_flags) inner_k = k;
                     else HIP_TRY(c, raise(s1, k, F_INNER));
                 }
+                if ((rc = after_inner(J, k))) return rc;
                 continue;
             }
             const size_t ncrit = s.ncol1 > 0 ? s.ncol1 - 1 : 0;
@@ -1690,6 +1767,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
                                                            // chain's wait for step k is enqueued at step k + 1
             }
+            if ((rc = after_inner(J, k))) return rc;
         }
         if ((rc = flush_inner())) return rc;           // the chain's next step must not queue behind the outer update
         if (o.nfirst + o.nnext + o.nrest == 0) continue;
@@ -1901,6 +1979,34 @@ int factor_check_waits(gprn_ctx* c)
                         sum[5] / n, sum[6] / n + sum[7] / n);
         }
     }
+    if (c->d_step_stamps && c->step_stamps_n > 0) {            // development aid: the last factorisations' chains as they ran
+        const int T = c->step_stamps_T, nph = std::min(c->step_stamps_n, 8);
+        std::vector<unsigned long long> h((size_t)8 * T * 9);
+        if (hipMemcpy(h.data(), c->d_step_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int back = std::min(nph, 2); back >= 1; --back) {
+                const int ph = (c->step_stamps_n - back) & 7;
+                const unsigned long long* p = h.data() + (size_t)ph * T * 9;
+                if (!p[0]) continue;
+                fprintf(stderr, "[gprn] chain of factorisation %d (batch %d), us: step | diag: ->start run | L: ->launch wait run | U: ->launch run | step total\n",
+                        c->step_stamps_n - back, c->step_stamps_batch[ph]);
+                unsigned long long prev_end = p[0];
+                for (int k = 0; k < c->T; ++k) {
+                    const unsigned long long* d = p + (size_t)k * 9;
+                    const unsigned long long* l = d + 3;
+                    const unsigned long long* u = d + 6;
+                    if (!d[0]) break;
+                    auto us = [](unsigned long long a, unsigned long long b) { return b >= a ? (double)(b - a) * 0.01 : -1.0; };
+                    if (l[0] && u[0])
+                        fprintf(stderr, "  %3d | %6.1f %6.1f | %6.1f %6.1f %6.1f | %6.1f %6.1f | %7.1f\n", k, us(prev_end, d[0]), us(d[0], d[2]),
+                                us(d[2], l[0]), us(l[0], l[1]), us(l[1], l[2]), us(l[2], u[0]), us(u[0], u[2]), us(prev_end, u[2]));
+                    else
+                        fprintf(stderr, "  %3d | %6.1f %6.1f |\n", k, us(prev_end, d[0]), us(d[0], d[2]));
+                    prev_end = u[0] ? u[2] : d[2];
+                }
+            }
+        }
+        c->step_stamps_n = 0;
+    }
     {
         const int rq = queue_check_waits(c);
         if (rq) return rq;
@@ -1941,6 +2047,20 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (rc) return rc;
     static int lat_max = 0;                        // GPRN_LAT_MAX overrides (experiments)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
+    static int step_stamps_env = -1;
+    if (step_stamps_env < 0) { const char* e = getenv("GPRN_STEP_STAMPS"); step_stamps_env = e ? atoi(e) : 0; }
+    if (step_stamps_env) {
+        if (c->step_stamps_T < c->T) {
+            if (c->d_step_stamps) hipFree(c->d_step_stamps);
+            HIP_TRY(c, hipMalloc(&c->d_step_stamps, (size_t)8 * c->T * 9 * sizeof(unsigned long long)));
+            c->step_stamps_T = c->T;
+            c->step_stamps_n = 0;
+        }
+        c->step_stamps_n += 1;
+        const int ph = (c->step_stamps_n - 1) & 7;
+        c->step_stamps_batch[ph] = nbatch;
+        HIP_TRY(c, hipMemsetAsync(c->d_step_stamps + (size_t)ph * c->step_stamps_T * 9, 0, (size_t)c->step_stamps_T * 9 * sizeof(unsigned long long), c->stream));
+    }
     if (!(split_sched() && !(queue_enabled(c) && c->T > 1))) c->rows_final = nullptr;   // only the launch schedule calls it
     // B still to be built (run_phase): the launch schedule builds what its first panel touches and forms the rest inside
     // that panel's update (factor_invert_split); every other schedule gets all of it now

@@ -222,8 +222,11 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     RW_STAMP(0);
     CHAIN_PRIO();
     const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const bool st = !QUEUE && pa.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
@@ -269,7 +272,10 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         q_complete(q, blockIdx.y, qop, false);
         if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
             q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
-    } else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    } else {
+        if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
+        signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    }
     RW_STAMP(6);
 }
 
@@ -348,8 +354,11 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     RW_STAMP(0);
     CHAIN_PRIO();
     const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const bool st = !QUEUE && pa.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0;
+    if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
     if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
     else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     int P = 0;
@@ -386,7 +395,10 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         q_complete(q, blockIdx.y, qop, false);
         if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
             q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
-    } else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    } else {
+        if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
+        signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    }
     RW_STAMP(6);
 }
 
@@ -463,6 +475,7 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
     prof_begin(c, fam, stream);
     double* const* tab = (double* const*)d_ptrs;
     PtrArgs pa;
+    pa.stamps = step_stamp_ptr(c, k, mode == 0 ? 1 : 2);
     const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
     unsigned* const tmo = aw.timed_out ? aw.timed_out : sig.timed_out;
     QueueCtl noq;
@@ -491,6 +504,7 @@ int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, 
     prof_begin(c, GPRN_T_PANEL, stream);
     double* const* tab = (double* const*)d_ptrs;
     PtrArgs pa;
+    pa.stamps = nullptr;
     const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
     const unsigned* const nf = nullptr;
     unsigned* const ns = nullptr;

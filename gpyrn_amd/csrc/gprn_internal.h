@@ -235,6 +235,12 @@ struct gprn_ctx {
     // enqueued by the next factor_invert right behind the start of its persistent chain kernel (factor.hip)
     std::function<int()> chain_started;
     unsigned long long* d_stamps = nullptr;   // GPRN_CHAIN_STAMPS: clock stamps of the chain kernel (probes)
+    // GPRN_STEP_STAMPS=1 (probes): per tile step and chain kernel (diag, L, U) the 100 MHz clock at its start, after its
+    // wait and at its end -- the launch schedule's chain as it really ran (a kernel trace slows the chain's small
+    // kernels by 15 %); [phase slot][T][3 kernels][3 stamps], printed by factor_check_waits
+    unsigned long long* d_step_stamps = nullptr;
+    int step_stamps_T = 0, step_stamps_n = 0;
+    int step_stamps_batch[8] = {0};
     int stamps_T = 0;
     size_t tasks_cap = 0;
     // dataflow schedule (queue.hip): one plan per (T, set), device buffers grown on demand
@@ -261,7 +267,8 @@ struct gprn_ctx {
     struct LStep { size_t u0, nu, ncrit; };
     std::vector<LStep> lsteps;
     struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA;
-                        size_t grp0[GPRN_OUTER], ngrp[GPRN_OUTER]; };   // "next" by column / row of the next panel (1 .. GPRN_OUTER - 1)  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
+                        size_t grp0[GPRN_OUTER], ngrp[GPRN_OUTER];
+                        size_t fa0, nfa, fb0, nfb; };   // "first" in two parts: all but the panel's last column (early), the last column   // "next" by column / row of the next panel (1 .. GPRN_OUTER - 1)  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
@@ -346,11 +353,13 @@ int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doubl
 int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld, hipStream_t stream);
 // BUF_B and BUF_X of up to GPRN_ARG_SLOTS matrices as a kernel argument
 #define GPRN_ARG_SLOTS 16
-struct PtrArgs { double* p[GPRN_ARG_SLOTS][2]; };
+struct PtrArgs { double* p[GPRN_ARG_SLOTS][2];
+                 unsigned long long* stamps; };   // GPRN_STEP_STAMPS: 100 MHz clock stamps of this launch (3 words), or null
 void tab_note(gprn_ctx* c, double** d_tab, double* const* rows, size_t count);
 void tab_forget(gprn_ctx* c, double** d_tab);                    // d_tab null: all of them
 // rows of `nbatch` matrices starting at d_ptrs if a host copy is known (and nbatch fits), else false
 bool tab_rows(gprn_ctx* c, double** d_ptrs, int nbatch, PtrArgs* out);
+unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which);   // GPRN_STEP_STAMPS (factor.hip)
 
 // the chain's two products of a tile step at 16 x 16 granularity (gemm_tile.hip); mode 0: L_{k+1,k} in place, 1: the
 // update of B_{k+1,k+1}
