@@ -817,6 +817,10 @@ void k_diag_chain(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int T, i
     }
 }
 
+// GPRN_STEP_STAMPS=2: a one-thread kernel between stream3's launches of a tile step writes the clock too (it costs the
+// stream 3-4 us each: a probe of where stream3's time goes, not of how long the step takes)
+__global__ void k_stamp(unsigned long long* at) { if (threadIdx.x == 0) *at = __builtin_amdgcn_s_memrealtime(); }
+
 // GPRN_STEP_STAMPS: where chain kernel `which` (0 diag, 1 L, 2 U) of tile step k of the running factorisation puts its
 // three clock stamps, or null
 unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which)
@@ -1347,6 +1351,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     // their flag themselves (Signal), so nothing at all sits between the chain's three dependent
     // launches.  Flags only grow: a call waits for its own epoch.  GPRN_FLAGS=0: events.
     const int use_flags = factor_use_flags(c);
+    auto side_stamp = [&](int k, int i) {          // GPRN_STEP_STAMPS=2: the clock on stream3 at this point of step k
+        if (c->side_stamps) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s1, c->side_stamps + (size_t)k * 8 + i);
+    };
     enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_U, F_RESTA, F_TAIL, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits reads the word behind T * GPRN_FLAG_KINDS flag pairs");
     if (use_flags && c->sig_T < c->T) {
@@ -1548,12 +1555,22 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // the first panel's update forms the tiles of B it touches from K (run_phase built only the others)
         struct FtScope { gprn_ctx* c; ~FtScope() { c->ft_s_now = nullptr; } } ft_scope{c};
         c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
+        if (o.k1 < c->T) side_stamp(o.k1, 6);          // (stamps of the NEXT panel's first step: behind the waits, behind "first")
         if (first_a_done == (int)J) {
             if ((rc = tiles(o.fb0, o.nfb, s1, shape_upd(o.nfb), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         } else if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
+        if (o.k1 < c->T) side_stamp(o.k1, 7);
         HIP_TRY(c, raise(s1, (int)J, F_FIRST));
         if (o.nfirst > 0) first_J = (int)J;
-        HIP_TRY(c, await(sn, (int)J, F_PANEL));
+        // GPRN_FIRST_ALONE=n (experiments; default 0): with up to n matrices "next", "ahead" and "bulk" start behind "first"
+        // instead of beside it.  stream3 cannot go on with the new panel before "first" is through -- the in-kernel stamps
+        // (GPRN_STEP_STAMPS=2) show it there for 90-100 us with two matrices, the other launches taking the CUs at the same
+        // moment -- and alone it takes 30-45 us; but the same launches then slow the panel products of the step behind it
+        // (60 us instead of 30): 110.6 sweeps/s at config 3 either way
+        static int first_alone = -1;
+        if (first_alone < 0) { const char* e = getenv("GPRN_FIRST_ALONE"); first_alone = e ? atoi(e) : 0; }
+        const int gate_kind = (use_flags && o.nfirst > 0 && nbatch <= first_alone) ? F_FIRST : F_PANEL;
+        HIP_TRY(c, await(sn, (int)J, gate_kind));
         if (sr && rest_J >= 0) HIP_TRY(c, await(sn, rest_J, F_RESTA));
         if (left) {
             for (int g = 1; g < o.k1 - o.k0 && o.k1 + g < c->T; ++g) {
@@ -1577,7 +1594,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if (bulk_big_batch < 0) { const char* e = getenv("GPRN_BULK_BIG_BATCH"); bulk_big_batch = e ? atoi(e) : 4; }
             const int bulk_shape = nbatch >= bulk_big_batch ? bulk_shape_big : bulk_shape_small;
             if (sr) {
-                HIP_TRY(c, await(s2, (int)J, F_PANEL));
+                HIP_TRY(c, await(s2, (int)J, gate_kind));
                 if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
                 HIP_TRY(c, raise(s2, (int)J, F_RESTA));
                 if ((rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
@@ -1697,7 +1714,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             } else if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
             if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;    // the previous panel's trailing update
             // beside it: the rest of the panel, then the rest of the in-panel updates
+            side_stamp(k, 0);
             if ((rc = side_sync(k))) return rc;
+            side_stamp(k, 1);
             // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
             static int merge_panel = -1;
             if (merge_panel < 0) { const char* e = getenv("GPRN_MERGE_PANEL"); merge_panel = e ? atoi(e) : 1; }
@@ -1725,6 +1744,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // read (profiles/r02_chain_timeline_cfg3.txt; the dataflow schedule of queue.hip made the false dependency
             // visible).  GPRN_SPLIT_INNER: 0 never, 1 (default) at panel boundaries, 2 at every step (one more launch per
             // step on stream3, itself a serial chain of launches: slower, 95.7 vs 103.2 sweeps/s in round 2).
+            side_stamp(k, 2);                              // behind the panel
             static int split_inner = -1;
             if (split_inner < 0) { const char* e = getenv("GPRN_SPLIT_INNER"); split_inner = e ? atoi(e) : 1; }
             if (left) {
@@ -1758,11 +1778,16 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if (use_flags && ncrit > 0 && (split_inner >= 2 || (split_inner == 1 && boundary && nbatch <= split_max_batch))) {
                 const bool skip = withheld(F_INNER);
                 if ((rc = tiles(s.upd0 + 1, ncrit, s1, TS_64x64, GPRN_T_PANEL, skip ? nosig : in_kernel(k, F_INNER)))) return rc;
+                side_stamp(k, 3);
                 if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+                side_stamp(k, 4);
                 if ((rc = tiles(s.upd0 + 1 + ncrit, s.nupd - 1 - ncrit, s1, shape_upd(s.nupd - 1 - ncrit)))) return rc;
+                side_stamp(k, 5);
             } else {
                 if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+                side_stamp(k, 4);
                 if ((rc = tiles(s.upd0 + 1, s.nupd - 1, s1, shape_upd(s.nupd - 1)))) return rc;
+                side_stamp(k, 5);
                 if (use_flags) inner_k = k;                // raised by stream3's next synchronisation kernel
                 else HIP_TRY(c, raise(s1, k, F_INNER));    // an event wait sees only records made before it: the
                                                            // chain's wait for step k is enqueued at step k + 1
@@ -1981,7 +2006,11 @@ int factor_check_waits(gprn_ctx* c)
     }
     if (c->d_step_stamps && c->step_stamps_n > 0) {            // development aid: the last factorisations' chains as they ran
         const int T = c->step_stamps_T, nph = std::min(c->step_stamps_n, 8);
-        std::vector<unsigned long long> h((size_t)8 * T * 9);
+        std::vector<unsigned long long> h((size_t)8 * T * 9), side;
+        if (c->d_side_stamps) {
+            side.resize((size_t)T * 8);
+            if (hipMemcpy(side.data(), c->d_side_stamps, side.size() * sizeof(side[0]), hipMemcpyDeviceToHost) != hipSuccess) side.clear();
+        }
         if (hipMemcpy(h.data(), c->d_step_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int back = std::min(nph, 2); back >= 1; --back) {
                 const int ph = (c->step_stamps_n - back) & 7;
@@ -1996,9 +2025,20 @@ int factor_check_waits(gprn_ctx* c)
                     const unsigned long long* u = d + 6;
                     if (!d[0]) break;
                     auto us = [](unsigned long long a, unsigned long long b) { return b >= a ? (double)(b - a) * 0.01 : -1.0; };
-                    if (l[0] && u[0])
-                        fprintf(stderr, "  %3d | %6.1f %6.1f | %6.1f %6.1f %6.1f | %6.1f %6.1f | %7.1f\n", k, us(prev_end, d[0]), us(d[0], d[2]),
+                    if (l[0] && u[0]) {
+                        fprintf(stderr, "  %3d | %6.1f %6.1f | %6.1f %6.1f %6.1f | %6.1f %6.1f | %7.1f", k, us(prev_end, d[0]), us(d[0], d[2]),
                                 us(d[2], l[0]), us(l[0], l[1]), us(l[1], l[2]), us(l[2], u[0]), us(u[0], u[2]), us(prev_end, u[2]));
+                        if (c->d_side_stamps && ph == c->side_stamps_ph && side.size()) {
+                            // stream3, relative to the END of this step's diagonal block: before its synchronisation kernel,
+                            // behind it, behind the panel, behind the chain's two tiles, behind the other updates
+                            const unsigned long long* sd = side.data() + (size_t)k * 8;
+                            fprintf(stderr, "   s3:");
+                            for (int i = 0; i < 8; ++i)
+                                if (sd[i]) fprintf(stderr, " %7.1f", sd[i] >= d[2] ? (double)(sd[i] - d[2]) * 0.01 : -(double)(d[2] - sd[i]) * 0.01);
+                                else fprintf(stderr, "       -");
+                        }
+                        fprintf(stderr, "\n");
+                    }
                     else
                         fprintf(stderr, "  %3d | %6.1f %6.1f |\n", k, us(prev_end, d[0]), us(d[0], d[2]));
                     prev_end = u[0] ? u[2] : d[2];
@@ -2049,9 +2089,13 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
     if (!lat_max) { const char* e = getenv("GPRN_LAT_MAX"); lat_max = e && atoi(e) > 0 ? atoi(e) : 32; }
     static int step_stamps_env = -1;
     if (step_stamps_env < 0) { const char* e = getenv("GPRN_STEP_STAMPS"); step_stamps_env = e ? atoi(e) : 0; }
+    c->side_stamps = nullptr;
     if (step_stamps_env) {
         if (c->step_stamps_T < c->T) {
             if (c->d_step_stamps) hipFree(c->d_step_stamps);
+            if (c->d_side_stamps) hipFree(c->d_side_stamps);
+            c->d_side_stamps = nullptr;
+            HIP_TRY(c, hipMalloc(&c->d_side_stamps, (size_t)c->T * 8 * sizeof(unsigned long long)));
             HIP_TRY(c, hipMalloc(&c->d_step_stamps, (size_t)8 * c->T * 9 * sizeof(unsigned long long)));
             c->step_stamps_T = c->T;
             c->step_stamps_n = 0;
@@ -2060,6 +2104,11 @@ static int factor_invert_impl(gprn_ctx* c, int nbatch)
         const int ph = (c->step_stamps_n - 1) & 7;
         c->step_stamps_batch[ph] = nbatch;
         HIP_TRY(c, hipMemsetAsync(c->d_step_stamps + (size_t)ph * c->step_stamps_T * 9, 0, (size_t)c->step_stamps_T * 9 * sizeof(unsigned long long), c->stream));
+        if (step_stamps_env >= 2 && nbatch <= 2) {       // (the node phase: the one the chain bounds)
+            HIP_TRY(c, hipMemsetAsync(c->d_side_stamps, 0, (size_t)c->step_stamps_T * 8 * sizeof(unsigned long long), c->stream));
+            c->side_stamps = c->d_side_stamps;
+            c->side_stamps_ph = ph;
+        }
     }
     if (!(split_sched() && !(queue_enabled(c) && c->T > 1))) c->rows_final = nullptr;   // only the launch schedule calls it
     // B still to be built (run_phase): the launch schedule builds what its first panel touches and forms the rest inside

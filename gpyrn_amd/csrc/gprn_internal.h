@@ -241,6 +241,8 @@ struct gprn_ctx {
     unsigned long long* d_step_stamps = nullptr;
     int step_stamps_T = 0, step_stamps_n = 0;
     int step_stamps_batch[8] = {0};
+    unsigned long long *d_side_stamps = nullptr, *side_stamps = nullptr;   // GPRN_STEP_STAMPS=2: stream3's clock, [T][8]
+    int side_stamps_ph = -1;
     int stamps_T = 0;
     size_t tasks_cap = 0;
     // dataflow schedule (queue.hip): one plan per (T, set), device buffers grown on demand
