@@ -11,6 +11,10 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
+#ifndef GPRN_DEEP_PREFETCH
+#define GPRN_DEEP_PREFETCH 1
+#endif
+
 // Staging geometry.  A thread moves R*8/NT 16-byte pieces of an operand chunk (R rows x 16 k); piece `it`
 // differs from piece 0 by +64 rows (only when the lanes cover 64 of 128 rows) and/or +8 k in BOTH memory
 // layouts, so one lane offset serves all pieces: memory address = base + lane offset + a uniform per-piece
@@ -112,8 +116,16 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     v4d acc[MI][NI];
 
     const int nchunks = klen / GPRN_KC;
+    // DEEP (64 x 64 on four waves): global loads THREE chunks ahead through two register sets (set A holds odd chunks, B
+    // even ones from chunk 2 on) instead of two chunks ahead through one.  PMC over the bulk launches: a wave spends 60 %
+    // of its cycles at a wait, a third of the L2 requests miss, and with two or three waves per SIMD that leaves the
+    // matrix pipes idle a third of the time -- one chunk period (16 MFMAs per wave) is not enough to cover an L2 miss.
+    // (GPRN_DEEP_PREFETCH=2: the 4-wave 64 x 128 / 128 x 64 forms too, i.e. the panel products)
+    constexpr bool DEEP = !SYRK && WM == 2 && WN == 2 &&
+                          ((GPRN_DEEP_PREFETCH >= 1 && BM == 64 && BN == 64) || (GPRN_DEEP_PREFETCH >= 2 && BM * BN == 64 * 128));
     v2d ra[A_IT], rb[B_IT];
-    auto load_chunk = [&]() {
+    v2d ra2[DEEP ? A_IT : 1], rb2[DEEP ? B_IT : 1];
+    auto load_chunk = [&](v2d (&ra)[A_IT], v2d (&rb)[B_IT]) {
         // raw buffer resources over the chunk's base: 48-bit address, no stride, no bounds (num_records max)
         const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7fffffff, 0x00020000);
@@ -128,7 +140,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
             rb[it] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, b_g, so, 0));
         }
     };
-    auto write_chunk = [&](int stage_bytes) {
+    auto write_chunk = [&](int stage_bytes, const v2d (&ra)[A_IT], const v2d (&rb)[B_IT]) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int imm = stage_bytes + (A_ROWS2 ? (it & 1) * 64 * 8 + (it >> 1) * 8 * PA * 8 : it * 8 * PA * 8);
@@ -143,7 +155,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
         }
     };
 
-    load_chunk();
+    load_chunk(ra, rb);
     // The C tile is requested AFTER the first operand chunk: memory returns in order, so the
     // LDS staging below waits only for the chunk, and the first MFMA of each accumulator only for
     // its own four values -- most of the tile streams in behind the first MFMAs.
@@ -183,9 +195,13 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
             for (int j = 0; j < NI; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
     }
     __builtin_amdgcn_sched_barrier(0);
-    write_chunk(0);
+    write_chunk(0, ra, rb);
     if (nchunks > 1) { A += a_step; B += b_step; }
-    load_chunk();                                // chunk 1 (chunk 0 again when there is only one)
+    load_chunk(ra, rb);                          // chunk 1 (chunk 0 again when there is only one)
+    if constexpr (DEEP) {
+        if (nchunks > 2) { A += a_step; B += b_step; }
+        load_chunk(ra2, rb2);                    // chunk 2 (or the last one once more)
+    }
     __syncthreads();
 
     // fragments of the k4-step about to be multiplied: B's are fetched a whole step ahead (every
@@ -203,7 +219,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     // the first fragments of the next chunk.  The sched_group_barrier sequences spread the memory
     // instructions between the MFMAs (each holds the matrix pipe for 64 cycles: whatever issues in
     // its shadow is free, whatever is clustered between two of them is not).
-    auto chunk = [&](auto last_c, int sb, int c) {
+    auto chunk = [&](auto last_c, int sb, int c, v2d (&rx)[A_IT], v2d (&ry)[B_IT]) {
         constexpr bool LAST = decltype(last_c)::value;
         const int nb = sb ^ (STAGE * 8);                       // byte offsets of this chunk's and the next one's stage
 #pragma unroll
@@ -216,12 +232,12 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
                 for (int j = 0; j < NI; ++j) bf[nxt][j] = frag(fb_off + b_fb[fb_ks] + j * 128);
             }
             if (ks == 1 && !LAST) {
-                write_chunk(nb);
-                // chunk c+2, or once more the last one (its registers are not read again)
-                const bool more = c + 2 < nchunks;
+                write_chunk(nb, rx, ry);
+                // chunk c+2 (DEEP: c+3), or once more the last one (its registers are not read again)
+                const bool more = c + (DEEP ? 3 : 2) < nchunks;
                 A += more ? a_step : 0;
                 B += more ? b_step : 0;
-                load_chunk();
+                load_chunk(rx, ry);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -260,11 +276,27 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
         }
     };
     int sb = 0;
-    for (int c = 0; c < nchunks - 1; ++c) {
-        chunk(std::false_type{}, sb, c);
-        sb ^= STAGE * 8;
+    if constexpr (DEEP) {
+        // chunk c writes chunk c+1 to LDS from the set that holds it (odd: A, even: B) and refills that set with c+3
+        int c = 0;
+        for (; c + 1 < nchunks - 1; c += 2) {
+            chunk(std::false_type{}, sb, c, ra, rb);
+            sb ^= STAGE * 8;
+            chunk(std::false_type{}, sb, c + 1, ra2, rb2);
+            sb ^= STAGE * 8;
+        }
+        if (c < nchunks - 1) {
+            chunk(std::false_type{}, sb, c, ra, rb);
+            sb ^= STAGE * 8;
+        }
+        chunk(std::true_type{}, sb, nchunks - 1, ra, rb);
+    } else {
+        for (int c = 0; c < nchunks - 1; ++c) {
+            chunk(std::false_type{}, sb, c, ra, rb);
+            sb ^= STAGE * 8;
+        }
+        chunk(std::true_type{}, sb, nchunks - 1, ra, rb);
     }
-    chunk(std::true_type{}, sb, nchunks - 1);
 
     // ---- epilogue: C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
 #pragma unroll
