@@ -14,6 +14,9 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 #ifndef GPRN_DEEP_PREFETCH
 #define GPRN_DEEP_PREFETCH 1
 #endif
+#ifndef GPRN_DEEP_SETS
+#define GPRN_DEEP_SETS 2
+#endif
 
 // Staging geometry.  A thread moves R*8/NT 16-byte pieces of an operand chunk (R rows x 16 k); piece `it`
 // differs from piece 0 by +64 rows (only when the lanes cover 64 of 128 rows) and/or +8 k in BOTH memory
@@ -125,6 +128,8 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
                           ((GPRN_DEEP_PREFETCH >= 1 && BM == 64 && BN == 64) || (GPRN_DEEP_PREFETCH >= 2 && BM * BN == 64 * 128));
     v2d ra[A_IT], rb[B_IT];
     v2d ra2[DEEP ? A_IT : 1], rb2[DEEP ? B_IT : 1];
+    constexpr bool DEEP3 = DEEP && GPRN_DEEP_SETS >= 3;        // (experiments: a third set, four chunks ahead)
+    v2d ra3[DEEP3 ? A_IT : 1], rb3[DEEP3 ? B_IT : 1];
     auto load_chunk = [&](v2d (&ra)[A_IT], v2d (&rb)[B_IT]) {
         // raw buffer resources over the chunk's base: 48-bit address, no stride, no bounds (num_records max)
         const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
@@ -201,6 +206,10 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     if constexpr (DEEP) {
         if (nchunks > 2) { A += a_step; B += b_step; }
         load_chunk(ra2, rb2);                    // chunk 2 (or the last one once more)
+        if constexpr (DEEP3) {
+            if (nchunks > 3) { A += a_step; B += b_step; }
+            load_chunk(ra3, rb3);                // chunk 3
+        }
     }
     __syncthreads();
 
@@ -234,7 +243,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
             if (ks == 1 && !LAST) {
                 write_chunk(nb, rx, ry);
                 // chunk c+2 (DEEP: c+3), or once more the last one (its registers are not read again)
-                const bool more = c + (DEEP ? 3 : 2) < nchunks;
+                const bool more = c + (DEEP3 ? 4 : (DEEP ? 3 : 2)) < nchunks;
                 A += more ? a_step : 0;
                 B += more ? b_step : 0;
                 load_chunk(rx, ry);
@@ -276,7 +285,20 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
         }
     };
     int sb = 0;
-    if constexpr (DEEP) {
+    if constexpr (DEEP3) {
+        int c = 0;
+        for (; c + 2 < nchunks - 1; c += 3) {
+            chunk(std::false_type{}, sb, c, ra, rb);
+            sb ^= STAGE * 8;
+            chunk(std::false_type{}, sb, c + 1, ra2, rb2);
+            sb ^= STAGE * 8;
+            chunk(std::false_type{}, sb, c + 2, ra3, rb3);
+            sb ^= STAGE * 8;
+        }
+        if (c < nchunks - 1) { chunk(std::false_type{}, sb, c, ra, rb); sb ^= STAGE * 8; ++c; }
+        if (c < nchunks - 1) { chunk(std::false_type{}, sb, c, ra2, rb2); sb ^= STAGE * 8; }
+        chunk(std::true_type{}, sb, nchunks - 1, ra, rb);
+    } else if constexpr (DEEP) {
         // chunk c writes chunk c+1 to LDS from the set that holds it (odd: A, even: B) and refills that set with c+3
         int c = 0;
         for (; c + 1 < nchunks - 1; c += 2) {
