@@ -110,10 +110,10 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     }
     if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
     else if (CAN_LOWER && lower && sr == sc)
-        tile_mma<BM, BN, WM, WN, TRI, false, -1, CAN_LOWER>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+        tile_mma<BM, BN, WM, WN, TRI, false, -1, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
                                                             (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
     else
-        tile_mma<BM, BN, WM, WN, TRI, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+        tile_mma<BM, BN, WM, WN, TRI, false, -1, false, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
                                              (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }

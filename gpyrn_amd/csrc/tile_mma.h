@@ -57,7 +57,9 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // formed from K (same offsets as C) and s = sqrt(d): delta + (s_row s_col) K, zero outside the n x n problem -- what
 // k_build_B would have written there (same expression, same rounding).  ft_row / ft_col: the part's first row / column
 // inside the matrix.
-template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1, bool LOWER = false>
+// DEEP_OK: the caller's register budget allows the second set of staging registers (the launch kernel's 64 x 64 form: 110
+// registers per lane; the dataflow schedule's worker is held to 96 and keeps the one-set pipeline)
+template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1, bool LOWER = false, bool DEEP_OK = false>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
                                          int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
                                          double* out_img = nullptr, const double* ft_K = nullptr,
@@ -124,7 +126,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     // of its cycles at a wait, a third of the L2 requests miss, and with two or three waves per SIMD that leaves the
     // matrix pipes idle a third of the time -- one chunk period (16 MFMAs per wave) is not enough to cover an L2 miss.
     // (GPRN_DEEP_PREFETCH=2: the 4-wave 64 x 128 / 128 x 64 forms too, i.e. the panel products)
-    constexpr bool DEEP = !SYRK && WM == 2 && WN == 2 &&
+    constexpr bool DEEP = DEEP_OK && !SYRK && WM == 2 && WN == 2 &&
                           ((GPRN_DEEP_PREFETCH >= 1 && BM == 64 && BN == 64) || (GPRN_DEEP_PREFETCH >= 2 && BM * BN == 64 * 128));
     v2d ra[A_IT], rb[B_IT];
     v2d ra2[DEEP ? A_IT : 1], rb2[DEEP ? B_IT : 1];
