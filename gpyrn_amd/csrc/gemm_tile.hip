@@ -72,8 +72,10 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     // contiguous eighth per XCD measured -25 % fabric traffic but +6 % time).  Placement is a speed matter
     // only: any bijection is correct.
     const unsigned gx = gridDim.x, nblk = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-    const unsigned n128 = nblk & ~127u, cx = lin >> 3;
-    const unsigned lb = (xcd_map && lin < n128) ? ((((cx >> 4) << 3) + (lin & 7u)) << 4) + (cx & 15u) : lin;
+    // (xcd_map = log2 of the chunk: 4 by default; GPRN_XCD_MAP=5 / 6 for chunks of 32 / 64 entries, 0 for grid order)
+    const unsigned sh = (unsigned)xcd_map, cmask = (1u << sh) - 1u;
+    const unsigned n128 = nblk & ~((8u << sh) - 1u), cx = lin >> 3;
+    const unsigned lb = (xcd_map && lin < n128) ? ((((cx >> sh) << 3) + (lin & 7u)) << sh) + (cx & cmask) : lin;
     const unsigned bx = lb % gx, by = lb / gx;
     const TileTask t = tasks[bx / (SM * SN)];
     const int sub = bx % (SM * SN), sr = sub / SN, sc = sub % SN;
@@ -561,7 +563,7 @@ int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
 static int xcd_map()                               // GPRN_XCD_MAP=0: grid order as dispatched (experiments)
 {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("GPRN_XCD_MAP"); v = e ? atoi(e) : 1; }
+    if (v < 0) { const char* e = getenv("GPRN_XCD_MAP"); v = e ? atoi(e) : 4; if (v == 1) v = 4; if (v < 0 || v > 8) v = 4; }
     return v;
 }
 
