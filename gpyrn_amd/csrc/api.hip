@@ -367,6 +367,9 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         dev_free(c->d_tasks);
         queue_free(c);
         if (c->d_sig) hipFree(c->d_sig);
+        if (c->d_step_stamps) hipFree(c->d_step_stamps);
+        if (c->d_side_stamps) hipFree(c->d_side_stamps);
+        if (c->d_stamps) hipFree(c->d_stamps);
         dev_free(c->d_agree);
         dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
         hipEventDestroy(c->ev_diag);

@@ -210,8 +210,14 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
  * per family and tile step, csrc/factor.hip); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb" (KiB of
  * unused dynamic LDS the bulk tile launches -- batches above / up to two matrices -- and the chain's own tile launches
  * ask for, to keep CUs open for the latency chain; -2 returns to the environment's / default value; a pad that does not
- * fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG instead of aborting the queue).  value == -1 only
- * reads; *old (may be NULL) receives the previous value. */
+ * fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG instead of aborting the queue); "block_sched" (1: the
+ * block schedule of the factorisation where it applies -- the chain factors the 512 x 512 diagonal block of an outer panel on
+ * its own, one product with the block's inverse per panel and side, csrc/factor.hip factor_invert_blocks --, 0: the
+ * step-synchronous launch schedule); "overlap" (bit mask of what runs beside the factorisations instead of before / behind
+ * them: 1 B formed inside the first panel's update, 2 row reductions over X panel by panel, 4 node term beside the weight
+ * phase, 8 log det B in the finalising kernel, 16 a sweep's end beside the next sweep's node phase, 32 ... with its X^T X
+ * product; results are bit-identical for every value).  value == -1 only reads; *old (may be NULL) receives the previous
+ * value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 
 /* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----
