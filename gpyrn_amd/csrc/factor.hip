@@ -1823,10 +1823,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
 // side stream (its three dependent launches per tile step were what the chain waited for when one or two matrices are
 // factored), a tenth of the launches and stream operations, and the in-panel tiles are read and written once per panel
 // instead of up to three times with K = 128.
-//   chain   : per step  diag(k) -> in-block panel -> in-block update;  per panel  [X_D complete: F_PANEL] ... wait F_FIRST
-//             -> update of the next diagonal block
-//   stream3 : wait F_PANEL(P), F_NEXT(P-1);  L mirrors of the next block's rows [F_FIRST], of the other rows [F_MINIL]
-//   stream4 : wait F_PANEL(P), F_NEXT(P-1);  X mirrors + copy back [F_XW];  wait F_MINIL(P), F_RESTA(P-1);  "next" [F_NEXT]
+//   chain   : per step  diag(k) -> in-block panel -> in-block update;  per panel  [X_D complete: F_PANEL], wait F_NEXT(P-1),
+//             the L mirrors of the next block's rows [F_FIRST] -> update of the next diagonal block
+//   stream3 : wait F_PANEL(P), F_NEXT(P-1);  L mirrors of the other rows [F_MINIL]
+//   stream4 : wait F_PANEL(P), F_NEXT(P-1);  X mirrors + copy back [F_XW];  wait F_MINIL(P), F_FIRST(P), F_RESTA(P-1);  "next" [F_NEXT]
 //   bulk    : wait F_MINIL(P), F_XW(P);  "ahead" [F_RESTA], "bulk" [F_REST], the phase's row reductions (rows_final)
 static int factor_invert_blocks(gprn_ctx* c, int nbatch)
 {
