@@ -396,6 +396,26 @@ def test_schedule_and_kernel_variants_agree(env, tmp_path):
     np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
 
 
+@pytest.mark.parametrize('env', [{'GPRN_LEFT': '1'}, {'GPRN_SPLIT_FIRST': '1'}, {'GPRN_LEFT': '1', 'GPRN_SPLIT_FIRST': '1'},
+                                 {'GPRN_BLOCK_SCHED': '1'}, {'GPRN_OVERLAP': '0'}, {'GPRN_OVERLAP': '63'},
+                                 {'GPRN_FIRST_ALONE': '8'}, {'GPRN_FLAGS': '0', 'GPRN_LEFT': '1'}],
+                         ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
+def test_throughput_schedule_variants_agree(env, tmp_path):
+    """Round 3's switches of the throughput schedule (outer panels of four tiles: needs more than 32 batch x tiles) -- the
+    left-looking in-panel updates with the next-panel update in groups, the two-part "first" update, the block schedule,
+    the overlap masks, "first" alone -- each in a process of its own against the golden values of BASELINE config 5's
+    shape at N = 2048 (T = 16, three nodes and twelve weights: four outer panels per factorisation)."""
+    tag = 'cfg5shape_N2048'
+    if not _cases.available(tag):
+        pytest.skip('fixture not generated')
+    meta, d = _cases.load(tag)
+    res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
+    assert int(res['sw_info']) == 0
+    np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
+    np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
+    np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
+
+
 def test_eval_pool_splits_independent_evaluations(tmp_path):
     """sharding.EvalPool: three ranks, each with the whole problem on the (shared)
     GPU, split five nELBO evaluations; every rank gets all five values, bit-identical to
