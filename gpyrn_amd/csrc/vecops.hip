@@ -105,15 +105,43 @@ void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q
 // part 0: every lower tile; part 1: what the factorisation's first outer panel touches before its K = outer * 128
 // update (tile columns < outer, and of the next `outer` columns the diagonal and sub-diagonal tiles, which the in-panel
 // lists keep up to date step by step: ensure_tasks, factor.hip); part 2: the others (built beside the first tile steps)
-__global__ __launch_bounds__(256)
-void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __restrict__ s, int part, int outer)
+// One workgroup per tile that is written, no empty ones: the grid's x index runs over the tiles of the part, column by
+// column (a workgroup that finds out it has nothing to do still costs its dispatch -- with T x T workgroups of which a
+// quarter of the lower half had work, part 1 took 139 us for 45 us of traffic at config 3).
+__device__ __forceinline__ bool build_B_tile(int idx, int T, int part, int outer, int& ti, int& tj)
 {
-    const int tj = blockIdx.x, ti = blockIdx.y, slot = blockIdx.z;
-    if (tj > ti) return;
-    if (part) {
-        const bool early = tj < outer || (tj < 2 * outer && ti <= tj + 1);
-        if (early != (part == 1)) return;
+    if (part == 1) {
+        // columns [0, outer): rows tj .. T-1;  then columns [outer, 2 outer): rows tj, tj + 1
+        for (tj = 0; tj < outer && tj < T; ++tj) {
+            const int n = T - tj;
+            if (idx < n) { ti = tj + idx; return true; }
+            idx -= n;
+        }
+        for (; tj < 2 * outer && tj < T; ++tj) {
+            const int n = tj + 1 < T ? 2 : 1;
+            if (idx < n) { ti = tj + idx; return true; }
+            idx -= n;
+        }
+        return false;
     }
+    // part 0: every lower tile; part 2: the lower tiles part 1 leaves out -- row by row
+    for (ti = 0; ti < T; ++ti) {
+        if (idx <= ti) {
+            tj = idx;
+            if (part == 2 && (tj < outer || (tj < 2 * outer && ti <= tj + 1))) return false;
+            return true;
+        }
+        idx -= ti + 1;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256)
+void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __restrict__ s, int part, int outer, int T)
+{
+    int ti, tj;
+    const int slot = blockIdx.y;
+    if (!build_B_tile((int)blockIdx.x, T, part, outer, ti, tj)) return;
     const double* K = ptrs[(size_t)slot * GPRN_NBUF + BUF_K];
     double* B = ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     const double* sv = s + (size_t)slot * ld;
@@ -405,8 +433,15 @@ int vec_build_B(gprn_ctx* c, int nslots, hipStream_t stream, int part, int outer
     if (!nslots) return GPRN_OK;
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_BUILD_B, stream);
-    hipLaunchKernelGGL(k_build_B, dim3(c->T, c->T, nslots), dim3(256), 0, stream,
-                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld, part, outer);
+    const int T = c->T;
+    int ntiles = T * (T + 1) / 2;                              // parts 0 and 2 (part 2's few part-1 tiles exit at once)
+    if (part == 1) {
+        ntiles = 0;
+        for (int tj = 0; tj < outer && tj < T; ++tj) ntiles += T - tj;
+        for (int tj = outer; tj < 2 * outer && tj < T; ++tj) ntiles += tj + 1 < T ? 2 : 1;
+    }
+    hipLaunchKernelGGL(k_build_B, dim3(ntiles, nslots), dim3(256), 0, stream,
+                       (double* const*)c->d_ptrs, c->N, c->ld, c->d_s + (size_t)c->slot0 * c->ld, part, outer, T);
     LAUNCH_END(c);
 }
 
