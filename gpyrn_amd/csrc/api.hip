@@ -273,7 +273,13 @@ static DeviceStreams* device_streams_acquire(int device)
     DeviceStreams* d = new DeviceStreams();
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const int prio[4] = {prio_hi, prio_lo, prio_hi, prio_hi};
+    int prio[4] = {prio_hi, prio_lo, prio_hi, prio_hi};
+    // GPRN_STREAM_PRIO="a,b,c,d" (experiments): 0 highest, 1 the level between, 2 lowest, for s[0..3]
+    if (const char* e = getenv("GPRN_STREAM_PRIO")) {
+        int v[4] = {0, 2, 0, 0};
+        if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int i = 0; i < 4; ++i) prio[i] = v[i] <= 0 ? prio_hi : (v[i] >= 2 ? prio_lo : (prio_hi + prio_lo) / 2);
+    }
     // GPRN_RESERVE_CUS=n (experiments; default 0): the bulk, side and fourth stream are created with a CU mask that
     // leaves the last n CUs of every XCD to the chain stream's kernels (bit i of the mask = CU i / 8 of XCD i % 8,
     // _probe/cumask_map.hip); masked streams have no priority

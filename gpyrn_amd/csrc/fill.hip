@@ -20,12 +20,65 @@ struct FillProgram {
     double nugget_val;        // 1e-6 (meanfield.py:433) for the priors, 1.25e-12 (_gp.py:47) for prediction
     int32_t ops[3 * GPRN_MAX_OPS];
     double par[GPRN_MAX_KPARAMS];
+    double aux[3];            // one-kernel SE / Periodic / QP programs: the reciprocals the element formula multiplies by
 };
 
 #define PI_D 3.141592653589793
-#ifndef GPRN_FILL_SINPI
-#define GPRN_FILL_SINPI 1
+// GPRN_FILL_FAST=0 at build time: the device library's exp / sinpi in the SE, Periodic and QP kernels (rounds 1-2)
+#ifndef GPRN_FILL_FAST
+#define GPRN_FILL_FAST 1
 #endif
+
+// exp(x) for x <= 0 -- the exponent of every kernel below is one: Cody-Waite reduction by ln 2 in two words, the Taylor
+// polynomial of degree 13 on |r| <= ln(2)/2 (truncation 4e-18), one ldexp (which also rounds into the denormals and
+// flushes to zero below them).  No branches, no special cases: 2.6e-16 worst relative error against long double on the
+// host over the benchmark's arguments, the same as the device library's exp, in 19 instead of ~30 instructions.
+__device__ __forceinline__ double exp_neg(double x)
+{
+    x = fmax(x, -800.0);
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// sin^2(pi x), x >= 0, the only form the periodic kernels use the sine in: the distance f of x to the nearest integer is
+// exact, so is g = min(f, 1/2 - f) <= 1/4, and sin(pi g) = g P(g^2) with the Taylor polynomial of degree 8 (pi g <= pi / 4:
+// the next term is 8e-20); beyond 1/4 the square is 1 - sin^2(pi g).  One polynomial instead of the library sinpi's two
+// (sine and cosine, selected by octant) and no sign logic.
+__device__ __forceinline__ double sinpi_sq(double x)
+{
+    const double f = fabs(x - rint(x));
+    const bool hi = f > 0.25;
+    const double g = hi ? 0.5 - f : f;
+    const double z = g * g;
+    double p = 7.952054001475508e-07;
+    p = fma(p, z, -2.1915353447830204e-05);
+    p = fma(p, z, 0.00046630280576761234);
+    p = fma(p, z, -0.007370430945714348);
+    p = fma(p, z, 0.08214588661112819);
+    p = fma(p, z, -0.5992645293207919);
+    p = fma(p, z, 2.550164039877345);
+    p = fma(p, z, -5.167712780049969);
+    p = fma(p, z, 3.141592653589793);
+    const double sn = p * g;
+    const double u = sn * sn;
+    return hi ? 1.0 - u : u;
+}
 
 __device__ __forceinline__ void harmonic_terms(double Nh, double P, double t, double& s, double& u)
 {
@@ -37,7 +90,7 @@ __device__ __forceinline__ void harmonic_terms(double Nh, double P, double t, do
 }
 
 __device__ __forceinline__ double eval_kernel(int kid, const double* __restrict__ q,
-                                              double ti, double tj, bool diag)
+                                              double ti, double tj, bool diag, const double* __restrict__ aux = nullptr)
 {
     const double r = ti - tj;
     switch (kid) {
@@ -47,23 +100,33 @@ __device__ __forceinline__ double eval_kernel(int kid, const double* __restrict_
     // expressions become multiplications by reciprocals, which depend on the parameters only and are hoisted
     // out of the element loop -- an IEEE fp64 division is ~10 quarter-rate instructions.  The argument of
     // exp / sin moves by <= 1 ulp: <= 1e-13 relative on K against NumPy's order of operations (test tolerance 1e-12).
+    // (aux: the same reciprocals formed once on the host, make_program -- an IEEE division is the same number on either
+    // side; a thread of k_fill_sym evaluates 8 elements, and QP's three divisions were a quarter of its instructions)
     case GPRN_K_SE: {
-        const double inv = 1.0 / (q[1] * q[1]);
-        return q[0] * q[0] * exp(-0.5 * (r * r) * inv);
+        const double inv = aux ? aux[0] : 1.0 / (q[1] * q[1]);
+        const double x = -0.5 * (r * r) * inv;
+        return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(x) : exp(x));
     }
-    // (sin(pi |r| / P) as sinpi(|r| / P): the argument reduction of sinpi is a `fract`, that of sin on an argument of
-    // several hundred periods a multi-word product -- GPRN_FILL_SINPI=0 at build time keeps sin)
+    // (sin(pi |r| / P) through the fraction of |r| / P, not through sin on an argument of several hundred periods, whose
+    // reduction is a multi-word product)
     case GPRN_K_PERIODIC: {
-        const double w = PI_D / q[1], inv = 1.0 / (q[2] * q[2]);
-        const double s = GPRN_FILL_SINPI ? sinpi(fabs(r) * (1.0 / q[1])) : sin(w * fabs(r));
-        return q[0] * q[0] * exp(-2 * (s * s) * inv);
+        const double inv = aux ? aux[0] : 1.0 / (q[2] * q[2]);
+        const double a = fabs(r) * (aux ? aux[1] : 1.0 / q[1]);
+        double s2;
+        if (GPRN_FILL_FAST) s2 = sinpi_sq(a);
+        else { const double s = sinpi(a); s2 = s * s; }
+        const double x = -2 * s2 * inv;
+        return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(x) : exp(x));
     }
     case GPRN_K_QP: {
-        const double w = PI_D / q[2], invp = 1.0 / (q[3] * q[3]), inve = 1.0 / (2 * (q[1] * q[1]));
-        const double s = GPRN_FILL_SINPI ? sinpi(fabs(r) * (1.0 / q[2])) : sin(w * fabs(r));
-        const double per = -2 * (s * s) * invp;
+        const double invp = aux ? aux[0] : 1.0 / (q[3] * q[3]), inve = aux ? aux[2] : 1.0 / (2 * (q[1] * q[1]));
+        const double a = fabs(r) * (aux ? aux[1] : 1.0 / q[2]);
+        double s2;
+        if (GPRN_FILL_FAST) s2 = sinpi_sq(a);
+        else { const double s = sinpi(a); s2 = s * s; }
+        const double per = -2 * s2 * invp;
         const double dec = (r * r) * inve;
-        return q[0] * q[0] * exp(per - dec);
+        return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(per - dec) : exp(per - dec));
     }
     case GPRN_K_RQ:
         return q[0] * q[0] * pow(1 + 0.5 * (r * r) / (q[1] * (q[2] * q[2])), -q[1]);
@@ -178,7 +241,8 @@ __device__ __forceinline__ double eval_program(const FillProgram& pg, double ti,
 template <int KID>
 __device__ __forceinline__ double eval_any(const FillProgram& pg, double ti, double tj, bool diag)
 {
-    if constexpr (KID >= 0) return eval_kernel(KID, pg.par, ti, tj, diag);
+    if constexpr (KID == GPRN_K_SE || KID == GPRN_K_PERIODIC || KID == GPRN_K_QP) return eval_kernel(KID, pg.par, ti, tj, diag, pg.aux);
+    else if constexpr (KID >= 0) return eval_kernel(KID, pg.par, ti, tj, diag);
     else return eval_program(pg, ti, tj, diag);
 }
 
@@ -213,46 +277,61 @@ void k_fill(FillProgram pg, const double* __restrict__ t, double* __restrict__ K
 }
 
 // Every built-in but Polynomial is an even function of t_i - t_j evaluated through r*r, |r| or
-// sin/cos pairs whose signs cancel, i.e. K is symmetric to the last bit: compute the lower 64x64
-// tiles only and write each one twice, the mirror image through an LDS transpose (both writes
-// 512-byte row segments).  Halves the VALU work, which is what bounds the fill.
+// sin/cos pairs whose signs cancel, i.e. K is symmetric to the last bit: compute the lower 64-column
+// blocks only and write each element twice, the mirror image through an LDS transpose.  Halves the VALU work.
+//
+// One workgroup = one 64 x 64 block; a thread = TWO adjacent columns x 8 rows: the two evaluations are independent
+// instruction streams the compiler interleaves (the exp / sin chains are latency-bound at this occupancy), and both
+// images go out as 16-byte stores in 512-byte row segments.  Measured stand-alone on config 3's shapes (N = 4096, ten
+// matrices in turn so that the infinity cache does not absorb the writes): SE 24.7 us per matrix = 5.4 TB/s, QP 27.4 us =
+// 4.9 TB/s, a kernel that stores a constant in the same pattern 23.6 us = 5.7 TB/s (32-row strips, 256-byte segments in
+// the mirror image: 5 % slower); one column per thread with the device library's exp / sinpi, as in rounds 1-2: 29.6 /
+// 40.8 us in the same bench.  (Into ONE matrix over and over the same kernels take 20.5 / 23.6 us: the 256 MB cache.)
 template <int KID>
 __global__ __launch_bounds__(256)
 void k_fill_sym(FillProgram pg, const double* __restrict__ t, double* __restrict__ K, int N, int ld,
                 const double* __restrict__ diag_add)
 {
-    __shared__ double tile[64][65];
-    // lower-triangular tile index -> (bi, bj), bi >= bj
-    const int L = blockIdx.x;
+    constexpr int TR = 64;
+    __shared__ double tile[TR][65];
+    // lower-triangular block index -> (bi, bj), bi >= bj
+    const int L = blockIdx.x, sub = 0;
     int bi = (int)((sqrt(8.0 * L + 1.0) - 1.0) * 0.5);
     while ((bi + 1) * (bi + 2) / 2 <= L) ++bi;
     while (bi * (bi + 1) / 2 > L) --bi;
     const int bj = L - bi * (bi + 1) / 2;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int n = bj * 64 + tx;
-    const double tn = (n < N) ? t[n] : 0.0;
-#pragma unroll 1
-    for (int i = 0; i < 16; ++i) {
-        const int r = ty + 4 * i, m = bi * 64 + r;
-        double v;
-        if (m < N && n < N) {
-            v = eval_any<KID>(pg, t[m], tn, m == n);
-            if (m == n) {
-                if (pg.nugget) v += pg.nugget_val;
-                if (diag_add) v += diag_add[m];
-            }
-        } else {
-            v = (m == n) ? 1.0 : 0.0;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = bj * 64 + 2 * tx;                // ld is a multiple of 128: n + 1 < ld
+    const double tn0 = (n < N) ? t[n] : 0.0, tn1 = (n + 1 < N) ? t[n + 1] : 0.0;
+    const int row0 = bi * 64 + sub * TR;
+#pragma unroll 2
+    for (int i = 0; i < TR / 8; ++i) {
+        const int r = ty + 8 * i, m = row0 + r;
+        const double tm = (m < N) ? t[m] : 0.0;
+        // (both evaluated unconditionally, on zeros in the padding: one straight-line instruction stream for the pair)
+        double v0 = eval_any<KID>(pg, tm, tn0, m == n);
+        double v1 = eval_any<KID>(pg, tm, tn1, m == n + 1);
+        if (m == n || m == n + 1) {
+            double d = (m == n) ? v0 : v1;
+            if (pg.nugget) d += pg.nugget_val;
+            if (diag_add && m < N) d += diag_add[m];
+            if (m == n) v0 = d; else v1 = d;
         }
-        K[(size_t)m * ld + n] = v;
-        tile[r][tx] = v;
+        // the padded region (>= N) becomes identity so that the blocked factorisation can run on whole tiles
+        if (m >= N || n >= N) v0 = (m == n) ? 1.0 : 0.0;
+        if (m >= N || n + 1 >= N) v1 = (m == n + 1) ? 1.0 : 0.0;
+        *(double2*)(K + (size_t)m * ld + n) = make_double2(v0, v1);
+        tile[r][2 * tx] = v0;
+        tile[r][2 * tx + 1] = v1;
     }
-    if (bi == bj) return;                          // a diagonal tile is complete as computed
+    if (bi == bj) return;                          // a diagonal block is complete as computed
     __syncthreads();
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int r = ty + 4 * i;                  // row of the mirrored tile = column of the computed one
-        K[(size_t)(bj * 64 + r) * ld + bi * 64 + tx] = tile[tx][r];
+    // mirror image: row = a column of the block, TR entries = 32 pairs
+    constexpr int CP = TR / 2;
+#pragma unroll
+    for (int idx = threadIdx.x; idx < 64 * CP; idx += 256) {
+        const int c = idx / CP, rp = idx % CP;
+        *(double2*)(K + (size_t)(bj * 64 + c) * ld + row0 + 2 * rp) = make_double2(tile[2 * rp][c], tile[2 * rp + 1][c]);
     }
 }
 
@@ -283,6 +362,14 @@ static void make_program(const KernelSpec& ks, double nugget_val, FillProgram& p
     for (int i = 0; i < ks.n_params; ++i) pg.par[i] = ks.params[i];
     for (int i = ks.n_params; i < GPRN_MAX_KPARAMS; ++i) pg.par[i] = 0.0;
     for (int i = 3 * ks.n_ops; i < 3 * GPRN_MAX_OPS; ++i) pg.ops[i] = 0;
+    pg.aux[0] = pg.aux[1] = pg.aux[2] = 0.0;
+    const double* q = pg.par;
+    switch (program_kid(pg)) {
+    case GPRN_K_SE: pg.aux[0] = 1.0 / (q[1] * q[1]); break;
+    case GPRN_K_PERIODIC: pg.aux[0] = 1.0 / (q[2] * q[2]); pg.aux[1] = 1.0 / q[1]; break;
+    case GPRN_K_QP: pg.aux[0] = 1.0 / (q[3] * q[3]); pg.aux[1] = 1.0 / q[2]; pg.aux[2] = 1.0 / (2 * (q[1] * q[1])); break;
+    default: break;
+    }
 }
 
 // ---- gradient of the ELBO in the hyper-parameters of ANY kernel program: per parameter l
