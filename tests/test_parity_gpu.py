@@ -44,6 +44,25 @@ def test_fill_matches_reference_kernels():
         np.testing.assert_allclose(K, d['K_' + tag], rtol=1e-12, atol=1e-12, err_msg=tag)
 
 
+@pytest.mark.parametrize('n', [1, 2, 63, 65, 129, 257])
+def test_fill_sizes_around_the_block_edges(n):
+    """k_fill_sym evaluates two adjacent columns per thread and mirrors 64 x 64 blocks: sizes that end inside a pair, a block
+    and a tile, against the host formulas (gpyrn_amd.covfunc, themselves checked against the reference's matrices in
+    test_api.py) -- SE / Periodic / QP go through exp_neg and sinpi_sq on the device."""
+    rng = np.random.default_rng(n)
+    t = np.sort(rng.uniform(0.0, 400.0, n))
+    g = gpyrn.inference(1, t, np.zeros(n), np.ones(n))
+    r = t[:, None] - t[None, :]
+    for k in (covfunc.SquaredExponential(1.3, 7.0), covfunc.Periodic(0.8, 23.0, 0.9),
+              covfunc.QuasiPeriodic(1.1, 31.0, 23.0, 0.7), covfunc.Matern32(0.9, 12.0),
+              covfunc.QuasiPeriodic(1.1, 31.0, 23.0, 0.7) + covfunc.SquaredExponential(0.3, 2.0)):
+        assert k._device_program() is not None
+        K = g._KMatrix(k)
+        want = k(r) + 1e-6 * np.eye(n)          # meanfield.py:433: the nugget of _KMatrix
+        np.testing.assert_allclose(K, want, rtol=1e-12, atol=1e-14, err_msg=type(k).__name__)
+        assert np.array_equal(K, K.T)
+
+
 def test_user_kernel_takes_host_path():
     class MySE(covfunc.covFunction):
         _param_names = ('a', 'l')
