@@ -1703,14 +1703,21 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             // (GPRN_CHAIN_ROWS=0: the throughput tile kernel for these two as well, as in round 1)
             static int chain_rows = -1;
             if (chain_rows < 0) { const char* e = getenv("GPRN_CHAIN_ROWS"); chain_rows = e ? atoi(e) : 1; }
+            // GPRN_MINIL_BY_U=1 (default): L_{k+1,k}'s flag goes up at the START of the update launch behind it on the chain
+            // stream instead of at the end of its own (launch_tile_rows) -- 1.7 us less between the two at every tile step;
+            // stream3 sees the flag a launch gap later, at the end of a panel launch that runs ten times as long
+            static int minil_by_u = -1;
+            if (minil_by_u < 0) { const char* e = getenv("GPRN_MINIL_BY_U"); minil_by_u = e ? atoi(e) : 1; }
+            const bool by_u = use_flags && chain_rows && !two_streams && minil_by_u;
             if (chain_rows) {
                 if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, sc,
-                                           in_kernel(k, F_MINIL), l_waits))) return rc;
+                                           by_u ? nosig : in_kernel(k, F_MINIL), l_waits))) return rc;
             } else if ((rc = tiles(s.panel0, 1, sc, TS_64x128, GPRN_T_PANEL, in_kernel(k, F_MINIL), l_waits))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
             if (chain_rows) {
                 if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, sc,
-                                           two_streams ? in_kernel(k, F_U) : nosig, noaw))) return rc;
+                                           two_streams ? in_kernel(k, F_U) : nosig, noaw,
+                                           by_u ? slot(k, F_MINIL) + 1 : (unsigned*)nullptr, epoch))) return rc;
             } else if ((rc = tiles(s.upd0, 1, sc, TS_64x64, GPRN_T_PANEL, two_streams ? in_kernel(k, F_U) : nosig))) return rc;
             if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;    // the previous panel's trailing update
             // beside it: the rest of the panel, then the rest of the in-panel updates

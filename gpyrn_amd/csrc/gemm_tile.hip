@@ -351,10 +351,14 @@ __global__ __launch_bounds__(64)
 void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t c_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
                unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2,
-               QueueCtl q, unsigned qop, int q_skip_wait)
+               QueueCtl q, unsigned qop, int q_skip_wait, unsigned* start_flag, unsigned start_value)
 {
     RW_STAMP(0);
     CHAIN_PRIO();
+    // (launch_tile_rows: the flag of the launch BEFORE this one on the stream, raised here instead of at that one's end --
+    // what it wrote is in memory by the time a workgroup of this launch runs)
+    if (start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const bool st = !QUEUE && pa.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0;
     if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
@@ -466,8 +470,11 @@ int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doubl
 
 // mode 0 / 1 as above, for tile step k: the operands are tiles (k+1, k), (k, k) [of X] resp. (k+1, k+1), (k+1, k) --
 // the first panel and the first update task of the step (ensure_tasks, factor.hip)
+// raise_at_start (mode 1): a flag word the launch sets to raise_value as soon as its first workgroup runs -- L_{k+1,k}'s
+// flag, when the launch before it on the stream is that product: its own end-of-kernel signal (wait for the stores, barrier,
+// release, atomic: 1.7 us between the two launches of every tile step, profiles/r03_chain_stamps_c2.txt) is then not needed
 int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
-                     hipStream_t stream, Signal sig, Await aw)
+                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start, unsigned raise_value)
 {
     if (!stream) stream = c->stream;
     if (nbatch == 0) return GPRN_OK;
@@ -485,7 +492,7 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
 #define GO_L(A) hipLaunchKernelGGL((k_chain_l<A, false>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
                                    b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0)
 #define GO_U(A) hipLaunchKernelGGL((k_chain_u<A, false>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0)
+                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0, raise_at_start, raise_value)
     if (mode == 0) { if (args) GO_L(true); else GO_L(false); }
     else { if (args) GO_U(true); else GO_U(false); }
 #undef GO_L
@@ -513,7 +520,7 @@ int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, 
 #define GO_LQ(A) hipLaunchKernelGGL((k_chain_l<A, true>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
                                     b_off, ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0)
 #define GO_UQ(A) hipLaunchKernelGGL((k_chain_u<A, true>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                    ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0)
+                                    ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0, ns, 0u)
     if (mode == 0) { if (args) GO_LQ(true); else GO_LQ(false); }
     else { if (args) GO_UQ(true); else GO_UQ(false); }
 #undef GO_LQ

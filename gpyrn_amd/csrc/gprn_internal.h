@@ -366,7 +366,7 @@ unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which);   // GPRN_STE
 // the chain's two products of a tile step at 16 x 16 granularity (gemm_tile.hip); mode 0: L_{k+1,k} in place, 1: the
 // update of B_{k+1,k+1}
 int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
-                     hipStream_t stream, Signal sig, Await aw);
+                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start = nullptr, unsigned raise_value = 0);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
                 Await aw = Await{nullptr, 0, nullptr, nullptr, 0});
