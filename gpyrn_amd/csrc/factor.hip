@@ -1245,6 +1245,20 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
     if (wait_flag) spin_until(wait_flag, wait_value, timed_out);
 }
 
+// ... and several of each in one: every stream memory operation of this runtime is a 4-5 us kernel of its own, and at a
+// panel boundary stream3 had five of them in a row, the chain stream four at the end of a factorisation
+struct FlagOps { unsigned* raise[2]; const unsigned* wait[4]; };
+__global__ void k_flag_multi(FlagOps ops, unsigned value, unsigned* timed_out)
+{
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        if (ops.raise[i]) __hip_atomic_store(ops.raise[i], value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ops.wait[i]) spin_until(ops.wait[i], value, timed_out);
+}
+
 #define GPRN_FLAG_KINDS 11          // flag kinds per tile step / outer panel (factor_invert_split)
 
 // Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
@@ -1534,6 +1548,20 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (split_first < 0) { const char* e = getenv("GPRN_SPLIT_FIRST"); split_first = e ? atoi(e) : 0; }
     int first_a_done = -1;
     int pending_outer = -1;                        // outer panel whose trailing update is not enqueued yet
+    unsigned* pending_up = nullptr;                // a flag the next folded panel launch on stream3 raises at its start
+    // GPRN_PANEL_SYNC=n (default 2): with up to n matrices stream3's synchronisation kernel is folded into the panel
+    // launch -- F_INNER of the step before goes up when its first workgroup runs, every workgroup waits for the
+    // diagonal block itself: one launch less per step on stream3 (config 2 737 -> 751 sweeps/s, config 3 +0.5 %;
+    // with six matrices, whose panel launches are hundreds of workgroups that would all poll: -1 %)
+    static int panel_sync = -1, merge_panel = -1;
+    if (panel_sync < 0) { const char* e = getenv("GPRN_PANEL_SYNC"); panel_sync = e ? atoi(e) : 2; }
+    // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
+    if (merge_panel < 0) { const char* e = getenv("GPRN_MERGE_PANEL"); merge_panel = e ? atoi(e) : 1; }
+    auto folds_sync = [&](int k) {                 // tile step k's panel launch takes stream3's synchronisation along
+        if (k < 0 || k >= c->T || use_chain) return false;
+        const gprn_ctx::StepRange& sk = c->steps[set][k];
+        return merge_panel && tri && use_flags && nbatch <= panel_sync && sk.npanel_l > 0 && sk.npanel > 1;
+    };
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
         const gprn_ctx::OuterRange& o = c->outers[set][J];
@@ -1542,7 +1570,11 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // the chain touches first in the next panel (its first column of B and first row of R, its diagonal
         // and sub-diagonal tiles); bulk stream: the rest of the next panel, then everything beyond.  The
         // chain itself goes straight on with the next diagonal block.
-        HIP_TRY(c, raise(s1, (int)J, F_PANEL));
+        // GPRN_MULTI_FLAG=0: every raise / wait below as a stream memory operation of its own (before round 3's last session)
+        static int multi_flag = -1;
+        if (multi_flag < 0) { const char* e = getenv("GPRN_MULTI_FLAG"); multi_flag = e ? atoi(e) : 1; }
+        const bool multi = use_flags && multi_flag;
+        if (!multi) HIP_TRY(c, raise(s1, (int)J, F_PANEL));
         // GPRN_SPLIT_REST=1 (default): the previous panel's "rest" went out as two launches and only the first (A: the
         // tiles this panel's outer update writes again) is waited for here; "next" runs on a stream of its own instead
         // of queueing behind the previous panel's whole "rest" on the bulk stream.  0: one launch, one stream.
@@ -1550,8 +1582,17 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // 64 tile steps by default, GPRN_SPLIT_REST=2 forces it)
         const bool sr = sr_all;
         hipStream_t sn = sr ? c->stream4 : s2;
+        if (multi) {
+            // F_PANEL up, then the two waits, in ONE kernel on stream3 (three operations, 13 us, before)
+            FlagOps ops = {{slot((int)J, F_PANEL) + 1, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+            if (rest_J >= 0) ops.wait[0] = slot(rest_J, sr ? F_RESTA : F_REST) + 1;
+            if (next_J >= 0) { ops.wait[1] = slot(next_J, F_NEXT) + 1; next_J = -1; }
+            hipLaunchKernelGGL(k_flag_multi, dim3(1), dim3(64), 0, s1, ops, epoch, timed_out);
+            HIP_TRY(c, hipGetLastError());
+        } else {
         if (rest_J >= 0) HIP_TRY(c, await(s1, rest_J, sr ? F_RESTA : F_REST));      // same tiles as the previous panel's rest / next
         if (next_J >= 0) { HIP_TRY(c, await(s1, next_J, F_NEXT)); next_J = -1; }
+        }
         // the first panel's update forms the tiles of B it touches from K (run_phase built only the others)
         struct FtScope { gprn_ctx* c; ~FtScope() { c->ft_s_now = nullptr; } } ft_scope{c};
         c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
@@ -1560,7 +1601,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if ((rc = tiles(o.fb0, o.nfb, s1, shape_upd(o.nfb), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         } else if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         if (o.k1 < c->T) side_stamp(o.k1, 7);
-        HIP_TRY(c, raise(s1, (int)J, F_FIRST));
+        // F_FIRST: by the first workgroup of the next launch on stream3 when that is a panel launch with the
+        // synchronisation folded in (below), else a stream write
+        if (multi && folds_sync(o.k1)) pending_up = slot((int)J, F_FIRST) + 1;
+        else HIP_TRY(c, raise(s1, (int)J, F_FIRST));
         if (o.nfirst > 0) first_J = (int)J;
         // GPRN_FIRST_ALONE=n (experiments; default 0): with up to n matrices "next", "ahead" and "bulk" start behind "first"
         // instead of beside it.  stream3 cannot go on with the new panel before "first" is through -- the in-kernel stamps
@@ -1722,15 +1766,26 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;    // the previous panel's trailing update
             // beside it: the rest of the panel, then the rest of the in-panel updates
             side_stamp(k, 0);
-            if ((rc = side_sync(k))) return rc;
+            const bool fold_sync = folds_sync(k);
+            if (!fold_sync) {
+                if (pending_up) { HIP_TRY(c, hipStreamWriteValue32(s1, pending_up, epoch, 0)); pending_up = nullptr; }
+                if ((rc = side_sync(k))) return rc;
+            }
             side_stamp(k, 1);
-            // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
-            static int merge_panel = -1;
-            if (merge_panel < 0) { const char* e = getenv("GPRN_MERGE_PANEL"); merge_panel = e ? atoi(e) : 1; }
             if (merge_panel && tri && use_flags) {
                 // (its last workgroup holds the launch open until L_{k+1,k} is there, see x_part_then)
+                unsigned* up = nullptr;
+                unsigned* up2 = nullptr;
+                Await aw_d = noaw;
+                if (fold_sync) {
+                    if (inner_k >= 0 && !withheld(F_INNER)) up = slot(inner_k, F_INNER) + 1;
+                    inner_k = -1;
+                    up2 = pending_up;
+                    pending_up = nullptr;
+                    aw_d = in_kernel_wait(k, F_DIAG);
+                }
                 if ((rc = launch_panel(c, c->d_tasks + s.panel0 + 1, s.npanel_l - 1, s.npanel - s.npanel_l, c->d_ptrs,
-                                       nbatch, c->ld, s1, x_part_then(k)))) return rc;
+                                       nbatch, c->ld, s1, x_part_then(k), aw_d, up, epoch, up2))) return rc;
             } else {
                 if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
                 if (s.npanel > s.npanel_l && use_flags) {
@@ -1809,14 +1864,29 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         pending_outer = (int)J;
     }
     if (pending_outer >= 0 && (rc = do_outer(pending_outer))) return rc;
+    if (pending_up) { HIP_TRY(c, hipStreamWriteValue32(s1, pending_up, epoch, 0)); pending_up = nullptr; }
+    if (tail_on_s2) HIP_TRY(c, raise(s2, 0, F_TAIL));
+    static int multi_end = -1;
+    if (multi_end < 0) { const char* e = getenv("GPRN_MULTI_FLAG"); multi_end = e ? atoi(e) : 1; }
+    if (use_flags && multi_end && !(left && last_grp >= 0)) {
+        // the chain stream joins the others in ONE kernel (up to four stream waits before)
+        FlagOps ops = {{nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        int nw = 0;
+        if (first_J >= 0) ops.wait[nw++] = slot(first_J, F_FIRST) + 1;
+        if (next_J >= 0) ops.wait[nw++] = slot(next_J, F_NEXT) + 1;
+        if (rest_J >= 0) ops.wait[nw++] = slot(rest_J, F_REST) + 1;
+        if (tail_on_s2) ops.wait[nw++] = slot(0, F_TAIL) + 1;
+        if (nw) {
+            hipLaunchKernelGGL(k_flag_multi, dim3(1), dim3(64), 0, s0, ops, epoch, timed_out);
+            HIP_TRY(c, hipGetLastError());
+        }
+        return GPRN_OK;
+    }
     if (first_J >= 0) HIP_TRY(c, await(s0, first_J, F_FIRST));
     if (next_J >= 0) HIP_TRY(c, await(s0, next_J, F_NEXT));
     if (left && last_grp >= 0) HIP_TRY(c, await(s0, last_grp, F_NEXT));
     if (rest_J >= 0) HIP_TRY(c, await(s0, rest_J, F_REST));
-    if (tail_on_s2) {
-        HIP_TRY(c, raise(s2, 0, F_TAIL));
-        HIP_TRY(c, await(s0, 0, F_TAIL));
-    }
+    if (tail_on_s2) HIP_TRY(c, await(s0, 0, F_TAIL));
     return GPRN_OK;
 }
 

@@ -127,8 +127,16 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 __global__ __launch_bounds__(256, 2)
 void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                  unsigned* wait_timed_out)
+                  unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value,
+                  unsigned* start_flag, unsigned start_value, unsigned* start_flag2)
 {
+    // (launch_panel: stream3's synchronisation folded into the launch -- the flags of the launches before this one on the
+    // stream go up here, and every workgroup waits for the diagonal block itself)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        if (start_flag) __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (start_flag2) __hip_atomic_store(start_flag2, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    await_flag(wait_flag, wait_value, wait_timed_out);
     __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (64 + 128 + 32)];
     const int ti = blockIdx.x >> 1, sub = blockIdx.x & 1;
     const TileTask t = tasks[ti];
@@ -155,7 +163,7 @@ __global__ void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double
                              unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value);     // the same panel at 16-row / 16-column granularity, below
 
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
-                 hipStream_t stream, Signal sig)
+                 hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start, unsigned raise_value, unsigned* raise_at_start2)
 {
     if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig);
     // GPRN_PANEL_ROWS=1 (experiments): k_panel_rows, 16-row / 16-column workgroups like the chain's kernels.  Slower:
@@ -170,7 +178,8 @@ int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, d
                            (const unsigned*)nullptr, 0u);
     else
     hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
-                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out);
+                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
+                       aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value, raise_at_start, raise_value, raise_at_start2);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

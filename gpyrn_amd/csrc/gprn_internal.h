@@ -346,7 +346,8 @@ int launch_grad_fd(gprn_ctx* c, const KernelSpec& ks, const double* Kinv, const 
                    double* part, double* out);
 // the L part (n_l tasks) and the X part (n_x tasks) of a tile step's panel in one launch (gemm_tile.hip)
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
-                 hipStream_t stream, Signal sig);
+                 hipStream_t stream, Signal sig, Await aw = Await{nullptr, 0, nullptr, nullptr, 0},
+                 unsigned* raise_at_start = nullptr, unsigned raise_value = 0, unsigned* raise_at_start2 = nullptr);
 // block schedule: the in-block panel of a tile step at 16-row / 16-column granularity; C = A^T over a list of tiles
 int launch_panel_rows(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                       hipStream_t stream, Signal sig, Await aw);
