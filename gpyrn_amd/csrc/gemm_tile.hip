@@ -57,8 +57,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map,
-                 const unsigned* wait_flag2, unsigned wait_value2, const double* ft_s, int ft_n)
+                 const unsigned* wait_flag2, unsigned wait_value2, const double* ft_s, int ft_n,
+                 unsigned* start_flag, unsigned start_value)
 {
+    // (gprn_ctx::start_flag_now: the flag of the launch before this one on the stream -- in memory once a workgroup of
+    // this launch runs -- instead of a stream write, a 4.5 us kernel of its own, between the two)
+    if (start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
     constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
@@ -618,7 +623,7 @@ static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doub
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
                        sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map(),
-                       aw.flag2, aw.value2, c->ft_s_now, c->N);
+                       aw.flag2, aw.value2, c->ft_s_now, c->N, c->start_flag_now, c->start_value_now);
     return true;
 }
 

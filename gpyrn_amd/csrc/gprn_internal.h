@@ -238,6 +238,8 @@ struct gprn_ctx {
     // GPRN_STEP_STAMPS=1 (probes): per tile step and chain kernel (diag, L, U) the 100 MHz clock at its start, after its
     // wait and at its end -- the launch schedule's chain as it really ran (a kernel trace slows the chain's small
     // kernels by 15 %); [phase slot][T][3 kernels][3 stamps], printed by factor_check_waits
+    unsigned* start_flag_now = nullptr;            // launch_tiles: a flag word the next tile launch sets to start_value_now when its
+    unsigned start_value_now = 0;                  // first workgroup runs (the flag of the launch BEFORE it on its stream)
     unsigned long long* d_step_stamps = nullptr;
     int step_stamps_T = 0, step_stamps_n = 0;
     int step_stamps_batch[8] = {0};
