@@ -237,6 +237,9 @@ static void free_problem(gprn_ctx* c)
     dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
     dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
     dev_free(c->d_cs); dev_free(c->d_ct); dev_free(c->d_part);
+    if (c->d_fin_terms) hipFree(c->d_fin_terms);
+    if (c->d_fin_tickets) hipFree(c->d_fin_tickets);
+    c->d_fin_terms = nullptr; c->d_fin_tickets = nullptr;
     dev_free(c->d_scal_base); c->d_scal = nullptr; dev_free(c->d_elbo_part); dev_free(c->d_out); dev_free(c->d_info);
     c->d_ptrs = nullptr;
     c->nslot = 0; c->out_cap = 0;
@@ -887,6 +890,9 @@ static int build_tables(gprn_ctx* c)
         dev_free(c->d_slotgp_node); dev_free(c->d_slotgp_weight); dev_free(c->d_slotgp_setup);
         dev_free(c->d_d); dev_free(c->d_s); dev_free(c->d_pred); dev_free(c->d_z); dev_free(c->d_u);
         dev_free(c->d_cs); dev_free(c->d_ct); dev_free(c->d_part); dev_free(c->d_info);
+        if (c->d_fin_terms) hipFree(c->d_fin_terms);
+        if (c->d_fin_tickets) hipFree(c->d_fin_tickets);
+        c->d_fin_terms = nullptr; c->d_fin_tickets = nullptr;
         const size_t tab = (size_t)want * GPRN_NBUF, vec = (size_t)want * c->ld;
         TRY(dev_alloc(c, &c->tab_node, tab)); TRY(dev_alloc(c, &c->tab_weight, tab));
         TRY(dev_alloc(c, &c->tab_setup, tab));
@@ -1090,9 +1096,15 @@ static int run_phase(gprn_ctx* c, bool weights)
         TRY(rc_f);
         TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, nullptr, rd * GPRN_TILE, -1));
         TRY(vec_colops_partial(c, ns, nullptr, rd, -1));
+        // GPRN_FUSED_FINALIZE=0: the column sums' reduction and the finalisation as two launches (the second one workgroup per GP)
+        static int fused_fin = -1;
+        if (fused_fin < 0) { const char* e = getenv("GPRN_FUSED_FINALIZE"); fused_fin = e ? atoi(e) : 1; }
+        if (fused_fin && (overlap & 8)) TRY(vec_reduce_finalize(c, slotgp, ns, true));
+        else {
         TRY(vec_colops_reduce(c, ns));
         if (!(overlap & 8)) TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
         TRY(vec_finalize(c, slotgp, ns, (overlap & 8) != 0));      // + log det B
+        }
         if (c->keep_sigma) {
             const size_t nn = (size_t)c->ld * c->ld;
             TRY(lauum_lower(c, ns));
@@ -1269,6 +1281,11 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         TRY(upload_table(c, c->tab_node2, rows));
     }
     c->q1_work = nullptr;
+    bool scal_cleared = false;
+    if (!comm_active(c)) {
+        HIP_TRY(c, hipMemsetAsync(c->d_scal_base, 0, 2 * nscal * sizeof(double), c->stream));
+        scal_cleared = true;
+    }
     for (int it = 0; it < n_sweeps; ++it) {
         c->node_alt = alt_ok && (((n_sweeps - 1 - it) & 1) != 0);
         c->defer_sweep_end = alt_ok && it + 1 < n_sweeps;
@@ -1276,7 +1293,9 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         double* const part = c->d_elbo_part + (size_t)(it & 1) * GPRN_ELBO_PART_DOUBLES;
         c->d_scal = scal;
         c->d_logdetB = scal; c->d_trBinv = scal + c->G; c->d_muKmu = scal + 2 * (size_t)c->G; c->d_q1 = scal + 3 * (size_t)c->G;
-        HIP_TRY(c, hipMemsetAsync(scal, 0, nscal * sizeof(double), c->stream));
+        // (every entry a sweep reads it has written itself, with '=': the two copies are cleared once per call, above; on a
+        // sharded context the all-reduce leaves the other ranks' entries behind, so there it is cleared every sweep)
+        if (comm_active(c) || !scal_cleared) HIP_TRY(c, hipMemsetAsync(scal, 0, nscal * sizeof(double), c->stream));
         c->node_term_done = false;
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));

@@ -1732,6 +1732,14 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
             if (s.npanel_l == 0) {
                 // last tile step of the matrix: row k of the inverse is all that is left
                 if ((rc = flush_inner())) return rc;
+                // (its workgroups wait for stream3's last update themselves: a stream wait is a 5 us kernel of its own
+                // on the chain stream, and the flag is up or about to be when they start; GPRN_LAST_WAIT=0: the stream wait)
+                static int last_wait = -1;
+                if (last_wait < 0) { const char* e = getenv("GPRN_LAST_WAIT"); last_wait = e ? atoi(e) : 1; }
+                if (k > 0 && use_flags && last_wait) {
+                    if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64, GPRN_T_PANEL, nosig, in_kernel_wait(k - 1, F_INNER)))) return rc;
+                    continue;
+                }
                 if (k > 0) HIP_TRY(c, await(s0, k - 1, F_INNER));
                 if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64))) return rc;
                 continue;

@@ -196,6 +196,8 @@ struct gprn_ctx {
     double *d_d = nullptr, *d_s = nullptr, *d_pred = nullptr, *d_w = nullptr,
            *d_z = nullptr, *d_u = nullptr, *d_cs = nullptr, *d_ct = nullptr;
     double* d_part = nullptr;        // partial column sums scratch [nslot][T][2][ld]
+    double* d_fin_terms = nullptr;   // k_reduce_finalize: per-element terms of tr B^-1 and log det B [nslot][2][ld]
+    unsigned* d_fin_tickets = nullptr;   // ... and its per-slot ticket counters (zero between launches)
     // per-GP scalars of the running sweep, one allocation (all-reduced as one message):
     // logdetB[G], trBinv[G], muKmu[G], Q1 traces [q*q]
     double* d_scal = nullptr;        // (two copies: a sweep's ELBO assembly may run beside the next sweep, sweep_impl)

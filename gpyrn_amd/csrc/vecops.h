@@ -13,6 +13,7 @@ int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, in
 int vec_colops(gprn_ctx* c, int nslots);                 // partial sums of every tile row + the reduction
 int vec_colops_partial(gprn_ctx* c, int nslots, hipStream_t stream, int ch0, int nch);   // tile rows [ch0, ch0 + nch)
 int vec_colops_reduce(gprn_ctx* c, int nslots);
+int vec_reduce_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet);   // vec_colops_reduce + vec_finalize in one launch
 int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet = false);   // with_logdet: log det B from BUF_B too
 int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double* s_k,
            double* scratch, double* out_scalar, hipStream_t stream);

@@ -297,6 +297,65 @@ void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
     }
 }
 
+// k_colops_reduce and k_finalize in one launch of ld / 256 workgroups per GP (16 at N = 4096) instead of two launches, the
+// second of ONE workgroup per GP whose threads walk 16 elements each through a dependent chain of loads, a strided
+// diagonal read, a log and two divisions (21-25 us at the end of every phase, on the chain stream, with nothing beside
+// it).  A thread owns one element: column sums in k_colops_reduce's order, mu / var, and the element's two terms of
+// tr B^-1 and log det B go to `terms`; the LAST workgroup of a GP to finish (ticket counter, reset by it) adds them up
+// exactly as k_finalize's threads did -- thread t: n = t, t + 256, ... in turn, then block_sum -- so both scalars keep
+// their bits.
+__global__ __launch_bounds__(256)
+void k_reduce_finalize(const int* __restrict__ slot_gp, int N, int ld, int T, int p, int q,
+                       const double* __restrict__ part, const double* __restrict__ d, const double* __restrict__ s,
+                       const double* __restrict__ z, double* __restrict__ cs, double* __restrict__ ct,
+                       double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv,
+                       double* const* __restrict__ ptrs, double* __restrict__ logdetB,
+                       double* __restrict__ terms /* [slot][2][ld] */, unsigned* __restrict__ tickets /* [slot] */)
+{
+    __shared__ double sh[4];
+    __shared__ unsigned last;
+    const int slot = blockIdx.y, gp = slot_gp[slot], n = blockIdx.x * 256 + threadIdx.x;
+    size_t row;
+    if (gp < q) row = gp;
+    else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
+    const double* Lm = ptrs ? ptrs[(size_t)slot * GPRN_NBUF + BUF_B] : nullptr;
+    double* const tt = terms + (size_t)slot * 2 * ld;
+    if (n < ld) {
+        double a = 0.0, b = 0.0;
+        for (int ch = n >> 7; ch < T; ++ch) {
+            const size_t o = (((size_t)slot * T + ch) * 2) * ld + n;
+            a += part[o];
+            b += part[o + ld];
+        }
+        const size_t o = (size_t)slot * ld + n;
+        cs[o] = a;
+        ct[o] = b;
+        if (n < N) {
+            mu[row * N + n] = (z[o] - b) / s[o];
+            var[row * N + n] = (1.0 - a) / d[o];
+            tt[n] = a;
+            if (Lm) tt[ld + n] = log(Lm[(size_t)n * ld + n]);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(tickets + slot, 1u) + 1 == gridDim.x ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;                              // (uniform)
+    __threadfence();
+    double tr = 0.0, ld_acc = 0.0;
+    for (int m = threadIdx.x; m < N; m += 256) {
+        tr += __hip_atomic_load(tt + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (Lm) ld_acc += __hip_atomic_load(tt + ld + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tr = block_sum(tr, sh);
+    if (threadIdx.x == 0) { trBinv[gp] = tr; atomicExch(tickets + slot, 0u); }
+    if (Lm) {
+        ld_acc = block_sum(ld_acc, sh);
+        if (threadIdx.x == 0) logdetB[gp] = 2.0 * ld_acc;
+    }
+}
+
 // rowsum[m] = sum_{n<=m} w(m,n) Kinv[m][n] (delta_mn - Binv[m][n]) / (s_m s_n), w = 2 off-diagonal
 __global__ __launch_bounds__(256)
 void k_q1_rows(const double* __restrict__ Kinv, const double* __restrict__ Binv, int N, int ld,
@@ -508,6 +567,24 @@ int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet
     hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                        c->p, c->q, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
                        c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB);
+    LAUNCH_END(c);
+}
+
+// vec_colops_reduce + vec_finalize (with log det B) in one launch
+int vec_reduce_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet)
+{
+    if (!nslots) return GPRN_OK;
+    if (!c->d_fin_terms) {
+        HIP_TRY(c, hipMalloc(&c->d_fin_terms, (size_t)c->nslot * 2 * c->ld * sizeof(double)));
+        HIP_TRY(c, hipMalloc(&c->d_fin_tickets, (size_t)c->nslot * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_fin_tickets, 0, (size_t)c->nslot * sizeof(unsigned)));
+    }
+    prof_begin(c, GPRN_T_VEC);
+    const size_t o = (size_t)c->slot0 * c->ld, po = (size_t)c->slot0 * c->T * 2 * c->ld;
+    hipLaunchKernelGGL(k_reduce_finalize, dim3((c->ld + 255) / 256, nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld, c->T,
+                       c->p, c->q, c->d_part + po, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
+                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB,
+                       c->d_fin_terms + (size_t)c->slot0 * 2 * c->ld, c->d_fin_tickets + c->slot0);
     LAUNCH_END(c);
 }
 
