@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace --output-format csv -d DIR -o runc -- python3 bench.py --no-cpu --no-calc --steps 6 --warmup 2 --blocks 1
     python3 profiles/phase_timeline.py DIR [sweep_index] [--kernels]
 
-A sweep = k_prep_nodes ... k_elbo_final.  Per phase (node / weight half-sweep): head (prep start -> first diagonal
+A sweep = k_prep_nodes ... the next k_prep_nodes (the last sweep of a call: ... its k_elbo_final).  Per phase (node / weight half-sweep): head (prep start -> first diagonal
 block starts), factorisation (first diagonal block -> last chain kernel ends), tail (-> the next phase's prep /
 k_elbo_final ends); with --kernels every kernel of head and tail with its start / end relative to the phase start.
 """
@@ -29,11 +29,20 @@ def idx(name):
 
 pn, pw, ef = idx('k_prep_nodes'), idx('k_prep_weights'), idx('k_elbo_final')
 sweeps = []
-for a in pn:
+for n, a in enumerate(pn):
+    # (a sweep's ELBO assembly may run beside the NEXT sweep's node phase -- option "overlap", bit 16 -- so the weight
+    # phase is taken to end where the next sweep's preparation starts; the last sweep of a call ends with its k_elbo_final)
     w = [i for i in pw if i > a]
-    e = [i for i in ef if i > a]
-    if w and e and w[0] < e[0]:
-        sweeps.append((a, w[0], e[0]))
+    nxt = pn[n + 1] if n + 1 < len(pn) else None
+    if not w or (nxt is not None and w[0] > nxt):
+        continue
+    if nxt is None or rows[nxt][0] - rows[w[0]][0] > 50e6:          # the next call's sweep: close with this call's last k_elbo_final
+        e = [i for i in ef if i > w[0] and (nxt is None or i < nxt)]
+        if not e:
+            continue
+        sweeps.append((a, w[0], e[-1]))
+    else:
+        sweeps.append((a, w[0], nxt - 1))
 print('%d kernels, %d sweeps' % (len(rows), len(sweeps)))
 CHAIN = ('k_diag_block', 'k_chain_l', 'k_chain_u', 'k_chain_step')
 
