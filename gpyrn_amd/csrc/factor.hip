@@ -988,6 +988,32 @@ int ensure_tasks(gprn_ctx* c)
                 ls.nu = v.size() - ls.u0;
             }
         }
+        // ---- "first" and "next" column by column (GPRN_EAGER_NEXT): at step k of the panel, behind its panel products,
+        // column k's K = 128 share of the update of the next panel's columns / rows (and of the panel after next's diagonal
+        // and sub-diagonal tiles) -- the same tiles, the same additions in the same order as the K = 512 launches at the
+        // panel boundary, three quarters of them before the boundary
+        if (set == 0) {
+            if (c->esteps.size() != (size_t)T) c->esteps.assign(T, gprn_ctx::EStep{0, 0});
+            const int n1e = std::min(T, k1 + outer), n2e = std::min(T, n1e + outer);
+            for (int k = k0; k < k1; ++k) {
+                gprn_ctx::EStep& es = c->esteps[k];
+                es.e0 = v.size();
+                const uint8_t ft = (k == 0) ? 32 : 0;                      // the first panel's first column: first touch
+                for (int j = k1; j < n1e; ++j)
+                    for (int i = j + 2; i < T; ++i)
+                        v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                             BUF_B, BUF_B, BUF_B, (uint8_t)(tile_modes(CM_SUB, 0, 0) | ft)});
+                for (int j = n1e; j < n2e; ++j)
+                    for (int i = j; i < std::min(T, j + 2); ++i)
+                        v.push_back(TileTask{toff(i, j, ld), toff(i, k, ld), toff(j, k, ld), GPRN_TILE,
+                                             BUF_B, BUF_B, BUF_B, (uint8_t)(tile_modes(CM_SUB, 0, 0, lower_diag && i == j) | ft)});
+                for (int i = k1; i < n1e; ++i)
+                    for (int cc = 0; cc <= k; ++cc)
+                        v.push_back(TileTask{toff(i, cc, ld), toff(i, k, ld), toff(k, cc, ld), GPRN_TILE,
+                                             BUF_X, BUF_B, BUF_X, tile_modes(cc == k ? CM_SETNEG : CM_SUB, 0, 1)});
+                es.ne = v.size() - es.e0;
+            }
+        }
         gprn_ctx::OuterRange o{k0, k1, 0, 0, 0, 0, 0, 0, 0, 0, 0, {0}, {0}, 0, 0, 0, 0};
         const int kw = (k1 - k0) * GPRN_TILE;
         const int n1 = std::min(T, k1 + outer);   // the next panel is tiles [k1, n1)
@@ -1438,8 +1464,10 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     };
     // the X part of the panel is a small launch: its last workgroup holds it open until L_{k+1,k} is
     // there, so the in-panel updates behind it need no stream wait
+    bool eager = false;                            // (set below: GPRN_EAGER_NEXT)
     auto x_part_then = [&](int k) {
-        return use_flags ? Signal{slot(k, F_XW), 0, slot(k, F_MINIL) + 1, epoch, timed_out}
+        // (eager: F_XW goes up when the panel products are in memory -- the next-panel stream waits for it)
+        return use_flags ? Signal{slot(k, F_XW), eager ? epoch : 0u, slot(k, F_MINIL) + 1, epoch, timed_out}
                          : Signal{nullptr, 0, nullptr, 0, nullptr};
     };
     const Await noaw{nullptr, 0, nullptr};
@@ -1557,6 +1585,12 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (panel_sync < 0) { const char* e = getenv("GPRN_PANEL_SYNC"); panel_sync = e ? atoi(e) : 2; }
     // GPRN_MERGE_PANEL=0: the two halves of the panel as two launches (the form of round 1)
     if (merge_panel < 0) { const char* e = getenv("GPRN_MERGE_PANEL"); merge_panel = e ? atoi(e) : 1; }
+    // GPRN_EAGER_NEXT=n (experiments; default 0): with up to n matrices the next panel's share of an outer update is applied
+    // column by column on the next-panel stream (ensure_tasks: esteps) instead of as "first" + "next" at the boundary
+    static int eager_next = -1;
+    if (eager_next < 0) { const char* e = getenv("GPRN_EAGER_NEXT"); eager_next = e ? atoi(e) : 0; }
+    eager = use_flags && set == 0 && !left && !use_chain && !persist && !split_first && sr_all && merge_panel && tri &&
+            nbatch <= eager_next && c->esteps.size() == (size_t)c->T;
     auto folds_sync = [&](int k) {                 // tile step k's panel launch takes stream3's synchronisation along
         if (k < 0 || k >= c->T || use_chain) return false;
         const gprn_ctx::StepRange& sk = c->steps[set][k];
@@ -1582,11 +1616,13 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // 64 tile steps by default, GPRN_SPLIT_REST=2 forces it)
         const bool sr = sr_all;
         hipStream_t sn = sr ? c->stream4 : s2;
+        const bool eager_J = eager && o.k1 < c->T;     // this panel's "first" + "next" went out column by column
         if (multi) {
             // F_PANEL up, then the two waits, in ONE kernel on stream3 (three operations, 13 us, before)
             FlagOps ops = {{slot((int)J, F_PANEL) + 1, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
             if (rest_J >= 0) ops.wait[0] = slot(rest_J, sr ? F_RESTA : F_REST) + 1;
             if (next_J >= 0) { ops.wait[1] = slot(next_J, F_NEXT) + 1; next_J = -1; }
+            if (eager_J) ops.wait[2] = slot((int)J, F_NEXT) + 1;          // (raised behind the panel's last column's share)
             hipLaunchKernelGGL(k_flag_multi, dim3(1), dim3(64), 0, s1, ops, epoch, timed_out);
             HIP_TRY(c, hipGetLastError());
         } else {
@@ -1597,15 +1633,17 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         struct FtScope { gprn_ctx* c; ~FtScope() { c->ft_s_now = nullptr; } } ft_scope{c};
         c->ft_s_now = (o.k0 == 0 && ft_fused) ? c->ft_s_phase : nullptr;
         if (o.k1 < c->T) side_stamp(o.k1, 6);          // (stamps of the NEXT panel's first step: behind the waits, behind "first")
-        if (first_a_done == (int)J) {
+        if (eager_J) { /* nothing left of "first" */ }
+        else if (first_a_done == (int)J) {
             if ((rc = tiles(o.fb0, o.nfb, s1, shape_upd(o.nfb), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         } else if ((rc = tiles(o.first0, o.nfirst, s1, shape_upd(o.nfirst), GPRN_T_PANEL, nosig, noaw, TG_NEXT))) return rc;
         if (o.k1 < c->T) side_stamp(o.k1, 7);
         // F_FIRST: by the first workgroup of the next launch on stream3 when that is a panel launch with the
         // synchronisation folded in (below), else a stream write
-        if (multi && folds_sync(o.k1)) pending_up = slot((int)J, F_FIRST) + 1;
+        if (eager_J) { /* no F_FIRST: nothing waits for it */ }
+        else if (multi && folds_sync(o.k1)) pending_up = slot((int)J, F_FIRST) + 1;
         else HIP_TRY(c, raise(s1, (int)J, F_FIRST));
-        if (o.nfirst > 0) first_J = (int)J;
+        if (o.nfirst > 0 && !eager_J) first_J = (int)J;
         // GPRN_FIRST_ALONE=n (experiments; default 0): with up to n matrices "next", "ahead" and "bulk" start behind "first"
         // instead of beside it.  stream3 cannot go on with the new panel before "first" is through -- the in-kernel stamps
         // (GPRN_STEP_STAMPS=2) show it there for 90-100 us with two matrices, the other launches taking the CUs at the same
@@ -1613,7 +1651,9 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         // (60 us instead of 30): 110.6 sweeps/s at config 3 either way
         static int first_alone = -1;
         if (first_alone < 0) { const char* e = getenv("GPRN_FIRST_ALONE"); first_alone = e ? atoi(e) : 0; }
-        const int gate_kind = (use_flags && o.nfirst > 0 && nbatch <= first_alone) ? F_FIRST : F_PANEL;
+        const int gate_kind = (use_flags && o.nfirst > 0 && nbatch <= first_alone && !eager_J) ? F_FIRST : F_PANEL;
+        if (eager_J) { /* "next" is done */ }
+        else {
         if (multi && sr && rest_J >= 0) {          // both waits of the "next" stream in one kernel
             FlagOps ops = {{nullptr, nullptr}, {slot((int)J, gate_kind) + 1, slot(rest_J, F_RESTA) + 1, nullptr, nullptr}};
             hipLaunchKernelGGL(k_flag_multi, dim3(1), dim3(64), 0, sn, ops, epoch, timed_out);
@@ -1636,6 +1676,7 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
         HIP_TRY(c, raise(sn, (int)J, F_NEXT));
         if (o.nnext > 0) next_J = (int)J;
         }
+        }   // !eager_J
         if (o.nrest) {
             // GPRN_BULK_SHAPE: workgroup shape of the bulk (TS_128x128 = 0: eight waves, two workgroups per
             // CU; TS_64x64 = 1: four per task, short-lived, leaves room on every CU for the chain's kernels)
@@ -1807,6 +1848,21 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 }
                 if ((rc = launch_panel(c, c->d_tasks + s.panel0 + 1, s.npanel_l - 1, s.npanel - s.npanel_l, c->d_ptrs,
                                        nbatch, c->ld, s1, x_part_then(k), aw_d, up, epoch, up2))) return rc;
+                if (eager && o.k1 < c->T && c->esteps[k].ne > 0) {
+                    // column k's share of the next panel's update, on the next-panel stream, as soon as column k of L and
+                    // row k of X are there (the panel's first column also behind the previous panel's "ahead" launch,
+                    // which wrote the same tiles)
+                    const gprn_ctx::EStep& es = c->esteps[k];
+                    FlagOps ops = {{nullptr, nullptr}, {slot(k, F_XW) + 1, slot(k, F_MINIL) + 1, nullptr, nullptr}};
+                    if (k == o.k0 && rest_J >= 0) ops.wait[2] = slot(rest_J, F_RESTA) + 1;
+                    hipLaunchKernelGGL(k_flag_multi, dim3(1), dim3(64), 0, c->stream4, ops, epoch, timed_out);
+                    HIP_TRY(c, hipGetLastError());
+                    c->ft_s_now = (k == 0 && ft_fused) ? c->ft_s_phase : nullptr;
+                    rc = tiles(es.e0, es.ne, c->stream4, TS_64x64, GPRN_T_PANEL, nosig, noaw, TG_NEXT);
+                    c->ft_s_now = nullptr;
+                    if (rc) return rc;
+                    if (k == o.k1 - 1) HIP_TRY(c, raise(c->stream4, (int)J, F_NEXT));
+                }
             } else {
                 if ((rc = tiles(s.panel0 + 1, s.npanel_l - 1, s1, TS_64x128))) return rc;
                 if (s.npanel > s.npanel_l && use_flags) {

@@ -272,6 +272,10 @@ struct gprn_ctx {
     // the panel has produced so far (K = 128 (k + 1 - k0)) instead of every remaining column with column k alone
     struct LStep { size_t u0, nu, ncrit; };
     std::vector<LStep> lsteps;
+    // the NEXT panel's share of an outer update column by column (GPRN_EAGER_NEXT; throughput set): step k's K = 128
+    // contribution to what "first" and "next" update with K = 512 at the panel boundary
+    struct EStep { size_t e0, ne; };
+    std::vector<EStep> esteps;
     struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA;
                         size_t grp0[GPRN_OUTER], ngrp[GPRN_OUTER];
                         size_t fa0, nfa, fb0, nfb; };   // "first" in two parts: all but the panel's last column (early), the last column   // "next" by column / row of the next panel (1 .. GPRN_OUTER - 1)  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)

@@ -420,13 +420,14 @@ def test_schedule_and_kernel_variants_agree(env, tmp_path):
                                  {'GPRN_FIRST_ALONE': '8'}, {'GPRN_FLAGS': '0', 'GPRN_LEFT': '1'},
                                  {'GPRN_MULTI_FLAG': '0', 'GPRN_MINIL_BY_U': '0', 'GPRN_LAST_WAIT': '0', 'GPRN_FUSED_FINALIZE': '0',
                                   'GPRN_PANEL_SYNC': '0'},
-                                 {'GPRN_PANEL_SYNC': '16'}],
+                                 {'GPRN_PANEL_SYNC': '16'}, {'GPRN_EAGER_NEXT': '16'}],
                          ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
 def test_throughput_schedule_variants_agree(env, tmp_path):
     """Round 3's switches of the throughput schedule (outer panels of four tiles: needs more than 32 batch x tiles) -- the
     left-looking in-panel updates with the next-panel update in groups, the two-part "first" update, the block schedule,
     the overlap masks, "first" alone, the flag operations as stream operations of their own (the form before the round's
-    last session) and stream3's synchronisation folded into the panel launch for EVERY batch size -- each in a process of
+    last session), stream3's synchronisation folded into the panel launch for EVERY batch size and the next panel's share
+    of an outer update applied column by column -- each in a process of
     its own against the golden values of BASELINE config 5's
     shape at N = 2048 (T = 16, three nodes and twelve weights: four outer panels per factorisation)."""
     tag = 'cfg5shape_N2048'
