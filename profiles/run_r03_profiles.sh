@@ -33,6 +33,7 @@ if [ "$PART" = "b" ]; then
 # --- the other configs on one GPU, the two-rank rehearsal
 timeout -k 10 300 python bench.py --no-cpu --config 2 > $O/r03_bench_cfg2.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --no-cpu --no-calc --config 4 --blocks 5 > $O/r03_bench_cfg4_one_gpu.json 2>> $O/bench.err
+timeout -k 10 1000 python bench.py --no-cpu --no-calc --config 5 --steps 5 --warmup 1 --blocks 3 > $O/r03_bench_cfg5_one_gpu.json 2>> $O/bench.err
 GPRN_COMM_TRANSPORT=shm timeout -k 10 300 python3 bench.py --gpus 2 --no-cpu --no-calc --blocks 5 > $O/r03_bench_selflaunch_2ranks_shm.json 2>> $O/bench.err
 # --- the dataflow schedule (opt-in): the bench line, worker statistics, a timeline of two sweeps, the contraction rate
 GPRN_QUEUE=1 GPRN_QUEUE_STATS=1 timeout -k 10 300 python bench.py --no-cpu --no-calc --blocks 5 > $O/r03_bench_dataflow_schedule.json 2> $O/r03_dataflow_worker_stats.txt
