@@ -161,6 +161,34 @@ def test_reference_own_inference_tests():
     np.testing.assert_allclose(e, e_ref, rtol=RTOL)
 
 
+@pytest.mark.parametrize('n,p,q', [(1, 1, 1), (2, 1, 1), (3, 2, 1), (5, 2, 2), (17, 1, 2), (127, 1, 1), (129, 2, 1), (257, 1, 1)])
+def test_elbocalc_at_sizes_around_the_tile_edges(n, p, q):
+    """Whole ELBOcalc at sizes that leave the padded tile almost empty, fill a block exactly but for one row, or start a
+    second tile with a single row (the factorisation runs on whole 128 x 128 tiles with identity padding; the fill works
+    in column pairs and 64 x 64 blocks): against the CPU oracle on the same seeded inputs -- "parity unpinned" by the
+    reference itself at these sizes, pinned through the oracle, which the golden vectors pin (test_oracle.py)."""
+    rng = np.random.RandomState(100 * n + 10 * p + q)
+    t = np.sort(rng.uniform(0.0, 60.0, n))
+    ys = [np.sin(0.3 * t + i) + 0.1 * rng.randn(n) for i in range(p)]
+    es = [0.05 + 0.05 * rng.rand(n) for _ in range(p)]
+    nodes = [covfunc.QuasiPeriodic(1.0, 20.0 + j, 11.0, 0.8) for j in range(q)]
+    weights = [covfunc.SquaredExponential(0.9 + 0.05 * k, 15.0 + k) for k in range(q * p)]   # node-major: j * p + i
+    means = [meanfunc.Constant(0.1 * i) for i in range(p)]
+    jit = [0.01] * p
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+    elbo, mu, var, it = g.ELBOcalc()
+    assert g.last_info == 0
+    y = np.array(ys)
+    Kf, Kw, Lf, Lw, yres, j2 = cpu_ref.setup(t, g.nodes, g.weights, g.means, g.jitters, y)
+    mu0, var0 = cpu_ref.init_mu_var(y, [k.pars[0] for k in g.nodes], [k.pars[0] for k in g.weights], g.jitters)
+    e_ref, mu_ref, var_ref, it_ref, _ = cpu_ref.elbo_calc(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu0, var0, form='ref')
+    assert it == it_ref
+    np.testing.assert_allclose(elbo, e_ref, rtol=RTOL)
+    np.testing.assert_allclose(mu, mu_ref, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var, var_ref, rtol=1e-6, atol=1e-10)
+
+
 def test_elboaux_shim_returns_sigma():
     meta, d, g = _model('step_p3q2')
     j2 = np.array(meta['jitters'])**2
