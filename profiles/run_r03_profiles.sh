@@ -28,6 +28,12 @@ python3 profiles/summarize_r02.py traffic $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > 
 ( cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_mfma -o runc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --blocks 1 --no-cpu --no-calc > $GRAFT_REPO_ROOT/$O/pmc_mfma.json 2>> $GRAFT_REPO_ROOT/$O/prof.err )
 python3 profiles/summarize_r02.py mfma $O/pmc_mfma > $O/r03_pmc_mfma_util.json
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_mfma
+# --- traffic of the covariance fill kernels (one set-up: 6 SE + 2 QP fills)
+for pmc in FETCH_SIZE WRITE_SIZE; do
+  ( cd /tmp && rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/pmcf_$pmc -o runc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --blocks 1 --no-cpu --no-calc > $GRAFT_REPO_ROOT/$O/pmcf_$pmc.json 2>> $GRAFT_REPO_ROOT/$O/prof.err )
+done
+python3 profiles/summarize_r02.py fill $O/pmcf_FETCH_SIZE $O/pmcf_WRITE_SIZE > $O/r03_pmc_fill.json
+rm -rf $O/pmcf_FETCH_SIZE $O/pmcf_WRITE_SIZE
 fi
 if [ "$PART" = "b" ]; then
 # --- the other configs on one GPU, the two-rank rehearsal

@@ -118,6 +118,27 @@ def traffic(df, dw):
     }, indent=1))
 
 
+def fill(df, dw):
+    """HBM traffic of the covariance fill kernels (k_fill_sym<2> SE, <4> QP) from a FETCH_SIZE and a WRITE_SIZE pass."""
+    def rows(d, counter):
+        out = {}
+        for r in csv.DictReader(open(_one(d, '*counter_collection.csv'))):
+            if r['Counter_Name'] == counter and 'k_fill_sym<' in r['Kernel_Name']:
+                kid = r['Kernel_Name'].split('k_fill_sym<')[1].split('>')[0]
+                out.setdefault(kid, []).append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+        return out
+    f, w = rows(df, 'FETCH_SIZE'), rows(dw, 'WRITE_SIZE')
+    res = {}
+    for kid in sorted(w):
+        wk = sum(x[0] for x in w[kid]) / len(w[kid])
+        fk = sum(x[0] for x in f.get(kid, [(0.0, 0.0)])) / max(1, len(f.get(kid, [])))
+        us = sum(x[1] for x in w[kid]) / len(w[kid])
+        res['k_fill_sym<%s>' % kid] = {'launches': len(w[kid]), 'write_size_kib_per_launch': wk, 'fetch_size_kib_raw_per_launch': fk,
+                                       'hbm_bytes_per_launch': (2 * fk + wk) * 1024, 'avg_launch_us_under_pmc': us}
+    print(json.dumps({'kernels': res, 'algorithmic_bytes_per_launch': '8 N^2 = 134217728 at N = 4096 (one write of the matrix)',
+                      'fetch_correction': 'x2 (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section)'}, indent=1))
+
+
 def mfma(d):
     names = ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_INSTS_VALU_MFMA_F64', 'GRBM_GUI_ACTIVE')
     c = {n: _bulk(d, n) for n in names}
@@ -142,4 +163,4 @@ def mfma(d):
 
 if __name__ == '__main__':
     what = sys.argv[1]
-    {'families': families, 'traffic': traffic, 'mfma': mfma, 'union': union}[what](*sys.argv[2:])
+    {'families': families, 'traffic': traffic, 'mfma': mfma, 'union': union, 'fill': fill}[what](*sys.argv[2:])
