@@ -391,6 +391,9 @@ def main():
             'full_elbocalc': calc,
             'independent_evaluations': pool,
             'elbo_last': float(elbo[-1]), 'info': int(info),
+            # which schedule produced the line: 1 = device-side flags (the default), 0 = HIP events; fallbacks = calls of this
+            # context that were re-run on events after an in-kernel wait timed out (0 in a healthy run)
+            'schedule': {'flags': int(ctx.option('flags')), 'fallbacks': int(ctx.option('fallbacks'))},
             'roofline': {
                 'kernel': 'k_tile_gemm<..., TG_BULK> (bulk trailing-update launches, K=512, v_mfma_f64_16x16x4_f64)',
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS,

@@ -151,8 +151,9 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
     c->use_flags = 0;
     c->fallbacks += 1;
     if (rc == GPRN_E_WAIT_TIMEOUT)
-        fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms; re-running the call with "
-                        "HIP events (device-side waits are now off for this context)\n", what, c->wait_budget_ms);
+        fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out after %d ms%s; re-running the call with "
+                        "HIP events (device-side waits are now off for this context)\n", what, c->wait_budget_ms,
+                c->last_timeout.c_str());
     else
         fprintf(stderr, "[gprn] %s: a device-side dependency wait timed out on another rank; re-running the call with "
                         "HIP events on this rank too (device-side waits are now off for this context)\n", what);

@@ -1302,16 +1302,16 @@ __global__ void k_flag_sync(unsigned* raise_flag, unsigned raise_value, const un
 // `producer` raise it -- i.e. the two streams sit on different hardware queues
 static bool streams_overlap(hipStream_t waiter, hipStream_t producer)
 {
-    unsigned* w = nullptr;                         // [0] flag, [2] time-out word, [3] budget in 100 MHz ticks
-    if (hipMalloc(&w, 4 * sizeof(unsigned)) != hipSuccess) return false;
-    const unsigned init[4] = {0u, 0u, 0u, 2000000u};
+    unsigned* w = nullptr;                         // [0] flag, [2] time-out word, [3] budget in 100 MHz ticks, [4] which flag
+    if (hipMalloc(&w, 8 * sizeof(unsigned)) != hipSuccess) return false;
+    const unsigned init[8] = {0u, 0u, 0u, 2000000u, 0u, 0u, 0u, 0u};
     bool ok = hipMemcpy(w, init, sizeof(init), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
         hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, waiter, (unsigned*)nullptr, 0u, (const unsigned*)w, 1u, w + 2);
         hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, producer, w, 1u, (const unsigned*)nullptr, 0u, w + 2);
         ok = hipStreamSynchronize(waiter) == hipSuccess && hipStreamSynchronize(producer) == hipSuccess;
     }
-    unsigned out[4] = {0, 0, 1, 0};
+    unsigned out[8] = {0, 0, 1, 0, 0, 0, 0, 0};
     if (ok) ok = hipMemcpy(out, w, sizeof(out), hipMemcpyDeviceToHost) == hipSuccess;
     hipFree(w);
     return ok && out[0] == 1u && out[2] == 0u;
@@ -1399,8 +1399,8 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
         c->d_sig = nullptr;
-        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
-        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 4) * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 4) * sizeof(unsigned)));
         c->sig_T = c->T;
         c->epoch = 0;
         c->sig_budget_ms = -1;
@@ -1591,10 +1591,21 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
     if (eager_next < 0) { const char* e = getenv("GPRN_EAGER_NEXT"); eager_next = e ? atoi(e) : 0; }
     eager = use_flags && set == 0 && !left && !use_chain && !persist && !split_first && sr_all && merge_panel && tri &&
             nbatch <= eager_next && c->esteps.size() == (size_t)c->T;
+    // A launch whose EVERY workgroup polls at its head must not be able to fill the device: workgroups are never
+    // preempted, so once pollers hold every slot a producer that is not resident yet never becomes so and the flag
+    // never rises (round 3, config 5's shape: the last tile step's 2 (T - 1) x 15 = 3810 workgroups polled for an
+    // update of stream3 that was still queued behind its panel launch -- gpurun_out/cfg5.err).  Up to half
+    // a workgroup per CU they leave room on every CU whatever else they are; above that a one-wave kernel waits.
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || n_cu <= 0) n_cu = 64;
+    static int poll_any = -1;                      // GPRN_POLL_ANY=1 (diagnosis of the round-3 time-out only): no bound
+    if (poll_any < 0) { const char* e = getenv("GPRN_POLL_ANY"); poll_any = e ? atoi(e) : 0; }
+    auto may_poll = [&](size_t nwg) { return use_flags && (poll_any || nwg * 2 <= (size_t)n_cu); };
     auto folds_sync = [&](int k) {                 // tile step k's panel launch takes stream3's synchronisation along
         if (k < 0 || k >= c->T || use_chain) return false;
         const gprn_ctx::StepRange& sk = c->steps[set][k];
-        return merge_panel && tri && use_flags && nbatch <= panel_sync && sk.npanel_l > 0 && sk.npanel > 1;
+        return merge_panel && tri && use_flags && nbatch <= panel_sync && sk.npanel_l > 0 && sk.npanel > 1 &&
+               may_poll(2 * (sk.npanel - 1) * (size_t)nbatch);
     };
     auto do_outer = [&](int Jp) -> int {
         const size_t J = (size_t)Jp;
@@ -1777,11 +1788,15 @@ static int factor_invert_split(gprn_ctx* c, int nbatch, int set)
                 // on the chain stream, and the flag is up or about to be when they start; GPRN_LAST_WAIT=0: the stream wait)
                 static int last_wait = -1;
                 if (last_wait < 0) { const char* e = getenv("GPRN_LAST_WAIT"); last_wait = e ? atoi(e) : 1; }
-                if (k > 0 && use_flags && last_wait) {
+                if (k > 0 && use_flags && last_wait && may_poll(2 * s.npanel * (size_t)nbatch)) {
                     if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64, GPRN_T_PANEL, nosig, in_kernel_wait(k - 1, F_INNER)))) return rc;
                     continue;
                 }
-                if (k > 0) HIP_TRY(c, await(s0, k - 1, F_INNER));
+                if (k > 0 && use_flags) {                  // (one wave waits, bounded by the budget like every in-kernel wait)
+                    hipLaunchKernelGGL(k_flag_sync, dim3(1), dim3(64), 0, s0, (unsigned*)nullptr, 0u,
+                                       (const unsigned*)(slot(k - 1, F_INNER) + 1), epoch, timed_out);
+                    HIP_TRY(c, hipGetLastError());
+                } else if (k > 0) HIP_TRY(c, await(s0, k - 1, F_INNER));
                 if ((rc = tiles(s.panel0, s.npanel, s0, TS_128x64))) return rc;
                 continue;
             }
@@ -1992,8 +2007,8 @@ static int factor_invert_blocks(gprn_ctx* c, int nbatch)
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
         c->d_sig = nullptr;
-        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
-        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(c, hipMalloc(&c->d_sig, ((size_t)c->T * F_KINDS * 2 + 4) * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_sig, 0, ((size_t)c->T * F_KINDS * 2 + 4) * sizeof(unsigned)));
         c->sig_T = c->T;
         c->epoch = 0;
         c->sig_budget_ms = -1;
@@ -2206,11 +2221,19 @@ int factor_check_waits(gprn_ctx* c)
         if (rq) return rq;
     }
     if (!c->d_sig) return GPRN_OK;
-    unsigned flag = 0;
-    HIP_TRY(c, hipMemcpy(&flag, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (flag) {
+    unsigned word[3] = {0, 0, 0};                      // sticky word, budget, which flag (spin_until)
+    HIP_TRY(c, hipMemcpy(word, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(word), hipMemcpyDeviceToHost));
+    if (word[0]) {
         hipMemset(c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0, sizeof(unsigned));
-        c->err = "factorisation: a device-side dependency wait timed out";
+        static const char* const kind_name[GPRN_FLAG_KINDS] = {"DIAG", "MINIL", "INNER", "PANEL", "NEXT", "REST", "FIRST", "XW", "U", "RESTA", "TAIL"};
+        const long long at = (long long)c->sig_T * GPRN_FLAG_KINDS * 2 + (long long)(int)word[2];
+        char what[96];
+        if (at >= 0 && at < (long long)c->sig_T * GPRN_FLAG_KINDS * 2)
+            snprintf(what, sizeof(what), " (flag %s of tile step / panel %lld, T = %d)", kind_name[(at / 2) % GPRN_FLAG_KINDS],
+                     at / 2 / GPRN_FLAG_KINDS, c->T);
+        else snprintf(what, sizeof(what), " (a flag outside the factorisation's table)");
+        c->err = std::string("factorisation: a device-side dependency wait timed out") + what;
+        c->last_timeout = what;
         return GPRN_E_WAIT_TIMEOUT;
     }
     return GPRN_OK;

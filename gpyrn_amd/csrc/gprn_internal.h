@@ -231,6 +231,7 @@ struct gprn_ctx {
     int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
+    std::string last_timeout;        // which flag the last time-out was waiting for (factor_check_waits)
     // LDS pads of the tile launches (gemm_tile.hip launch_tiles), KiB; -1: the environment's / the default
     int pad_kb_opt = -1, pad_small_kb_opt = -1, chain_pad_kb_opt = -1;
     int sig_budget_ms = -1;          // budget the device word holds
@@ -408,7 +409,9 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value,
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) break;
             if (timed_out && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
-                if (timed_out) atomicExch(timed_out, 1u);
+                // the first wait of the call that gives up also says WHICH flag it was (word offset from the
+                // time-out word, two's complement: the flags lie in front of it) -- factor_check_waits names it
+                if (timed_out && atomicExch(timed_out, 1u) == 0u) timed_out[2] = (unsigned)(flag - timed_out);
                 break;
             }
         }

@@ -124,6 +124,27 @@ def test_factor_invert_schedules_at_size(ctx, flags):
         ctx.option('flags', old)
 
 
+def test_factor_invert_flag_schedule_t128(ctx):
+    # the default (flag) schedule at BASELINE config 5's matrix size, T = 128 tile steps, with more than two
+    # matrices -- the un-split "rest" path of factor_invert_split (T > 64) and launches of thousands of workgroups.  In
+    # round 3 the last tile step's panel launch polled in-kernel in every one of its 2 (T - 1) x batch workgroups, filled
+    # the device and kept its own producer off the CUs: the wait ran into its budget and the call was silently re-run on
+    # HIP events.  The factors are checked as always; what this test adds is that NO fallback happened.
+    if not ctx.option('flags'):
+        pytest.skip('device-side flags are off for this context (serialising tool or no stream memory ops)')
+    rng = np.random.RandomState(83)
+    n, batch = 16384, 3
+    A = np.array([_spd(n, rng, 1.5 + 0.5 * b) for b in range(batch)])
+    before = ctx.option('fallbacks')
+    L, X, info = ctx.test_factor_invert(A)
+    assert info == 0
+    assert ctx.option('fallbacks') == before and ctx.option('flags') == 1
+    for b in range(batch):
+        _check_factor_by_probes(A[b], L[b], X[b], rng, 1e-9)
+        d = np.diag(L[b])
+        assert np.all(d > 0) and np.isfinite(d).all()
+
+
 def test_factor_invert_event_schedule_n16384(ctx):
     # once, at BASELINE config 5's matrix size (128 tile steps), on the event schedule
     old = ctx.option('flags', 0)

@@ -48,6 +48,7 @@ def test_forced_sweeps(tag, form):
         if s == 0:
             np.testing.assert_allclose(mu, d['mu_1'], rtol=1e-7, atol=1e-9)
             np.testing.assert_allclose(var, d['var_1'], rtol=1e-6, atol=1e-12)
+    _cases.assert_state('oracle %s-form forced sweeps %s' % (form, tag), mu, d['mu_final'], var, d['var_final'])
     np.testing.assert_allclose(mu, d['mu_final'], rtol=1e-6, atol=1e-8)
 
 
@@ -63,6 +64,7 @@ def test_forced_sweeps_at_config_5_shape():
         E, mu, var, parts = cpu_ref.sweep_B(*args, mu, var)
         np.testing.assert_allclose(E, d['elbo_sweeps'][s], rtol=1e-8)
         np.testing.assert_allclose(parts, d['parts_sweeps'][s], rtol=1e-8)
+    _cases.assert_state('oracle B-form cfg5shape_N1024', mu, d['mu_final'], var, d['var_final'])
     np.testing.assert_allclose(mu, d['mu_final'], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(var, d['var_final'], rtol=1e-6, atol=1e-12)
     assert abs(d['elbo_sweeps'][1]) > 5 * abs(d['elbo_sweeps'][0])          # the divergence, as recorded
@@ -78,6 +80,7 @@ def test_elbo_calc_trajectory(tag, form):
     assert it == int(d['calc_iter'])
     np.testing.assert_allclose(hist, d['calc_elbo_array'], rtol=1e-8)
     np.testing.assert_allclose(E, float(d['calc_elbo']), rtol=1e-8)
+    _cases.assert_state('oracle %s-form ELBOcalc %s' % (form, tag), mu, d['calc_mu'], var, d['calc_var'])
     np.testing.assert_allclose(mu, d['calc_mu'], rtol=1e-6, atol=1e-8)
     assert hist[0] == hist[1]          # Q7: first sweep's update is discarded
 
@@ -109,6 +112,7 @@ def test_elbo_calc_trajectory_at_config_2():
     E, mu, var, it, hist = cpu_ref.elbo_calc(Kf, Kw, Lf, Lw, yres, y, np.array(es)**2, j2, mu0, var0, form='B')
     assert it == int(d['calc_iter'])
     np.testing.assert_allclose(hist, d['calc_elbo_array'], rtol=1e-8)
+    _cases.assert_state('oracle B-form ELBOcalc traj_cfg2_N2048', mu, d['calc_mu'], var, d['calc_var'])
     np.testing.assert_allclose(mu, d['calc_mu'], rtol=1e-6, atol=1e-8)
 
 
