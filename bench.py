@@ -466,8 +466,7 @@ def main():
         ms_upd, n_upd = prof['update']
         ms_ahd, n_ahd = prof.get('update_ahead', (0.0, 0))
         T = (N + TILE - 1) // TILE
-        sr_env = os.environ.get('GPRN_SPLIT_REST', '1')           # csrc/factor.hip: two launches up to 64 tile steps
-        split = sr_env not in ('0',) and (sr_env == '2' or T <= 64)
+        split = T <= 64                                             # csrc/factor.hip: "rest" in two launches up to 64 tile steps
         per_sweep = update_flops(T, len(nodes_l) + len(weights_l), split=split)
         fl, fl_ahd = (x * a.steps * len(block_s) for x in per_sweep[:2])
         uni = k512_union() if world == 1 and a.config == 3 and not a.shape else None

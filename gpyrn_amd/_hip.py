@@ -63,7 +63,6 @@ SIGNATURES = {
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_test_gemm_rate': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp]),
-    'gprn_test_queue_plan': (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
@@ -98,20 +97,6 @@ def load_library():
 
 def device_count():
     return int(load_library().gprn_device_count())
-
-
-def queue_plan(T, outer=4):
-    """Nodes (n, 12) and edges (m, 2) of the dataflow schedule's task graph for T tile steps (host only)."""
-    lib = load_library()
-    n, m = c_int64(0), c_int64(0)
-    rc = lib.gprn_test_queue_plan(int(T), int(outer), byref(n), byref(m), None, None)
-    if rc:
-        raise BackendError(f'gprn_test_queue_plan failed ({rc})')
-    ops = np.zeros((n.value, 12), dtype=np.int64)
-    edges = np.zeros((m.value, 2), dtype=np.int64)
-    lib.gprn_test_queue_plan(int(T), int(outer), byref(n), byref(m), ops.ctypes.data_as(POINTER(c_int64)),
-                             edges.ctypes.data_as(POINTER(c_int64)))
-    return ops, edges
 
 
 def _f64(a, shape=None):
@@ -377,8 +362,8 @@ class Context:
         return L, X, info
 
     def gemm_rate(self, M, N, K, how, reps=3):
-        """TFLOP/s of C -= A.B^T (M x N x K) through the tile contraction: how 0 / 1 = one launch (64 x 64 / 128 x 128
-        workgroups), 2 / 3 = independent nodes of the dataflow schedule's worker kernel (per quarter / per node)."""
+        """TFLOP/s of C -= A.B^T (M x N x K) through the tile contraction: one launch of 64 x 64 (how 0) / 128 x 128 (how 1)
+        workgroups."""
         v = c_double(0.0)
         self._check(self._lib.gprn_test_gemm_rate(self._h, int(M), int(N), int(K), int(how), int(reps), byref(v)), 'test_gemm_rate')
         return 2.0 * M * N * K / (v.value * 1e-3) / 1e12

@@ -1,11 +1,6 @@
 // standalone: cycles of one base16() call (the 16-pivot chain) -- hipcc --offload-arch=gfx950 base16_bench.hip -o base16_bench
-#include "../factor.hip"
+#include "../diag_tile.h"
 #include <stdio.h>
-void prof_begin(gprn_ctx*, int, hipStream_t) {}
-void prof_end(gprn_ctx*) {}
-int launch_tiles(gprn_ctx*, const TileTask*, size_t, double**, int, int, int, hipStream_t, int, Signal, Await, int) { return 0; }
-int launch_tile_rows(gprn_ctx*, int, double**, int, int, int, int, hipStream_t, Signal, Await) { return 0; }
-int launch_panel(gprn_ctx*, const TileTask*, size_t, size_t, double**, int, int, hipStream_t, Signal) { return 0; }
 
 template <int OLD>
 __global__ void k_bench(double* A, double* Xg, long long* out, int* info, int reps)
@@ -18,8 +13,7 @@ __global__ void k_bench(double* A, double* Xg, long long* out, int* info, int re
     for (int r = 0; r < reps; ++r) {
         for (int i = l; i < 256; i += 64) St[(i / 16) * PP + (i % 16)] = A[i];
         wave_lds_sync();
-        if (OLD == 1) base16_lanes(St, xd, (gptr_t)Xg, 16, info, 0, 0, line);
-        else if (OLD == 0) base16(St, xd, (gptr_t)Xg, 16, info, 0, 0, line);
+        if (OLD == 0) base16(St, xd, (gptr_t)Xg, 16, info, 0, 0, line);
         else wave_lds_sync();
     }
     long long t1 = clock64();

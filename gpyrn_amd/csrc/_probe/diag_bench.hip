@@ -1,14 +1,9 @@
 // standalone: shader-clock timeline of one diag_tile() call (potrf + inverse of a 128x128 tile), per wave and phase
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 diag_bench.hip -o diag_bench
 #define DIAG_STAMPS
-#include "../factor.hip"
+#include "../diag_tile.h"
 #include <stdio.h>
 #include <vector>
-void prof_begin(gprn_ctx*, int, hipStream_t) {}
-void prof_end(gprn_ctx*) {}
-int launch_tiles(gprn_ctx*, const TileTask*, size_t, double**, int, int, int, hipStream_t, int, Signal, Await, int) { return 0; }
-int launch_tile_rows(gprn_ctx*, int, double**, int, int, int, int, hipStream_t, Signal, Await) { return 0; }
-int launch_panel(gprn_ctx*, const TileTask*, size_t, size_t, double**, int, int, hipStream_t, Signal) { return 0; }
 
 __global__ __launch_bounds__(256) void k_bench(double* B, double* X, int ld, int* info, long long* total)
 {

@@ -81,7 +81,6 @@ extern "C" int gprn_profile_read(gprn_ctx* c, double* ms, int64_t* launches, int
     DeviceLock lock_(c);
     if (!c) return GPRN_E_ARG;
     prof_collect(c);
-    queue_print_stats(c);
     for (int i = 0; i < GPRN_T_COUNT; ++i) {
         if (ms) ms[i] = c->prof.ms[i];
         if (launches) launches[i] = c->prof.n[i];
@@ -166,18 +165,13 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //   "flags"          1/0: device-side flags or HIP events for the factorisation's cross-stream dependencies
 //   "wait_budget_ms" wall-clock budget of one in-kernel wait
 //   "withhold_inner" test hook: the n-th F_INNER raise of every following call is skipped (0 = off)
-//   "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb"  unused dynamic LDS of the bulk launches (batches above / up to two
-//                    matrices) and of the chain's own tile launches, KiB (-2: back to the environment / default).  A pad that does
-//                    not fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG
-//   "queue"          1/0: the factorisation as a task graph run by a persistent worker kernel (queue.hip; needs "flags"), or
-//                    the launch-per-step schedule of factor.hip
-//   "block_sched"    1/0: the block schedule of the factorisation where it applies (factor_invert_blocks, factor.hip) or the
-//                    step-synchronous launch schedule everywhere; -1: the environment's GPRN_BLOCK_SCHED / the default (1)
+//   "bulk_pad_kb" / "small_pad_kb"  unused dynamic LDS of the bulk launches (batches above / up to two matrices), KiB
+//                    (-2: back to the default).  A pad that does not fit a workgroup's LDS makes the factorising calls
+//                    return GPRN_E_ARG
 //   "overlap"        bit mask of what runs beside the factorisations instead of before / behind them (overlap_mask below:
 //                    1 B formed inside the first update, 2 row reductions panel by panel, 4 node term beside the weight
-//                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep, 32 ... with its X^T X);
-//                    0 = everything in sequence as in rounds 1-2; -1: GPRN_OVERLAP / the default (31).  Results are
-//                    bit-identical for every value
+//                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep); 0 = everything in sequence
+//                    as in rounds 1-2; -1: the default (31).  Results are bit-identical for every value
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -187,17 +181,13 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     if (!strcmp(name, "flags")) { factor_use_flags(c); field = &c->use_flags; }
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
-    else if (!strcmp(name, "queue")) { queue_enabled(c); field = &c->queue_mode; }
-    else if (!strcmp(name, "block_sched")) field = &c->block_sched;
     else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
-    else if (!strcmp(name, "chain_pad_kb")) field = &c->chain_pad_kb_opt;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
-    else if (!strcmp(name, "chain_streams")) { if (old) *old = factor_probe_streams(c); return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
-    const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt || field == &c->chain_pad_kb_opt;
+    const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt;
     if (is_pad && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
     if (value >= 0) {
         if (field == &c->use_flags && value) {
@@ -222,11 +212,6 @@ static void free_problem(gprn_ctx* c)
     for (auto& p : c->Sig) dev_free(p);
     for (auto& p : c->wsB) dev_free(p);
     for (auto& p : c->wsX) dev_free(p);
-    for (auto& p : c->wsB2) dev_free(p);
-    for (auto& p : c->wsX2) dev_free(p);
-    c->wsB2.clear(); c->wsX2.clear();
-    if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
-    dev_free(c->d_s_keep);
     c->K.clear(); c->KLinv.clear(); c->Kinv.clear(); c->Sig.clear(); c->wsB.clear(); c->wsX.clear();
     dev_free(c->d_logdetK);
     for (auto& p : c->predKs) dev_free(p);
@@ -265,7 +250,7 @@ extern "C" int gprn_device_count(void)
 // device's lock (DeviceLock at the top of each entry point).
 //   s[0] chain (high priority): everything, incl. the latency chain of the factorisation
 //   s[1] bulk (low priority): trailing updates running behind the chain (look-ahead)
-//   s[2] side: in-panel work that is off the chain        s[3]: second chain stream (GPRN_CHAIN_STREAMS=1)
+//   s[2] side: in-panel work that is off the chain        s[3]: the next panel's share of an outer update
 static std::mutex g_streams_mu;
 static std::map<int, DeviceStreams*> g_streams;
 
@@ -278,30 +263,10 @@ static DeviceStreams* device_streams_acquire(int device)
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     int prio[4] = {prio_hi, prio_lo, prio_hi, prio_hi};
-    // GPRN_STREAM_PRIO="a,b,c,d" (experiments): 0 highest, 1 the level between, 2 lowest, for s[0..3]
-    if (const char* e = getenv("GPRN_STREAM_PRIO")) {
-        int v[4] = {0, 2, 0, 0};
-        if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
-            for (int i = 0; i < 4; ++i) prio[i] = v[i] <= 0 ? prio_hi : (v[i] >= 2 ? prio_lo : (prio_hi + prio_lo) / 2);
-    }
-    // GPRN_RESERVE_CUS=n (experiments; default 0): the bulk, side and fourth stream are created with a CU mask that
-    // leaves the last n CUs of every XCD to the chain stream's kernels (bit i of the mask = CU i / 8 of XCD i % 8,
-    // _probe/cumask_map.hip); masked streams have no priority
-    static int reserve = -1;
-    if (reserve < 0) { const char* e = getenv("GPRN_RESERVE_CUS"); reserve = e ? atoi(e) : 0; }
-    int n_cu = 0;
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device);
-    uint32_t mask[8];
-    const int per_xcd = n_cu / 8;
-    const bool masked = reserve > 0 && n_cu == 256 && reserve < per_xcd;
-    if (masked) {
-        for (int w = 0; w < 8; ++w) mask[w] = 0xffffffffu;
-        for (int i = 0; i < 256; ++i)
-            if (i / 8 >= per_xcd - reserve) mask[i / 32] &= ~(1u << (i % 32));
-    }
+    // (stream priorities do not order workgroup dispatch in any way a sweep can see -- six assignments measured 115.0-116.3
+    // against 115.9 sweeps/s -- and CU masks that keep CUs free for the chain cost more than the free CUs give: DESIGN.md 8)
     for (int i = 0; i < 4; ++i)
-        if ((masked && i > 0 ? hipExtStreamCreateWithCUMask(&d->s[i], 8, mask)
-                             : hipStreamCreateWithPriority(&d->s[i], hipStreamNonBlocking, prio[i])) != hipSuccess) {
+        if (hipStreamCreateWithPriority(&d->s[i], hipStreamNonBlocking, prio[i]) != hipSuccess) {
             for (int j = 0; j < i; ++j) hipStreamDestroy(d->s[j]);
             delete d;
             return nullptr;
@@ -348,7 +313,6 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
         hipEventCreateWithFlags(&c->ev_next, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_nodes, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_tail, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_xw, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_q1, hipEventDisableTiming) != hipSuccess) {
         device_streams_release(c->shared);
         delete c;
@@ -375,11 +339,9 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         comm_teardown(c);
         free_problem(c);
         dev_free(c->d_tasks);
-        queue_free(c);
         if (c->d_sig) hipFree(c->d_sig);
         if (c->d_step_stamps) hipFree(c->d_step_stamps);
         if (c->d_side_stamps) hipFree(c->d_side_stamps);
-        if (c->d_stamps) hipFree(c->d_stamps);
         dev_free(c->d_agree);
         dev_free(c->d_test[0]); dev_free(c->d_test[1]); dev_free(c->d_test[2]);
         hipEventDestroy(c->ev_diag);
@@ -393,7 +355,6 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         hipEventDestroy(c->ev_nodes);
         hipEventDestroy(c->ev_q1);
         hipEventDestroy(c->ev_tail);
-        hipEventDestroy(c->ev_xw);
     }
     device_streams_release(c->shared);
     delete c;
@@ -868,11 +829,6 @@ static int build_tables(gprn_ctx* c)
 {
     if (c->tables_ready) return GPRN_OK;
     // (the second set of node workspaces and its table are rebuilt on demand: sweep_impl)
-    for (auto& p : c->wsB2) dev_free(p);
-    for (auto& p : c->wsX2) dev_free(p);
-    c->wsB2.clear(); c->wsX2.clear();
-    if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
-    dev_free(c->d_s_keep);
     c->loc_nodes.clear(); c->loc_weights.clear();
     for (int g = 0; g < c->q; ++g) if (c->owner[g] == c->rank) c->loc_nodes.push_back(g);
     for (int g = c->q; g < c->G; ++g) if (c->owner[g] == c->rank) c->loc_weights.push_back(g);
@@ -1042,15 +998,12 @@ static int factor_priors_impl(gprn_ctx* c)
 }
 
 // ------------------------------------------------------------------ sweep
-// What of a phase's head and tail runs beside a factorisation (bits; option "overlap", else GPRN_OVERLAP, else all but 32):
+// What of a phase's head and tail runs beside a factorisation (bits; option "overlap", default all):
 //   1 B formed inside the first panel's update   2 row reductions over X panel by panel   4 node term beside the weight phase
-//   8 log det B in k_finalize   16 the end of a sweep beside the next sweep's node phase   32 ... with the Q1 product
-static int overlap_mask(const gprn_ctx* c)
-{
-    static int env = -1;
-    if (env < 0) { const char* e = getenv("GPRN_OVERLAP"); env = e ? atoi(e) : 31; }
-    return c->overlap_opt >= 0 ? c->overlap_opt : env;
-}
+//   8 log det B in k_finalize   16 the end of a sweep beside the next sweep's node phase
+// (bit 32 of round 3 -- ... with the X^T X product of quirk Q1 too, the node phases alternating between two sets of
+// workspaces -- measured 108.4 against 111.3 sweeps/s at config 3 and is gone: DESIGN.md 5d)
+static int overlap_mask(const gprn_ctx* c) { return c->overlap_opt >= 0 ? c->overlap_opt : 31; }
 
 static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr, double* out = nullptr);
 
@@ -1059,24 +1012,18 @@ static int run_phase(gprn_ctx* c, bool weights)
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
     const int ns = (int)gps.size();
     const int* slotgp = weights ? c->d_slotgp_weight : c->d_slotgp_node;
-    // (node_alt: the node phase works in the second set of node workspaces, so that the previous sweep's X stays intact
-    // for its X^T X product, which then runs beside THIS node phase: sweep_impl)
-    const bool alt = !weights && c->node_alt;
-    c->d_ptrs = weights ? c->tab_weight : (alt ? c->tab_node2 : c->tab_node);
-    std::vector<double*>& nodeB = alt ? c->wsB2 : c->wsB;
+    c->d_ptrs = weights ? c->tab_weight : c->tab_node;
     c->slot0 = weights ? (int)c->loc_nodes.size() : 0;
     c->d_info_cur = c->d_info + (weights ? 2 : 1) * (size_t)c->nslot;
     const size_t o = (size_t)c->slot0 * c->ld;
     if (ns) {
         TRY(vec_prep(c, weights, slotgp, ns));
-        // B = I + D^1/2 K D^1/2: built by factor_invert -- under the launch schedule only the tiles its first outer panel's
-        // tile steps touch; the others are formed from K inside that panel's K = 512 update (GPRN_OVERLAP bit 1)
+        // B = I + D^1/2 K D^1/2: built by factor_invert -- only the tiles its first outer panel's tile steps touch; the
+        // others are formed from K inside that panel's K = 512 update (overlap bit 1).
         // The reductions over the rows of X = L^-1 (u = X z, column norms, X^T u: 8 N^2 bytes per matrix) run outer
-        // panel by outer panel as the rows become final (rows_final, called by the launch schedule on the bulk
-        // stream); behind the factorisation only the last panel's rows, the reduction over the partial sums and the
-        // new state are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
-        // GPRN_OVERLAP bits: 1 B formed inside the first update, 2 this, 4 the node phase's mu^T K^-1 mu beside the weight
-        // phase, 8 log det B in k_finalize.
+        // panel by outer panel as the rows become final (rows_final, called by the schedule on the bulk stream: bit 2);
+        // behind the factorisation only the last panel's rows, the reduction over the partial sums and the new state
+        // are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
         const int overlap = overlap_mask(c);
         c->rows_done = 0;
         c->build_pending = ns;
@@ -1088,23 +1035,18 @@ static int run_phase(gprn_ctx* c, bool weights)
                 return vec_colops_partial(c, ns, st, r0, r1 - r0);
             };
         }
-        c->fast_factor = true;                       // X's lower tiles and diag(L) are all the phase reads
         const int rc_f = factor_invert(c, ns);
-        c->fast_factor = false;
         c->ft_s_phase = nullptr; c->build_pending = 0;
         const int rd = c->rows_done;
         c->rows_final = nullptr; c->rows_done = 0;
         TRY(rc_f);
         TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, nullptr, rd * GPRN_TILE, -1));
         TRY(vec_colops_partial(c, ns, nullptr, rd, -1));
-        // GPRN_FUSED_FINALIZE=0: the column sums' reduction and the finalisation as two launches (the second one workgroup per GP)
-        static int fused_fin = -1;
-        if (fused_fin < 0) { const char* e = getenv("GPRN_FUSED_FINALIZE"); fused_fin = e ? atoi(e) : 1; }
-        if (fused_fin && (overlap & 8)) TRY(vec_reduce_finalize(c, slotgp, ns, true));
+        if (overlap & 8) TRY(vec_reduce_finalize(c, slotgp, ns, true));     // column sums, new state, tr B^-1, log det B
         else {
-        TRY(vec_colops_reduce(c, ns));
-        if (!(overlap & 8)) TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
-        TRY(vec_finalize(c, slotgp, ns, (overlap & 8) != 0));      // + log det B
+            TRY(vec_colops_reduce(c, ns));
+            TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
+            TRY(vec_finalize(c, slotgp, ns, false));
         }
         if (c->keep_sigma) {
             const size_t nn = (size_t)c->ld * c->ld;
@@ -1121,73 +1063,41 @@ static int run_phase(gprn_ctx* c, bool weights)
             // quirk Q1: <K_j^-1, Sigma_k> for k < j needs the explicit B_k^-1 = X^T X of every node
             // but the last.  Nothing in the weight phase reads it, so it runs beside that phase on
             // the second stream and is joined before the ELBO assembly.  It is handed to the weight
-            // phase's factorisation, which enqueues it once its chain kernel holds its CUs (a launch of
-            // 528 long-running workgroups just before would keep the chain waiting for a free CU).
+            // phase's factorisation, which enqueues it behind its first diagonal block (a launch of
+            // 528 long-running workgroups just before would keep that block waiting for a free CU).
             const int n_inv = (gps.back() == c->q - 1) ? ns - 1 : ns;
             const std::vector<int> node_gps = gps;
             double** const node_tab = c->d_ptrs;
-            const std::vector<double*> node_B(nodeB.begin(), nodeB.begin() + ns);
+            const std::vector<double*> node_B(c->wsB.begin(), c->wsB.begin() + ns);
             double* const q1_out = c->d_q1;
-            // the product and the traces, on the bulk stream (s = sqrt(d) of the node slots: overwritten by the next
-            // node phase's k_prep_nodes only -- the deferred form below runs behind that phase's first diagonal block, so it
-            // keeps a copy)
-            c->q1_work = [c, n_inv, ns, node_gps, node_tab, node_B, q1_out](const double* s_nodes) -> int {
-                double** const cur = c->d_ptrs;
-                c->d_ptrs = node_tab;
-                int rc = GPRN_OK;
-                // (the dataflow schedule takes the product along as filler of its worker kernel: queue.hip)
-                if (n_inv && !c->keep_sigma && !c->q_lauum_in_queue) rc = lauum_lower(c, n_inv, c->stream2);
-                c->q_lauum.n = 0;
-                for (int s = 0; s < ns && !rc; ++s) {
-                    const int k = node_gps[s];
-                    for (int j = k + 1; j < c->q && !rc; ++j)
-                        rc = vec_q1(c, c->Kinv[j], node_B[s], s_nodes + (size_t)s * c->ld, c->d_u,
-                                    q1_out + (size_t)j * c->q + k, c->stream2);
-                }
-                c->d_ptrs = cur;
-                return rc;
-            };
-            if (c->defer_sweep_end) {
-                // sweep_impl runs it with the rest of the sweep's end beside the NEXT sweep's node phase, where the chain
-                // bounds the time and the tile kernels have room -- not beside this sweep's weight phase, which is bound
-                // by their throughput
-                HIP_TRY(c, hipMemcpyAsync(c->d_s_keep, c->d_s, (size_t)ns * c->ld * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-                c->q1_pending = false;
-            } else {
             HIP_TRY(c, hipEventRecord(c->ev_nodes, c->stream));
             const bool early_term = (overlap & 4) && !c->loc_weights.empty();
             c->node_term_done = early_term;
-            c->chain_started = [c, early_term]() -> int {
+            c->chain_started = [c, early_term, n_inv, ns, node_gps, node_tab, node_B, q1_out]() -> int {
                 double** const cur = c->d_ptrs;
                 const int cur_slot0 = c->slot0;
                 HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_nodes, 0));
                 // mu_f^T K_f^-1 mu_f needs the node phase's result only: HBM-bound work beside the MFMA-bound weight phase
                 int rc = early_term ? mu_k_mu(c, false, c->stream2) : GPRN_OK;
+                c->d_ptrs = node_tab;
+                if (!rc && n_inv && !c->keep_sigma) rc = lauum_lower(c, n_inv, c->stream2);
+                for (int s = 0; s < ns && !rc; ++s) {
+                    const int k = node_gps[s];
+                    for (int j = k + 1; j < c->q && !rc; ++j)
+                        rc = vec_q1(c, c->Kinv[j], node_B[s], c->d_s + (size_t)s * c->ld, c->d_u,
+                                    q1_out + (size_t)j * c->q + k, c->stream2);
+                }
                 c->d_ptrs = cur;
                 c->slot0 = cur_slot0;
-                std::function<int(const double*)> w;
-                w.swap(c->q1_work);
-                if (!rc && w) rc = w(c->d_s);
                 if (rc) return rc;
                 HIP_TRY(c, hipEventRecord(c->ev_q1, c->stream2));
                 return GPRN_OK;
             };
             c->q1_pending = true;
-            }
-            // offer the product to the next factorisation's worker kernel (taken when the dataflow schedule runs it)
-            c->q_lauum.n = 0;
-            if (n_inv && !c->keep_sigma && n_inv <= 16) {
-                c->q_lauum.rows.assign((size_t)n_inv * GPRN_NBUF, nullptr);
-                for (int s = 0; s < n_inv; ++s) {
-                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_B] = (alt ? c->wsB2 : c->wsB)[s];
-                    c->q_lauum.rows[(size_t)s * GPRN_NBUF + BUF_X] = (alt ? c->wsX2 : c->wsX)[s];
-                }
-                c->q_lauum.n = n_inv;
-            }
         }
     }
     if (weights && c->chain_started) {
-        // no factorisation took it along (no weight GP on this rank, or the launch schedule): now
+        // no factorisation took it along (no weight GP on this rank): now
         std::function<int()> f;
         f.swap(c->chain_started);
         TRY(f());
@@ -1239,57 +1149,28 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
     }
     HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
-    timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     // The end of a sweep -- mu_w^T K_w^-1 mu_w (one pass over the six L_K^-1), the ELBO assembly and the wait for the
     // Q1 traces, some 150 us on the chain stream -- reads only what the sweep has left behind, and the next sweep's node
     // phase reads none of its results: inside a call of several sweeps it runs beside that phase, on the bulk stream,
     // handed to its factorisation like the X^T X product (chain_started: behind the first diagonal block, i.e. after
     // everything this sweep enqueued on the chain stream; the bulk stream is in order, so the Q1 traces are there too).
     // The per-GP scalars live in two copies for it.  Single-rank calls under the flag schedule only (no collective may
-    // move; GPRN_OVERLAP bit 16); the last sweep of a call is assembled in line.
+    // move; overlap bit 16); the last sweep of a call is assembled in line.
     const int overlap = overlap_mask(c);
     const size_t nscal = 3 * (size_t)c->G + (size_t)c->q * c->q;
     // (the node phase's factorisation must be one that joins the bulk stream at its end: an outer panel with a "rest")
     c->chain_started = nullptr;
     TRY(ensure_tasks(c));
-    const int node_set = (int)c->loc_nodes.size() * c->T <= 32 ? 1 : 0;
+    const int node_set = (int)c->loc_nodes.size() * c->T <= GPRN_LAT_MAX ? 1 : 0;
     const bool node_joins = !c->outers[node_set].empty() && c->outers[node_set][0].nrest > 0;
-    const bool may_defer = (overlap & 16) && !comm_active(c) && factor_use_flags(c) == 1 && !queue_enabled(c) &&
+    const bool may_defer = (overlap & 16) && !comm_active(c) && factor_use_flags(c) == 1 &&
                            !c->loc_nodes.empty() && !c->loc_weights.empty() && !c->keep_sigma && node_joins;
-    // With q > 1 the deferred end of a sweep includes the X^T X product of quirk Q1 (N^3/3 per node but the last): the
-    // node phases then alternate between two sets of node workspaces (the last sweep of a call uses the first set, which
-    // is what the read-back entry points look at).
-    // (GPRN_OVERLAP bit 32, off by default: measured 108.4 against 111.3 sweeps/s at config 3 -- the node phase is bound by
-    // its latency chain, and the product's workgroups on every CU slow the chain's kernels by more than the weight phase gains)
-    const bool alt_ok = may_defer && (overlap & 32) && c->q > 1 && n_sweeps > 1;
-    if (alt_ok && c->wsB2.size() != c->loc_nodes.size()) {
-        const size_t nn2 = (size_t)c->ld * c->ld, nnod = c->loc_nodes.size();
-        for (auto& p : c->wsB2) dev_free(p);
-        for (auto& p : c->wsX2) dev_free(p);
-        c->wsB2.assign(nnod, nullptr); c->wsX2.assign(nnod, nullptr);
-        for (size_t sidx = 0; sidx < nnod; ++sidx) { TRY(dev_alloc(c, &c->wsB2[sidx], nn2)); TRY(dev_alloc(c, &c->wsX2[sidx], nn2)); }
-        if (c->tab_node2) { tab_forget(c, c->tab_node2); dev_free(c->tab_node2); }
-        dev_free(c->d_s_keep);
-        TRY(dev_alloc(c, &c->tab_node2, (size_t)c->nslot * GPRN_NBUF));
-        TRY(dev_alloc(c, &c->d_s_keep, nnod * (size_t)c->ld));
-        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
-        for (size_t sidx = 0; sidx < nnod; ++sidx) {
-            rows[sidx * GPRN_NBUF + BUF_B] = c->wsB2[sidx];
-            rows[sidx * GPRN_NBUF + BUF_X] = c->wsX2[sidx];
-            rows[sidx * GPRN_NBUF + BUF_K] = c->K[c->loc_nodes[sidx]];
-            rows[sidx * GPRN_NBUF + BUF_KLINV] = c->KLinv[c->loc_nodes[sidx]];
-        }
-        TRY(upload_table(c, c->tab_node2, rows));
-    }
-    c->q1_work = nullptr;
     bool scal_cleared = false;
     if (!comm_active(c)) {
         HIP_TRY(c, hipMemsetAsync(c->d_scal_base, 0, 2 * nscal * sizeof(double), c->stream));
         scal_cleared = true;
     }
     for (int it = 0; it < n_sweeps; ++it) {
-        c->node_alt = alt_ok && (((n_sweeps - 1 - it) & 1) != 0);
-        c->defer_sweep_end = alt_ok && it + 1 < n_sweeps;
         double* const scal = c->d_scal_base + (size_t)(it & 1) * nscal;
         double* const part = c->d_elbo_part + (size_t)(it & 1) * GPRN_ELBO_PART_DOUBLES;
         c->d_scal = scal;
@@ -1308,13 +1189,10 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         const bool node_term = !c->node_term_done;
         double* const out4 = c->d_out + 4 * (size_t)it;
         if (defer) {
-            std::function<int(const double*)> q1w;
-            q1w.swap(c->q1_work);
-            c->chain_started = [c, scal, part, out4, node_term, q1w]() -> int {
+            c->chain_started = [c, scal, part, out4, node_term]() -> int {
                 double** const cur = c->d_ptrs;
                 const int cur_slot0 = c->slot0;
-                int rc = q1w ? q1w(c->d_s_keep) : GPRN_OK;
-                if (!rc && node_term) rc = mu_k_mu(c, false, c->stream2, scal + 2 * (size_t)c->G);
+                int rc = node_term ? mu_k_mu(c, false, c->stream2, scal + 2 * (size_t)c->G) : GPRN_OK;
                 if (!rc) rc = mu_k_mu(c, true, c->stream2, scal + 2 * (size_t)c->G);
                 if (!rc) rc = vec_elbo(c, out4, scal, part, c->stream2);
                 c->d_ptrs = cur; c->slot0 = cur_slot0;
@@ -1327,20 +1205,13 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         TRY(reduce_scalars(c));
         TRY(vec_elbo(c, out4, scal, part));
     }
-    c->node_alt = false; c->defer_sweep_end = false; c->q1_work = nullptr;
     if (!commit) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
     }
-    timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1);
     std::vector<double> h(4 * (size_t)n_sweeps);
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (getenv("GPRN_DEBUG_TIMING")) {
-        timespec ts2; clock_gettime(CLOCK_MONOTONIC, &ts2);
-        auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
-        fprintf(stderr, "[gprn] %d sweeps: host enqueue %.3f ms, until results %.3f ms\n", n_sweeps, ms(ts0, ts1), ms(ts0, ts2));
-    }
     for (int it = 0; it < n_sweeps; ++it) {
         elbo_out[it] = h[4 * it];
         if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];
@@ -1903,12 +1774,11 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
 }
 
 // Rate of the tile contraction on an M x N x K product C -= A.B^T of random data already on the device (diagnostic):
-// how = 0 / 1: one launch of the tile kernel, 64 x 64 / 128 x 128 workgroups; 2 / 3: the same tasks as independent nodes
-// of the dataflow schedule's worker kernel, one queue entry per 64 x 64 quarter / per node.  ms: average of `reps` runs.
+// how = 0 / 1: one launch of the tile kernel, 64 x 64 / 128 x 128 workgroups.  ms: average of `reps` runs.
 extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, int reps, double* ms)
 {
     DeviceLock lock_(c);
-    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || reps < 1 || !ms || how < 0 || how > 3)
+    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || reps < 1 || !ms || how < 0 || how > 1)
         return bad(c, "test_gemm_rate: bad argument");
     const int ld = std::max(std::max(M, N), K);
     TRY(test_setup(c, ld, 3, 1));
@@ -1933,8 +1803,7 @@ extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, in
     HIP_TRY(c, hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice));
     int rc = GPRN_OK;
     float t = 0.f;
-    if (how >= 2) rc = queue_run_independent(c, tasks, d_p, ld, how == 3, reps, &t);
-    else {
+    {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
         float total = 0.f;

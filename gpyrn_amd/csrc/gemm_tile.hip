@@ -33,7 +33,6 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "dag.h"
 #include "tile_mma.h"
 
 // Output tile of one workgroup: BM x BN in {64,128}^2, computed by NW = 4 waves (2 x 2) or 8 waves (2 x 4).
@@ -57,14 +56,14 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
 void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                  const unsigned* wait_flag, unsigned wait_value, unsigned* wait_timed_out, int xcd_map,
-                 const unsigned* wait_flag2, unsigned wait_value2, const double* ft_s, int ft_n,
+                 const double* ft_s, int ft_n,
                  unsigned* start_flag, unsigned start_value)
 {
     // (gprn_ctx::start_flag_now: the flag of the launch before this one on the stream -- in memory once a workgroup of
     // this launch runs -- instead of a stream write, a 4.5 us kernel of its own, between the two)
     if (start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    await_flag(wait_flag, wait_value, wait_timed_out);
     constexpr int WM = 2, WN = NW / 2;                          // waves: WM x WN
     constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;     // sub-tiles per task
     __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
@@ -77,7 +76,8 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     // contiguous eighth per XCD measured -25 % fabric traffic but +6 % time).  Placement is a speed matter
     // only: any bijection is correct.
     const unsigned gx = gridDim.x, nblk = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
-    // (xcd_map = log2 of the chunk: 4 by default; GPRN_XCD_MAP=5 / 6 for chunks of 32 / 64 entries, 0 for grid order)
+    // (xcd_map = log2 of the chunk, GPRN_XCD_CHUNK_LOG2 = 4: chunks of 32 / 64 / 128 entries measured 110.4 / 107.5 / 112.7
+    // sweeps/s against 112.8 at config 3, 8 entries 113.3 -- DESIGN.md 8; 0 would be grid order)
     const unsigned sh = (unsigned)xcd_map, cmask = (1u << sh) - 1u;
     const unsigned n128 = nblk & ~((8u << sh) - 1u), cx = lin >> 3;
     const unsigned lb = (xcd_map && lin < n128) ? ((((cx >> sh) << 3) + (lin & 7u)) << sh) + (cx & cmask) : lin;
@@ -117,11 +117,11 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     }
     if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
     else if (CAN_LOWER && lower && sr == sc)
-        tile_mma<BM, BN, WM, WN, TRI, false, -1, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                                            (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
+        tile_mma<BM, BN, WM, WN, TRI, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+                                                       (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
     else
-        tile_mma<BM, BN, WM, WN, TRI, false, -1, false, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                             (sr * BM) >> 4, (sc * BN) >> 4, nullptr, ft_K, ft_sv, ft_row, ft_col, ft_n);
+        tile_mma<BM, BN, WM, WN, TRI, false, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+                                                   (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
@@ -153,52 +153,24 @@ void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __
         const double* A = pick(t.a_buf) + t.a_off + (a_mode ? (size_t)sub * 64 : (size_t)sub * 64 * ld);
         const double* B = pick(t.b_buf) + t.b_off;
         gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sub * 64 * ld;
-        tile_mma<64, 128, 2, 2, 1, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, (sub * 64) >> 4, 0);
+        tile_mma<64, 128, 2, 2, 1>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, (sub * 64) >> 4, 0);
     } else {                                                    // columns split
         const double* A = pick(t.a_buf) + t.a_off;
         const double* B = pick(t.b_buf) + t.b_off + (b_mode ? (size_t)sub * 64 : (size_t)sub * 64 * ld);
         gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + sub * 64;
-        tile_mma<128, 64, 2, 2, 2, false>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, 0, (sub * 64) >> 4);
+        tile_mma<128, 64, 2, 2, 2>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, 0, (sub * 64) >> 4);
     }
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
-
-__global__ void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
-                             unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                             unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value);     // the same panel at 16-row / 16-column granularity, below
 
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
                  hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start, unsigned raise_value, unsigned* raise_at_start2)
 {
     if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig);
-    // GPRN_PANEL_ROWS=1 (experiments): k_panel_rows, 16-row / 16-column workgroups like the chain's kernels.  Slower:
-    // 106.4 vs 109.1 sweeps/s at config 3, 657 vs 684 at config 2, 232 vs 256 with one N = 4096 matrix per phase --
-    // eight times as many workgroups each fetch their share of X_kk, and their fixed costs add up.
-    static int panel_rows = -1;
-    if (panel_rows < 0) { const char* e = getenv("GPRN_PANEL_ROWS"); panel_rows = e ? atoi(e) : 0; }
     prof_begin(c, GPRN_T_PANEL, stream);
-    if (panel_rows)
-        hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)(8 * (n_l + n_x)), (unsigned)nbatch), dim3(512), 0, stream, d_tasks, (int)n_l,
-                           (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, sig.timed_out,
-                           (const unsigned*)nullptr, 0u);
-    else
     hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
                        (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
                        aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value, raise_at_start, raise_value, raise_at_start2);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
-}
-
-// the in-block panel of a tile step of the block schedule (factor.hip): k_panel_rows on the chain stream
-int launch_panel_rows(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
-                      hipStream_t stream, Signal sig, Await aw)
-{
-    if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig, aw);
-    prof_begin(c, GPRN_T_PANEL, stream);
-    hipLaunchKernelGGL(k_panel_rows, dim3((unsigned)(8 * (n_l + n_x)), (unsigned)nbatch), dim3(512), 0, stream, d_tasks, (int)n_l,
-                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                       aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -226,24 +198,18 @@ __device__ unsigned long long rows_stamps[8];
 // rows, fully coalesced; eight waves fetching all of it themselves kept the CU's vector memory path busy for 3.5 us
 // -- and the X_kk rows come straight from global memory, 16 (Q + 1) columns of them.
 #define ROWS_PITCH 136                              // doubles per LDS row: 16-byte reads of 64 lanes spread over all banks
-// QUEUE: a node of the dataflow schedule (queue.hip) -- q / qop / q_skip_wait replace the flag arguments
-template <bool ARGS, bool QUEUE = false>
+template <bool ARGS>
 __global__ __launch_bounds__(512)
 void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t b_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2,
-               QueueCtl q, unsigned qop, int q_skip_wait)
+               unsigned* wait_timed_out)
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
     RW_STAMP(0);
-    CHAIN_PRIO();
-    const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const bool st = !QUEUE && pa.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
+    const bool st = pa.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
-    if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
-    else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    await_flag(wait_flag, wait_value, wait_timed_out);
     if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -284,102 +250,28 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    if (QUEUE) {
-        q_complete(q, blockIdx.y, qop, false);
-        if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
-            q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
-    } else {
-        if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-        signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
-    }
+    if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
-}
-
-// stream3's panel of a tile step at the same granularity (GPRN_PANEL_ROWS=1): tasks [0, n_l) are L_ik = B_ik X_kk^T (in
-// place over B_ik: one 8-wave workgroup per 16-ROW block, as k_chain_l), the others X_kc = X_kk R_kc (in place over
-// R_kc: one workgroup per 16-COLUMN block, which passes through LDS transposed, wave = row block, X_kk's rows up to
-// the diagonal straight from global memory).  Eight workgroups of 3-4 us per task instead of two of 14 -- and slower
-// in every configuration measured (launch_panel), so off by default.
-__global__ __launch_bounds__(512)
-void k_panel_rows(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
-                  unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
-                  unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value)
-{
-    __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
-    CHAIN_PRIO();
-    await_flag(wait_flag, wait_value, wait_timed_out);
-    const int ti = blockIdx.x >> 3, blk = blockIdx.x & 7;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
-    const TileTask t = tasks[ti];
-    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
-    double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
-    auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
-    const bool l_part = ti < n_l;
-    // the operand that is NOT in place: 16 rows of X_kk, k below 16 (wv + 1), straight into registers
-    const double* Xk = (l_part ? pick(t.b_buf) + t.b_off : pick(t.a_buf) + t.a_off) + (size_t)(16 * wv + fr) * ld + 2 * fk;
-    const int nj = 2 * (wv + 1);
-    double xo[32];
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < nj) {
-            const double2 v = *(const double2*)(Xk + 8 * j);
-            xo[2 * j] = v.x; xo[2 * j + 1] = v.y;
-        }
-    double* const Cm = pick(t.c_buf) + t.c_off;
-    if (l_part) {
-        // rows 2 wv, 2 wv + 1 of row block `blk`: lane l takes 16 bytes at column 2 l
-        const double* Ar = Cm + (size_t)(16 * blk + 2 * wv) * ld + 2 * lane;
-        const double2 r0 = *(const double2*)Ar, r1 = *(const double2*)(Ar + ld);
-        *(double2*)(rows + (2 * wv) * ROWS_PITCH + 2 * lane) = r0;
-        *(double2*)(rows + (2 * wv + 1) * ROWS_PITCH + 2 * lane) = r1;
-    } else {
-        // rows 16 wv .. 16 wv + 15 of column block `blk`, transposed: rows[n][k]
-        const int r = 16 * wv + (lane >> 2), g = lane & 3;
-        const double* Br = Cm + (size_t)r * ld + 16 * blk + 4 * g;
-        const double2 c0 = *(const double2*)Br, c1 = *(const double2*)(Br + 2);
-        rows[(4 * g) * ROWS_PITCH + r] = c0.x; rows[(4 * g + 1) * ROWS_PITCH + r] = c0.y;
-        rows[(4 * g + 2) * ROWS_PITCH + r] = c1.x; rows[(4 * g + 3) * ROWS_PITCH + r] = c1.y;
-    }
-    __syncthreads();                 // the block is in LDS: from here on its memory may be overwritten (in place)
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* ar = rows + fr * ROWS_PITCH + 2 * fk;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (j < nj) {
-            const double2 v = *(const double2*)(ar + 8 * j);
-            // L part: A = the row block (LDS), B = X_kk's rows; X part: A = X_kk's rows, B = the column block (LDS)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l_part ? v.x : xo[2 * j], l_part ? xo[2 * j] : v.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(l_part ? v.y : xo[2 * j + 1], l_part ? xo[2 * j + 1] : v.y, acc, 0, 0, 0);
-        }
-    gptr_t C = (gptr_t)Cm + (l_part ? (size_t)(16 * blk + fk) * ld + 16 * wv + fr : (size_t)(16 * wv + fk) * ld + 16 * blk + fr);
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
-    signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
 // MODE 1, one single-wave workgroup per lower 16 x 16 block (36 per matrix, each on a CU of its own: 32 KiB of
 // operands per CU instead of 256)
-template <bool ARGS, bool QUEUE = false>
+template <bool ARGS>
 __global__ __launch_bounds__(64)
 void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t c_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-               unsigned* wait_timed_out, const unsigned* wait_flag2, unsigned wait_value2,
-               QueueCtl q, unsigned qop, int q_skip_wait, unsigned* start_flag, unsigned start_value)
+               unsigned* wait_timed_out, unsigned* start_flag, unsigned start_value)
 {
     RW_STAMP(0);
-    CHAIN_PRIO();
     // (launch_tile_rows: the flag of the launch BEFORE this one on the stream, raised here instead of at that one's end --
     // what it wrote is in memory by the time a workgroup of this launch runs)
     if (start_flag && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned long long tr0 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const bool st = !QUEUE && pa.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0;
+    const bool st = pa.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0;
     if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
-    if (QUEUE) { if (!q_skip_wait) q_await(q, blockIdx.y, qop); }
-    else await_flag(wait_flag, wait_value, wait_timed_out, wait_flag2, wait_value2);
+    await_flag(wait_flag, wait_value, wait_timed_out);
     if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long tr1 = QUEUE && q.trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     RW_STAMP(1);
     int P = 0;
     while ((P + 1) * (P + 2) / 2 <= (int)blockIdx.x) ++P;
@@ -411,75 +303,9 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
-    if (QUEUE) {
-        q_complete(q, blockIdx.y, qop, false);
-        if (q.trace && threadIdx.x == 0 && blockIdx.x == 0)
-            q_trace(q, (unsigned long long)q_entry(blockIdx.y, 0, qop) | (0xffffull << 32), tr0, tr1, __builtin_amdgcn_s_memrealtime());
-    } else {
-        if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-        signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
-    }
-    RW_STAMP(6);
-}
-
-// The block schedule's in-block updates (factor.hip): a LIST of 128 x 128 tile tasks at the same granularity -- one
-// single-wave workgroup per 16 x 16 block of the output, operands straight from global memory into MFMA operand
-// registers, 128 of K at a time (32 MFMAs).  Every operand / output mode of TileTask; a diagonal tile of a symmetric
-// update (modes bit 4) computes its lower blocks only.  Latency kernel: no LDS, no staging pipeline, a few microseconds
-// beside whatever fills the CUs (the throughput kernel needs 17-34 us for the same tasks on a loaded device).
-__global__ __launch_bounds__(64)
-void k_blk_update(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld,
-                  unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-                  unsigned* wait_timed_out)
-{
-    CHAIN_PRIO();
-    await_flag(wait_flag, wait_value, wait_timed_out);
-    const TileTask t = tasks[blockIdx.x >> 6];
-    const int P = (blockIdx.x >> 3) & 7, Q = blockIdx.x & 7;
-    const int c_mode = t.modes & 3, a_mode = (t.modes >> 2) & 1, b_mode = (t.modes >> 3) & 1;
-    if (!(((t.modes >> 4) & 1) && Q > P)) {           // (uniform)
-        double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
-        const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
-        // K index of a lane: load j brings k = 8 j + 2 fk and 8 j + 2 fk + 1 (the same split for both operands)
-        const double* A = gp[t.a_buf] + t.a_off + (a_mode ? (size_t)(2 * fk) * ld + 16 * P + fr : (size_t)(16 * P + fr) * ld + 2 * fk);
-        const double* B = gp[t.b_buf] + t.b_off + (b_mode ? (size_t)(2 * fk) * ld + 16 * Q + fr : (size_t)(16 * Q + fr) * ld + 2 * fk);
-        gptr_t C = (gptr_t)(gp[t.c_buf] + t.c_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
-        const size_t a_step = a_mode ? (size_t)8 * ld : 8, b_step = b_mode ? (size_t)8 * ld : 8;
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (c_mode == CM_SUB) {
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
-        }
-        const bool neg = c_mode != CM_SET;
-        for (int k0 = 0; k0 < t.klen; k0 += GPRN_TILE) {
-            double a[32], b[32];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                if (a_mode) { a[2 * j] = A[j * a_step]; a[2 * j + 1] = A[j * a_step + ld]; }
-                else { const double2 v = *(const double2*)(A + j * a_step); a[2 * j] = v.x; a[2 * j + 1] = v.y; }
-                if (b_mode) { b[2 * j] = B[j * b_step]; b[2 * j + 1] = B[j * b_step + ld]; }
-                else { const double2 v = *(const double2*)(B + j * b_step); b[2 * j] = v.x; b[2 * j + 1] = v.y; }
-            }
-            A += 16 * a_step; B += 16 * b_step;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(neg ? -a[j] : a[j], b[j], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
-    }
+    if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
-}
-
-int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld,
-                      hipStream_t stream, Signal sig, Await aw)
-{
-    if (ntasks == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_64x64, sig, aw);
-    prof_begin(c, GPRN_T_PANEL, stream);
-    hipLaunchKernelGGL(k_blk_update, dim3((unsigned)(64 * ntasks), (unsigned)nbatch), dim3(64), 0, stream, d_tasks,
-                       (double* const*)d_ptrs, ld, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
+    RW_STAMP(6);
 }
 
 // mode 0 / 1 as above, for tile step k: the operands are tiles (k+1, k), (k, k) [of X] resp. (k+1, k+1), (k+1, k) --
@@ -501,12 +327,10 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
     pa.stamps = step_stamp_ptr(c, k, mode == 0 ? 1 : 2);
     const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
     unsigned* const tmo = aw.timed_out ? aw.timed_out : sig.timed_out;
-    QueueCtl noq;
-    memset(&noq, 0, sizeof(noq));
-#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A, false>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
-                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0)
-#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A, false>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                   sig.slot, sig.value, aw.flag, aw.value, tmo, aw.flag2, aw.value2, noq, 0u, 0, raise_at_start, raise_value)
+#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
+                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo)
+#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
+                                   sig.slot, sig.value, aw.flag, aw.value, tmo, raise_at_start, raise_value)
     if (mode == 0) { if (args) GO_L(true); else GO_L(false); }
     else { if (args) GO_U(true); else GO_U(false); }
 #undef GO_L
@@ -514,78 +338,6 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
-}
-
-// the same two launches as nodes of the dataflow schedule (queue.hip)
-int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, hipStream_t stream,
-                       const QueueCtl& q, unsigned op, bool skip_wait)
-{
-    if (nbatch == 0) return GPRN_OK;
-    auto toff = [&](int ti, int tj) { return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE; };
-    const int64_t a_off = toff(k + 1, k), b_off = mode == 0 ? toff(k, k) : toff(k + 1, k);
-    const int64_t c_off = mode == 0 ? toff(k + 1, k) : toff(k + 1, k + 1);
-    prof_begin(c, GPRN_T_PANEL, stream);
-    double* const* tab = (double* const*)d_ptrs;
-    PtrArgs pa;
-    pa.stamps = nullptr;
-    const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
-    const unsigned* const nf = nullptr;
-    unsigned* const ns = nullptr;
-#define GO_LQ(A) hipLaunchKernelGGL((k_chain_l<A, true>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
-                                    b_off, ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0)
-#define GO_UQ(A) hipLaunchKernelGGL((k_chain_u<A, true>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                    ns, 0u, nf, 0u, ns, nf, 0u, q, op, skip_wait ? 1 : 0, ns, 0u)
-    if (mode == 0) { if (args) GO_LQ(true); else GO_LQ(false); }
-    else { if (args) GO_UQ(true); else GO_UQ(false); }
-#undef GO_LQ
-#undef GO_UQ
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
-}
-
-// C = A^T for a list of 128 x 128 tiles (block schedule, factor.hip: the mirrors of a panel back into place), one
-// workgroup per 64 x 64 quarter; modes bit 0: clear A afterwards
-__global__ __launch_bounds__(256)
-void k_tile_tcopy(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld)
-{
-    __shared__ double t[64][65];
-    const TileTask tk = tasks[blockIdx.x >> 2];
-    const int q = blockIdx.x & 3, qr = q >> 1, qc = q & 1;          // quarter of the source tile
-    double* const* gp = ptrs + (size_t)blockIdx.y * GPRN_NBUF;
-    double* const A = gp[tk.a_buf] + tk.a_off + (size_t)qr * 64 * ld + qc * 64;
-    double* const C = gp[tk.c_buf] + tk.c_off + (size_t)qc * 64 * ld + qr * 64;
-    const int col = threadIdx.x & 63, r0 = threadIdx.x >> 6;
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int r = r0 + 4 * it;
-        t[r][col] = A[(size_t)r * ld + col];
-        if (tk.modes & 1) A[(size_t)r * ld + col] = 0.0;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int r = r0 + 4 * it;
-        C[(size_t)r * ld + col] = t[col][r];
-    }
-}
-
-int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld, hipStream_t stream)
-{
-    if (ntasks == 0 || nbatch == 0) return GPRN_OK;
-    prof_begin(c, GPRN_T_PANEL, stream);
-    hipLaunchKernelGGL(k_tile_tcopy, dim3((unsigned)(4 * ntasks), (unsigned)nbatch), dim3(256), 0, stream, d_tasks,
-                       (double* const*)d_ptrs, ld);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
-}
-
-static int xcd_map()                               // GPRN_XCD_MAP=0: grid order as dispatched (experiments)
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GPRN_XCD_MAP"); v = e ? atoi(e) : 4; if (v == 1) v = 4; if (v < 0 || v > 8) v = 4; }
-    return v;
 }
 
 // LDS one workgroup may ask for on this device (static + dynamic).  A launch beyond it is not refused by the
@@ -615,15 +367,15 @@ static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doub
     if (dyn && static_lds + dyn > lds_limit(c->device)) {
         c->err = "tile launch: " + std::to_string(static_lds) + " B of LDS plus a pad of " + std::to_string(dyn) +
                  " B exceed the " + std::to_string(lds_limit(c->device)) + " B a workgroup may have on this device "
-                 "(GPRN_BULK_PAD_KB / GPRN_PAD_SMALL_KB / GPRN_CHAIN_PAD_KB or the *_pad_kb options)";
+                 "(options bulk_pad_kb / small_pad_kb)";
         return false;
     }
     constexpr int per_task = (GPRN_TILE / BM) * (GPRN_TILE / BN);
     constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
-                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, xcd_map(),
-                       aw.flag2, aw.value2, c->ft_s_now, c->N, c->start_flag_now, c->start_value_now);
+                       sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, GPRN_XCD_CHUNK_LOG2,
+                       c->ft_s_now, c->N, c->start_flag_now, c->start_value_now);
     return true;
 }
 
@@ -637,67 +389,29 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
         // the workgroups", and flags never go down) is written from the stream.  Signals and waits exist in
         // the flag schedule only, which requires stream memory operations (factor_use_flags).
         if (aw.flag) HIP_TRY(c, hipStreamWaitValue32(stream, (void*)aw.flag, aw.value, hipStreamWaitValueGte, 0xffffffffu));
-        if (aw.flag2) HIP_TRY(c, hipStreamWaitValue32(stream, (void*)aw.flag2, aw.value2, hipStreamWaitValueGte, 0xffffffffu));
         if (sig.slot && sig.value) HIP_TRY(c, hipStreamWriteValue32(stream, sig.slot + 1, sig.value, 0));
         if (sig.slot && sig.then_wait)
             HIP_TRY(c, hipStreamWaitValue32(stream, (void*)sig.then_wait, sig.then_value, hipStreamWaitValueGte, 0xffffffffu));
         return GPRN_OK;
     }
     prof_begin(c, fam, stream);
-    // Bulk launches on the look-ahead stream ask for 16 KiB of unused dynamic LDS on top of the
-    // 72 KiB image: one workgroup per CU instead of two.  Workgroups are never preempted and stream
-    // priorities do not reorder dispatch, so this is what keeps half of every CU's LDS and wave
-    // slots open for the latency chain's kernels (measured +4 % sweeps/s at config 3; a CU mask
-    // for the bulk stream measured worse).  GPRN_BULK_PAD_KB overrides.
-    static int pad_kb = -1;
-    if (pad_kb < 0) { const char* e = getenv("GPRN_BULK_PAD_KB"); pad_kb = e ? atoi(e) : 16; }
-    static int pad_fams = -1;                      // GPRN_PAD_FAMS: bit per family that gets the pad (default: the
-                                                   // bulk update and the X^T X product; the next-panel launches measured
-                                                   // slightly better without it)
-    if (pad_fams < 0) { const char* e = getenv("GPRN_PAD_FAMS"); pad_fams = e ? atoi(e) : ((1 << GPRN_T_UPDATE) | (1 << GPRN_T_UPDATE_AHEAD) | (1 << GPRN_T_LAUUM)); }
-    static int pad_all = -1;                       // GPRN_PAD_ALL=1 (probes): pad on every stream
-    if (pad_all < 0) { const char* e = getenv("GPRN_PAD_ALL"); pad_all = e ? atoi(e) : 0; }
-    // Launches over one or two matrices (node half-sweep, sharded runs) ask for 64 KiB instead: one bulk
-    // workgroup per CU, so that those phases' chain and side kernels find room on every CU -- they are bound by the
-    // chains, not by the bulk (+3 % sweeps/s at config 3 in round 1, when the 67 KiB diagonal-block kernel could not
-    // share a CU with such a workgroup at all; with its 46.6 KiB of round 2, pads of 74 KiB -- no sharing again --
-    // measure the same).  GPRN_PAD_SMALL_KB / GPRN_PAD_SMALL_BATCH override.
-    static int pad_small_kb = -1, pad_small_batch = -1;
-    if (pad_small_kb < 0) { const char* e = getenv("GPRN_PAD_SMALL_KB"); pad_small_kb = e ? atoi(e) : 64; }
-    if (pad_small_batch < 0) { const char* e = getenv("GPRN_PAD_SMALL_BATCH"); pad_small_batch = e ? atoi(e) : 2; }
-    const int kb = nbatch <= pad_small_batch ? (c->pad_small_kb_opt >= 0 ? c->pad_small_kb_opt : pad_small_kb)
-                                             : (c->pad_kb_opt >= 0 ? c->pad_kb_opt : pad_kb);
-    size_t dyn = ((stream == c->stream2 || pad_all) && ((pad_fams >> fam) & 1)) ? (size_t)kb * 1024 : 0;
-    // the block schedule's side launches (panel products with the block inverse, "next"): the same pad, so that every CU
-    // keeps a diagonal-block kernel's worth of LDS and registers free whatever mix of them it runs
-    if (c->pad_side_now && stream != c->stream) dyn = (size_t)kb * 1024;
-    // The next-panel part of an outer update ("first" / "next", K = 512 on the side streams) starts at a panel boundary,
-    // when the chain's next diagonal block is about to be dispatched: without a pad its workgroups fill every CU three
-    // deep and the block waits for a CU to drain (GPRN_PAD_NEXT_KB / GPRN_PAD_NEXT_SMALL_KB, KiB; -1: none)
-    static int pad_next_kb = -2, pad_next_small_kb = -2;
-    if (pad_next_kb == -2) { const char* e = getenv("GPRN_PAD_NEXT_KB"); pad_next_kb = e ? atoi(e) : -1; }
-    if (pad_next_small_kb == -2) { const char* e = getenv("GPRN_PAD_NEXT_SMALL_KB"); pad_next_small_kb = e ? atoi(e) : -1; }
-    if (tag == TG_NEXT && stream != c->stream) {
-        const int nk = nbatch <= pad_small_batch ? pad_next_small_kb : pad_next_kb;
-        if (nk >= 0) dyn = (size_t)nk * 1024;
-    }
-    // The chain's own tile launches (one task: L_{k+1,k}, the B_{k+1,k+1} update) can ask for unused LDS too: with
-    // enough of it they only land on CUs that run no bulk workgroup and are not slowed by MFMA-saturating
-    // neighbours (GPRN_CHAIN_PAD_KB, experiments).
-    static int chain_pad_kb = -1;
-    if (chain_pad_kb < 0) { const char* e = getenv("GPRN_CHAIN_PAD_KB"); chain_pad_kb = e ? atoi(e) : 0; }
-    const int chain_kb = c->chain_pad_kb_opt >= 0 ? c->chain_pad_kb_opt : chain_pad_kb;
-    if (chain_kb && ntasks == 1 && (stream == c->stream || stream == c->stream4)) dyn = (size_t)chain_kb * 1024;
+    // Bulk launches on the look-ahead stream (the K = 512 trailing updates, the X^T X product) ask for 16 KiB of unused
+    // dynamic LDS on top of their image: two 64 x 64 workgroups per CU instead of three (one 128 x 128 instead of two).
+    // Workgroups are never preempted and stream priorities do not reorder dispatch, so this is what keeps part of every
+    // CU's LDS and wave slots open for the latency chain's kernels (measured +4 % sweeps/s at config 3; a CU mask for the
+    // bulk stream measured worse; pads of 0 / 8 / 24 KiB 112.0 / 113.5 / 113.7 against 114.2 with 16).  Launches over one
+    // or two matrices (node half-sweep, sharded runs) ask for 64 KiB: one such workgroup per CU -- those phases are bound by
+    // their chains, not by the bulk.  Options "bulk_pad_kb" / "small_pad_kb" override (tests).
+    const int kb = nbatch <= 2 ? (c->pad_small_kb_opt >= 0 ? c->pad_small_kb_opt : 64) : (c->pad_kb_opt >= 0 ? c->pad_kb_opt : 16);
+    const bool padded_fam = fam == GPRN_T_UPDATE || fam == GPRN_T_UPDATE_AHEAD || fam == GPRN_T_LAUUM;
+    const size_t dyn = (stream == c->stream2 && padded_fam) ? (size_t)kb * 1024 : 0;
     double* const* tab = (double* const*)d_ptrs;
 #define GO(BM, BN, TRI, TAG) fits = launch_one<BM, BN, TRI, TAG>(c, d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw)
     bool known = true, fits = true;
     switch (shape * 8 + tag) {
-    // panel products (K = 128 against the triangular X_kk; the plain forms when GPRN_TRI=0)
+    // panel products (K = 128 against the triangular X_kk)
     case TS_64x128_BTRI * 8 + TG_PANEL: GO(64, 128, 1, TG_PANEL); break;
     case TS_128x64_ATRI * 8 + TG_PANEL: GO(128, 64, 2, TG_PANEL); break;
-    case TS_64x128 * 8 + TG_PANEL: GO(64, 128, 0, TG_PANEL); break;
-    case TS_128x64 * 8 + TG_PANEL: GO(128, 64, 0, TG_PANEL); break;
-    case TS_128x128 * 8 + TG_PANEL: GO(128, 128, 0, TG_PANEL); break;
     // in-panel updates, K = 128
     case TS_64x64 * 8 + TG_INNER: GO(64, 64, 0, TG_INNER); break;
     case TS_128x128 * 8 + TG_INNER: GO(128, 128, 0, TG_INNER); break;
@@ -707,17 +421,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // bulk of an outer update, K = 512
     case TS_64x64 * 8 + TG_BULK: GO(64, 64, 0, TG_BULK); break;
     case TS_128x128 * 8 + TG_BULK: GO(128, 128, 0, TG_BULK); break;
-    // (experiments, GPRN_BULK_SHAPE=2/3: the 4-wave 64 x 128 / 128 x 64 forms for the bulk)
-    case TS_64x128 * 8 + TG_BULK: GO(64, 128, 0, TG_BULK); break;
-    case TS_128x64 * 8 + TG_BULK: GO(128, 64, 0, TG_BULK); break;
-    case TS_64x128 * 8 + TG_AHEAD: GO(64, 128, 0, TG_AHEAD); break;
-    case TS_128x64 * 8 + TG_AHEAD: GO(128, 64, 0, TG_AHEAD); break;
     // ... its look-ahead part (what the next panel's outer update writes again), a launch of its own
     case TS_64x64 * 8 + TG_AHEAD: GO(64, 64, 0, TG_AHEAD); break;
     case TS_128x128 * 8 + TG_AHEAD: GO(128, 128, 0, TG_AHEAD); break;
-    // block schedule: a panel's products with the inverse of its diagonal block, K <= 512
-    case TS_64x64 * 8 + TG_TRMM: GO(64, 64, 0, TG_TRMM); break;
-    case TS_128x128 * 8 + TG_TRMM: GO(128, 128, 0, TG_TRMM); break;
     // X^T X, prediction products, diagnostics
     case TS_128x128 * 8 + TG_MISC: GO(128, 128, 0, TG_MISC); break;
     case TS_64x64 * 8 + TG_MISC: GO(64, 64, 0, TG_MISC); break;

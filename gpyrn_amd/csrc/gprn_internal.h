@@ -16,6 +16,9 @@
 #define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
 #define GPRN_OUTER 4           // tiles per outer panel: bulk updates contract over 4*128 = 512
 #define GPRN_OUTER_SMALL 16    // ... when batch x tiles <= 32 (latency-bound: measured +11 % at N=2048, batch 1)
+#define GPRN_LAT_MAX 32        // batch x tiles up to which a factorisation runs on the latency set of task lists
+#define GPRN_FEW_TASKS 4000    // tasks x batch above which a tile launch uses 128 x 128 workgroups (100 ... 8000 swept)
+#define GPRN_XCD_CHUNK_LOG2 4  // consecutive task-list entries that meet in one XCD's L2 (k_tile_gemm): 16
 
 // Pointers fetched from a device pointer table are generic to the compiler, which then emits
 // FLAT loads; those also tick the LDS counter (lgkmcnt), so the wait before the first MFMA of
@@ -57,48 +60,6 @@ static inline uint8_t tile_modes(int c_mode, int a_mode, int b_mode, int lower_o
         }                                                                      \
     } while (0)
 
-// ---- dataflow schedule of the factorisation (queue.hip) -------------------------------------
-// The factorisation as ONE task graph per matrix: the latency chain's three kernels per tile step stay launches
-// on the chain stream; every other tile product is a node that a persistent worker kernel executes as soon as
-// its inputs exist.  Dependencies are edges between tasks (derived on the host from the sequential algorithm:
-// read-after-write, write-after-write, write-after-read on 128 x 128 tiles); a finished task decrements its
-// successors' counters and pushes the ones that reach zero onto a ready queue of their priority class.
-struct QOp {                       // one node (the graph is the same for every matrix of a batch)
-    TileTask t;                    // tile nodes: the product; chain nodes: unused
-    uint32_t succ0, nsucc;         // successors: succ[succ0 .. succ0 + nsucc)
-    uint8_t kind, cls, nent, flags;// QK_*; priority class; ready-queue entries the node is pushed as; QF_*
-    uint8_t pad[4];
-};
-enum { QK_TILE = 0, QK_PANEL_L = 1, QK_PANEL_X = 2, QK_CHAIN = 3 };
-enum { QF_DIAG_SYRK = 1 };         // C -= A A^T on a diagonal tile: the upper-right 64 x 64 quarter is never read
-#define GPRN_QCLASSES 5            // ready queues, most urgent first; the last holds the previous phase's X^T X
-#define GPRN_QCTR_STRIDE 32        // words between two counters (a 128-byte line each)
-// counters of a call (index x GPRN_QCTR_STRIDE words into QueueCtl::ctr): per class the head hint and the tail, entries
-// not finished yet, the time-out word (+1: budget), the doorbell idle workers watch, CUs registered per XCD (8 words in
-// one line); behind them the CU registry (one word per CU) and an image of the control block
-enum { QC_HEAD = 0, QC_TAIL = GPRN_QCLASSES, QC_LEFT = 2 * GPRN_QCLASSES, QC_TIMEOUT, QC_BELL, QC_XCC, QC_COUNT };
-#define GPRN_QCU_WORDS 1024        // registry: word xcc * 128 + se * 32 + sh * 16 + cu
-#define GPRN_QCTR_WORDS (QC_COUNT * GPRN_QCTR_STRIDE + GPRN_QCU_WORDS)
-#define GPRN_Q_EMPTY 0xffffffffu       // slot of a ready queue: nothing pushed yet
-#define GPRN_Q_TAKEN 0xfffffffeu       // ... its entry has been claimed
-#define GPRN_Q_WHOLE 7u            // sub-tile field of a queue entry: the whole 128 x 128 node
-struct QueueCtl {                  // by value to every kernel that takes part
-    const QOp* ops;
-    const uint32_t* succ;
-    unsigned* state;               // [matrix][node]: bits 0-15 unmet dependencies, bits 16-31 entries not finished
-    unsigned* slots[GPRN_QCLASSES];
-    unsigned cap[GPRN_QCLASSES];
-    unsigned* ctr;                 // counters (QC_*), GPRN_QCTR_STRIDE words apart, then the CU registry
-    unsigned* timed_out;           // [0] sticky "a wait gave up", [1] budget of one wait, 100 MHz ticks
-    unsigned long long* trace;     // GPRN_QUEUE_TRACE: [0] records written, then 4 words per record (queue.hip); else null
-    int nops, trace_cap, call_id;
-    int per_cu, reserve_per_xcc;   // workers that stay per CU; CUs per XCD left to the chain's kernels (0 workers)
-};
-#ifdef __HIPCC__
-__host__ __device__
-#endif
-static inline unsigned q_entry(unsigned m, unsigned sub, unsigned op) { return (m << 24) | (sub << 21) | op; }
-
 struct Profiler {
     bool on = false;
     struct Rec { int fam; hipEvent_t a, b; };
@@ -128,19 +89,11 @@ struct gprn_ctx {
     hipStream_t stream = nullptr;    // everything, incl. the latency chain of the factorisation
     hipStream_t stream2 = nullptr;   // bulk trailing updates running behind the chain (look-ahead)
     hipStream_t stream3 = nullptr;   // in-panel work that is off the chain (panel rest, inner rest)
-    hipStream_t stream4 = nullptr;   // the chain's two tile launches of a step, dispatched ahead of their inputs
-    int chain_streams = -1;          // 1: the chain runs on two streams (diagonal blocks | tile launches) whose
-                                     // kernels wait for each other in-kernel; 0: one stream; -1: not probed yet
+    hipStream_t stream4 = nullptr;   // the next panel's share of an outer update ("next"), beside the previous panel's "rest"
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr, ev_resta = nullptr;
-    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr, ev_xw = nullptr;
+    hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
     // head / tail of a phase beside its factorisation (run_phase, api.hip; factor_invert_split, factor.hip)
     hipEvent_t ev_tail = nullptr;
-    // second set of node workspaces + table (sweep_impl: a sweep's X^T X beside the next sweep's node phase)
-    std::vector<double*> wsB2, wsX2;
-    double** tab_node2 = nullptr;
-    double* d_s_keep = nullptr;      // copy of the node slots' s = sqrt(d) for the deferred Q1 traces
-    bool node_alt = false, defer_sweep_end = false;
-    std::function<int(const double* s_nodes)> q1_work;   // run_phase(nodes) -> whoever runs the Q1 product and traces
     bool node_term_done = false;     // the node phase's mu^T K^-1 mu went to the bulk stream beside the weight phase (run_phase)
     // run_phase: called (by schedules that know) once tile rows [r0, r1) of X are final in `stream` order -- the O(N^2)
     // reductions over X's rows (X z, column norms, X^T u) then run beside the rest of the factorisation instead of
@@ -233,11 +186,10 @@ struct gprn_ctx {
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
     std::string last_timeout;        // which flag the last time-out was waiting for (factor_check_waits)
     // LDS pads of the tile launches (gemm_tile.hip launch_tiles), KiB; -1: the environment's / the default
-    int pad_kb_opt = -1, pad_small_kb_opt = -1, chain_pad_kb_opt = -1;
+    int pad_kb_opt = -1, pad_small_kb_opt = -1;
     int sig_budget_ms = -1;          // budget the device word holds
-    // enqueued by the next factor_invert right behind the start of its persistent chain kernel (factor.hip)
+    // enqueued by the next factor_invert behind its first diagonal block (factor.hip)
     std::function<int()> chain_started;
-    unsigned long long* d_stamps = nullptr;   // GPRN_CHAIN_STAMPS: clock stamps of the chain kernel (probes)
     // GPRN_STEP_STAMPS=1 (probes): per tile step and chain kernel (diag, L, U) the 100 MHz clock at its start, after its
     // wait and at its end -- the launch schedule's chain as it really ran (a kernel trace slows the chain's small
     // kernels by 15 %); [phase slot][T][3 kernels][3 stamps], printed by factor_check_waits
@@ -248,63 +200,26 @@ struct gprn_ctx {
     int step_stamps_batch[8] = {0};
     unsigned long long *d_side_stamps = nullptr, *side_stamps = nullptr;   // GPRN_STEP_STAMPS=2: stream3's clock, [T][8]
     int side_stamps_ph = -1;
-    int stamps_T = 0;
     size_t tasks_cap = 0;
-    // dataflow schedule (queue.hip): one plan per (T, set), device buffers grown on demand
-    struct QueuePlanRef* qplan[2] = {nullptr, nullptr};
-    unsigned* d_qstate = nullptr; size_t qstate_cap = 0;
-    unsigned* d_qslots = nullptr; size_t qslots_cap = 0;
-    unsigned* d_qctr = nullptr;      // counters + time-out word + budget
-    hipEvent_t ev_qreset = nullptr, ev_qdone = nullptr;
-    int queue_mode = -1;             // 1: dataflow schedule when device-side waits are usable; 0: launches; -1: environment
-    int q_budget_ms = -1;
-    // X^T X of the previous phase handed to the next factorisation's worker kernel as filler (run_phase, api.hip)
-    struct { int n = 0; std::vector<double*> rows; } q_lauum;     // rows: n x GPRN_NBUF pointers (BUF_B out, BUF_X in)
-    bool q_lauum_in_queue = false;   // while the hand-over hook runs: the product was the worker kernel's
-    unsigned long long* d_qstats = nullptr;   // GPRN_QUEUE_STATS=1: per-worker tick counters (queue.hip)
-    unsigned long long* d_qtrace = nullptr;   // GPRN_QUEUE_TRACE=n: n records of what ran when (queue.hip)
-    int qtrace_cap = 0, q_calls = 0;
     std::vector<TileTask> h_tasks;
     struct StepRange { size_t panel0, npanel_l, npanel, upd0, nupd, ncol1; };   // per tile step: panel (L part first, then X part), in-panel update (the first ncol1 tasks: the chain's own tile and the two its next step touches)
     // two sets: [0] throughput schedule (outer panel = GPRN_OUTER tiles), [1] latency schedule for
     // small problems (batch x tiles <= 32; wider outer panels: fewer bulk-update joins on the chain)
     std::vector<StepRange> steps[2]; // T entries each
-    // left-looking form of a step's updates (throughput set only; ensure_tasks): column k+1 of the panel with everything
-    // the panel has produced so far (K = 128 (k + 1 - k0)) instead of every remaining column with column k alone
-    struct LStep { size_t u0, nu, ncrit; };
-    std::vector<LStep> lsteps;
-    // the NEXT panel's share of an outer update column by column (GPRN_EAGER_NEXT; throughput set): step k's K = 128
-    // contribution to what "first" and "next" update with K = 512 at the panel boundary
-    struct EStep { size_t e0, ne; };
-    std::vector<EStep> esteps;
-    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, c1_0, nc1, nrestA;
-                        size_t grp0[GPRN_OUTER], ngrp[GPRN_OUTER];
-                        size_t fa0, nfa, fb0, nfb; };   // "first" in two parts: all but the panel's last column (early), the last column   // "next" by column / row of the next panel (1 .. GPRN_OUTER - 1)  // per outer panel of GPRN_OUTER tiles (the first nrestA of "rest": what the next panel's outer update touches again)
+    // per outer panel: the three parts of its K = (k1 - k0) * 128 update -- "first" (the next panel's first column of B and
+    // first row of R), "next" (the rest of the next panel's columns / rows), "rest" (everything beyond; its first nrestA
+    // tasks are what the NEXT panel's outer update writes again)
+    struct OuterRange { int k0, k1; size_t first0, nfirst, next0, nnext, rest0, nrest, nrestA; };
     std::vector<OuterRange> outers[2];
     size_t lauum0 = 0, nlauum = 0;
     int tasks_T = 0;
-    // ---- block schedule (factor_invert_blocks, factor.hip): the latency chain factors and inverts the 512 x 512
-    // diagonal block of an outer panel on its own; everything else of the panel is ONE triangular product per side
-    // with the block's inverse (K <= 512) and the K = 512 trailing update
-    struct BlkStep { size_t l0, nl_l, nl, u0, nu; };           // in-block: L tiles then X tiles of the step; its updates
-    struct BlkPanel { int k0, k1;
-                      size_t tl0, ntl, ntl_early;              // L[i, panel]^T -> mirror (BUF_X upper), rows of the next block first
-                      size_t tx0, ntx, cbx0;                   // X[panel, c]^T -> mirror (BUF_B upper); copy back into X (ntx tasks)
-                      size_t cbl0;                             // L mirror -> B lower (ntl tasks; callers that want L in place)
-                      size_t dn0, ndn, next0, nnext, rest0, nrest, nrestA; };
-    std::vector<BlkStep> bsteps;
-    std::vector<BlkPanel> bpanels;
     // run_phase -> factor_invert_split: s = sqrt(d) of the phase's slots when B's tiles beyond the first outer panel are
     // still to be formed -- by the first panel's K = 512 update, on the way in (tile_mma ft_K); ft_s_now: what launch_tiles
     // passes to the kernel right now (set around that update's launches only)
     int build_pending = 0;           // run_phase: B of this many slots is still to be built by the next factor_invert
     const double* ft_s_phase = nullptr;
     const double* ft_s_now = nullptr;
-    bool pad_side_now = false;       // launch_tiles: LDS pad on every launch off the chain stream (block schedule)
-    bool fast_factor = false;        // run_phase: the caller reads X's lower tiles and diag(L) only -- far tiles of L may
-                                     // stay in their mirror, the strictly upper tiles of both buffers are scratch
-    int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: environment / default
-    int block_sched = -1;            // gprn_set_option "block_sched": 1 block schedule where it applies, 0 never, -1 environment
+    int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: the default
 };
 
 struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)
@@ -327,8 +242,7 @@ enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
 // launch family of a tile launch: a template tag of k_tile_gemm, so that a kernel trace reports every
 // family under its own kernel name (panel products, in-panel K=128 updates, next-panel K=512 updates,
 // bulk K=512 updates, everything else)
-enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4, TG_AHEAD = 5,
-       TG_TRMM = 6 };   // block schedule: a panel's products with the inverse of its diagonal block (K <= 512)
+enum { TG_PANEL = 0, TG_INNER = 1, TG_NEXT = 2, TG_BULK = 3, TG_MISC = 4, TG_AHEAD = 5 };
 // Completion signal of a launch, raised from the device: slot[0] counts the workgroups that have
 // finished, the last one resets it and stores `value` to slot[1] (system scope).  Another stream
 // picks it up with hipStreamWaitValue32 about 2 us later (_probe/streamvalue.hip) -- no event
@@ -342,8 +256,7 @@ struct Signal {
 // The other direction, for launches of a FEW workgroups only (a spinning launch that fills the GPU
 // could keep its own producer from being dispatched): every workgroup of the launch waits at its
 // start until *flag >= value; a wait that times out (about a second) sets *timed_out and goes on.
-struct Await { const unsigned* flag; unsigned value; unsigned* timed_out;
-               const unsigned* flag2; unsigned value2; };       // optional second flag, same time-out word
+struct Await { const unsigned* flag; unsigned value; unsigned* timed_out; };
 size_t lds_limit(int device);         // LDS bytes one workgroup may ask for, static + dynamic (gemm_tile.hip)
 int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs,
                  int nbatch, int ld, int fam, hipStream_t stream = nullptr, int shape = TS_128x128,
@@ -355,14 +268,8 @@ int launch_grad_fd(gprn_ctx* c, const KernelSpec& ks, const double* Kinv, const 
                    double* part, double* out);
 // the L part (n_l tasks) and the X part (n_x tasks) of a tile step's panel in one launch (gemm_tile.hip)
 int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
-                 hipStream_t stream, Signal sig, Await aw = Await{nullptr, 0, nullptr, nullptr, 0},
+                 hipStream_t stream, Signal sig, Await aw = Await{nullptr, 0, nullptr},
                  unsigned* raise_at_start = nullptr, unsigned raise_value = 0, unsigned* raise_at_start2 = nullptr);
-// block schedule: the in-block panel of a tile step at 16-row / 16-column granularity; C = A^T over a list of tiles
-int launch_panel_rows(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, double** d_ptrs, int nbatch, int ld,
-                      hipStream_t stream, Signal sig, Await aw);
-int launch_blk_update(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld,
-                      hipStream_t stream, Signal sig, Await aw);   // a list of tile tasks, one wave per 16 x 16 block
-int launch_tcopy(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d_ptrs, int nbatch, int ld, hipStream_t stream);
 // BUF_B and BUF_X of up to GPRN_ARG_SLOTS matrices as a kernel argument
 #define GPRN_ARG_SLOTS 16
 struct PtrArgs { double* p[GPRN_ARG_SLOTS][2];
@@ -379,17 +286,9 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
                      hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start = nullptr, unsigned raise_value = 0);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
-                Await aw = Await{nullptr, 0, nullptr, nullptr, 0});
+                Await aw = Await{nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
-// The latency chain's kernels (diagonal block, L_{k+1,k}, the B_{k+1,k+1} update) share their CUs with throughput
-// workgroups whose waves keep the SIMDs' issue slots and matrix pipes busy; with -DGPRN_CHAIN_PRIO=3 the chain's waves ask
-// for the highest issue priority (s_setprio).  Measured (round 3, two builds side by side): no difference -- 108.1 / 108.3
-// vs 108.3 / 108.3 sweeps/s at config 3, 680 / 684 vs 685 / 684 at config 2 -- so it is off.
-#ifndef GPRN_CHAIN_PRIO
-#define GPRN_CHAIN_PRIO 0
-#endif
-#define CHAIN_PRIO() do { if (GPRN_CHAIN_PRIO > 0) __builtin_amdgcn_s_setprio(GPRN_CHAIN_PRIO); } while (0)
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
 // timed_out[1] the budget of one wait in ticks of the 100 MHz constant clock (s_memrealtime): a wall-clock
 // bound, not a spin count -- on a shared device a legitimate wait can be long.  Once any wait of the call
@@ -401,11 +300,7 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value,
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long budget = timed_out ? (unsigned long long)timed_out[1] : 200000000ull;
         for (;;) {
-#ifdef GPRN_SPIN_SLEEP
-            __builtin_amdgcn_s_sleep(GPRN_SPIN_SLEEP);
-#else
             __builtin_amdgcn_s_sleep(8);
-#endif
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) break;
             if (timed_out && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
@@ -421,14 +316,10 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned value,
 }
 
 // start of a kernel: every thread of the workgroup calls it
-__device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out,
-                                           const unsigned* flag2 = nullptr, unsigned value2 = 0)
+__device__ __forceinline__ void await_flag(const unsigned* flag, unsigned value, unsigned* timed_out)
 {
-    if (!flag && !flag2) return;                    // uniform
-    if (threadIdx.x == 0) {
-        if (flag) spin_until(flag, value, timed_out);
-        if (flag2) spin_until(flag2, value2, timed_out);
-    }
+    if (!flag) return;                              // uniform
+    if (threadIdx.x == 0) spin_until(flag, value, timed_out);
     __syncthreads();
 }
 
@@ -464,17 +355,4 @@ int ensure_tasks(gprn_ctx* c);
 #define GPRN_E_WAIT_TIMEOUT (-100)
 int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel dependency wait timed out since the last check
 int factor_use_flags(gprn_ctx* c);
-// queue.hip
-int queue_enabled(gprn_ctx* c);                          // dataflow schedule for this context's next factorisation?
-int factor_invert_queue(gprn_ctx* c, int nbatch, int set);
-void queue_free(gprn_ctx* c);
-void queue_print_stats(gprn_ctx* c);
-int queue_run_independent(gprn_ctx* c, const std::vector<TileTask>& tasks, double** d_ptrs, int ld, bool whole, int reps, float* ms);
-int queue_check_waits(gprn_ctx* c);                      // GPRN_E_WAIT_TIMEOUT if a wait of the dataflow schedule gave up
-// chain kernels inside the dataflow schedule: op = node of the launch (same for every matrix), skip_wait: the launch is
-// preceded by a one-wave wait kernel on its stream and does not poll itself
-int launch_diag_q(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
-                  const QueueCtl& q, unsigned op);
-int launch_tile_rows_q(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, hipStream_t stream,
-                       const QueueCtl& q, unsigned op, bool skip_wait);
-int factor_probe_streams(gprn_ctx* c);
+

@@ -1,6 +1,5 @@
-// The tile contraction shared by k_tile_gemm (gemm_tile.hip) and the factorisation's persistent chain kernel
-// (factor.hip): one workgroup of WM x WN waves computes a BM x BN tile  C (op)= A . B  over klen on
-// v_mfma_f64_16x16x4_f64.  See gemm_tile.hip for the design notes.
+// The tile contraction of k_tile_gemm / k_tile_panel (gemm_tile.hip): one workgroup of WM x WN waves computes a
+// BM x BN tile  C (op)= A . B  over klen on v_mfma_f64_16x16x4_f64.  See gemm_tile.hip for the design notes.
 #pragma once
 #include "gprn_internal.h"
 
@@ -13,9 +12,6 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 #ifndef GPRN_DEEP_PREFETCH
 #define GPRN_DEEP_PREFETCH 1
-#endif
-#ifndef GPRN_DEEP_SETS
-#define GPRN_DEEP_SETS 2
 #endif
 
 // Staging geometry.  A thread moves R*8/NT 16-byte pieces of an operand chunk (R rows x 16 k); piece `it`
@@ -45,11 +41,6 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // operands; modes as in TileTask; mb16_0 / nb16_0: index of the part's first 16-row / 16-column block inside
 // its 128 x 128 tile (TRI).  Every thread of the workgroup calls it; the last LDS reads are retired on return
 // only after the caller's next barrier.
-// WSEL >= 0 (SYRK only): the calling wave's index as a compile-time constant -- the caller switches on the wave
-// and every wave runs its own copy, in which "which blocks are mine" is resolved at compile time (no per-MFMA
-// branches, no registers for the blocks of other waves).  out_img (SYRK only): instead of storing the lower
-// blocks to C, leave them in LDS for the caller: block (P, Q), P >= Q, at out_img + (P (P + 1) / 2 + Q) * 256,
-// 16 x 16 row-major.
 // LOWER: the part lies on the diagonal of a symmetric update C -= A A^T of which only the lower triangle is ever read
 // (the factorisation's diagonal tiles): 16 x 16 blocks strictly above the diagonal (block column > block row inside the
 // 128 x 128 tile) are loaded and stored back unchanged, their MFMAs skipped.
@@ -57,18 +48,17 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // formed from K (same offsets as C) and s = sqrt(d): delta + (s_row s_col) K, zero outside the n x n problem -- what
 // k_build_B would have written there (same expression, same rounding).  ft_row / ft_col: the part's first row / column
 // inside the matrix.
-// DEEP_OK: the caller's register budget allows the second set of staging registers (the launch kernel's 64 x 64 form: 110
-// registers per lane; the dataflow schedule's worker is held to 96 and keeps the one-set pipeline)
-template <int BM, int BN, int WM, int WN, int TRI, bool SYRK, int WSEL = -1, bool LOWER = false, bool DEEP_OK = false>
+// DEEP_OK: the caller's register budget allows the second set of staging registers (the 64 x 64 form: 110 registers per lane)
+template <int BM, int BN, int WM, int WN, int TRI, bool LOWER = false, bool DEEP_OK = false>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
                                          int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
-                                         double* out_img = nullptr, const double* ft_K = nullptr,
+                                         const double* ft_K = nullptr,
                                          const double* ft_s = nullptr, int ft_row = 0, int ft_col = 0, int ft_n = 0)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // in an SGPR: conditions on it are scalar branches
-    const int wr = WSEL >= 0 ? WSEL : wave / WN, wc = WSEL >= 0 ? 0 : wave % WN;
+    const int wr = wave / WN, wc = wave % WN;
     constexpr int NT = 64 * WM * WN;
     constexpr int TM = BM / WM, TN = BN / WN;                   // a wave's part of the tile
     constexpr int MI = TM / 16, NI = TN / 16;                   // 16x16 MFMA tiles per wave
@@ -78,7 +68,6 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;       // 16-byte loads per thread per chunk
     constexpr bool A_ROWS2 = BM * 4 > NT, B_ROWS2 = BN * 4 > NT;   // the pieces of a thread span 2 x 64 rows
     static_assert(A_IT >= 1 && B_IT >= 1 && NI >= 1 && (MI % 2 == 0) && (NI % 2 == 0), "tile too small for the workgroup");
-    static_assert(!SYRK || (BM == 128 && BN == 128 && WM == 4 && WN == 1 && TRI == 0), "SYRK: 128x128 on 4 x 1 waves");
 
     // ---- global -> LDS staging (lane_geometry): buffer loads = uniform base (advanced per chunk) + lane
     // offset + uniform piece offset; the two doubles of a piece go to lane base (+ dl) + immediate
@@ -97,12 +86,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     // k4-step ks = lane base[ks] + immediate (16-row block, stage)
     const int fr = lane & 15, fk = lane >> 4;
     const int mb16 = mb16_0 + ((wr * TM) >> 4), nb16 = nb16_0 + ((wc * TN) >> 4);   // wave's first 16-blocks
-    // SYRK (C -= A A^T, lower blocks only, 4 x 1 waves): wave w takes the 16-row blocks w and 7-w -- 9 of the
-    // 36 lower blocks each -- instead of two adjacent ones
-    const int row0 = SYRK ? 16 * wr : wr * TM;                 // first row of the wave's block i = 0
-    const int row1_off = SYRK ? 16 * (7 - 2 * wr) : 16;        // rows from block i = 0 to block i = 1 (SYRK: MI = 2)
-    const int blk[2] = {SYRK ? wr : 0, SYRK ? 7 - wr : 0};     // SYRK: 16-block row index of block i
-    static_assert(WSEL < 0 || SYRK, "WSEL is for the SYRK form");
+    const int row0 = wr * TM;                                  // first row of the wave's block i = 0
     int a_fb[4], b_fb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -116,8 +100,8 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
 
     const bool neg = c_mode != CM_SET;                       // acc holds -(result)
     gptr_t Cw = C + (size_t)(row0 + fk) * ld + wc * TN + fr;
-    auto crow = [&](int i) { return SYRK ? (size_t)(i * row1_off) : (size_t)(i * 16); };   // rows of block i past Cw
-    auto arow_bytes = [&](int i) { return SYRK ? i * row1_off * 8 : i * 128; };           // same, LDS bytes
+    auto crow = [&](int i) { return (size_t)(i * 16); };       // rows of block i past Cw
+    auto arow_bytes = [&](int i) { return i * 128; };          // same, LDS bytes
     v4d acc[MI][NI];
 
     const int nchunks = klen / GPRN_KC;
@@ -126,12 +110,10 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     // of its cycles at a wait, a third of the L2 requests miss, and with two or three waves per SIMD that leaves the
     // matrix pipes idle a third of the time -- one chunk period (16 MFMAs per wave) is not enough to cover an L2 miss.
     // (GPRN_DEEP_PREFETCH=2: the 4-wave 64 x 128 / 128 x 64 forms too, i.e. the panel products)
-    constexpr bool DEEP = DEEP_OK && !SYRK && WM == 2 && WN == 2 &&
+    constexpr bool DEEP = DEEP_OK && WM == 2 && WN == 2 &&
                           ((GPRN_DEEP_PREFETCH >= 1 && BM == 64 && BN == 64) || (GPRN_DEEP_PREFETCH >= 2 && BM * BN == 64 * 128));
     v2d ra[A_IT], rb[B_IT];
     v2d ra2[DEEP ? A_IT : 1], rb2[DEEP ? B_IT : 1];
-    constexpr bool DEEP3 = DEEP && GPRN_DEEP_SETS >= 3;        // (experiments: a third set, four chunks ahead)
-    v2d ra3[DEEP3 ? A_IT : 1], rb3[DEEP3 ? B_IT : 1];
     auto load_chunk = [&](v2d (&ra)[A_IT], v2d (&rb)[B_IT]) {
         // raw buffer resources over the chunk's base: 48-bit address, no stride, no bounds (num_records max)
         const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
@@ -194,7 +176,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] = (SYRK && j > blk[i]) ? 0.0 : -Cw[(crow(i) + 4 * r) * ld + j * 16];
+                    acc[i][j][r] = -Cw[(crow(i) + 4 * r) * ld + j * 16];
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -208,10 +190,6 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     if constexpr (DEEP) {
         if (nchunks > 2) { A += a_step; B += b_step; }
         load_chunk(ra2, rb2);                    // chunk 2 (or the last one once more)
-        if constexpr (DEEP3) {
-            if (nchunks > 3) { A += a_step; B += b_step; }
-            load_chunk(ra3, rb3);                // chunk 3
-        }
     }
     __syncthreads();
 
@@ -245,7 +223,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
             if (ks == 1 && !LAST) {
                 write_chunk(nb, rx, ry);
                 // chunk c+2 (DEEP: c+3), or once more the last one (its registers are not read again)
-                const bool more = c + (DEEP3 ? 4 : (DEEP ? 3 : 2)) < nchunks;
+                const bool more = c + (DEEP ? 3 : 2) < nchunks;
                 A += more ? a_step : 0;
                 B += more ? b_step : 0;
                 load_chunk(rx, ry);
@@ -256,13 +234,12 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
                 for (int j = 0; j < NI; ++j) {
                     if (TRI == 1 && c > nb16 + j) continue;     // wave-uniform
                     if (TRI == 2 && c > mb16 + i) continue;
-                    if (SYRK && j > blk[i]) continue;
                     if (LOWER && nb16 + j > mb16 + i) continue;   // wave-uniform
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[cur][j], acc[i][j], 0, 0, 0);
                 }
                 if (fetch) af[i] = frag(fb_off + a_fb[fb_ks] + arow_bytes(i));
             }
-            if (TRI == 0 && !SYRK) {
+            if (TRI == 0) {
                 // issue order of this step: MFMAs and memory instructions in turn (adjacent fragment
                 // reads pair up into ds_read2_b64: (MI + NI) / 2 read instructions per step)
                 constexpr int NMF = MI * NI, NRD = (MI + NI) / 2;
@@ -287,20 +264,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
         }
     };
     int sb = 0;
-    if constexpr (DEEP3) {
-        int c = 0;
-        for (; c + 2 < nchunks - 1; c += 3) {
-            chunk(std::false_type{}, sb, c, ra, rb);
-            sb ^= STAGE * 8;
-            chunk(std::false_type{}, sb, c + 1, ra2, rb2);
-            sb ^= STAGE * 8;
-            chunk(std::false_type{}, sb, c + 2, ra3, rb3);
-            sb ^= STAGE * 8;
-        }
-        if (c < nchunks - 1) { chunk(std::false_type{}, sb, c, ra, rb); sb ^= STAGE * 8; ++c; }
-        if (c < nchunks - 1) { chunk(std::false_type{}, sb, c, ra2, rb2); sb ^= STAGE * 8; }
-        chunk(std::true_type{}, sb, nchunks - 1, ra, rb);
-    } else if constexpr (DEEP) {
+    if constexpr (DEEP) {
         // chunk c writes chunk c+1 to LDS from the set that holds it (odd: A, even: B) and refills that set with c+3
         int c = 0;
         for (; c + 1 < nchunks - 1; c += 2) {
@@ -329,9 +293,6 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (SYRK && j > blk[i]) continue;
-                const double v = neg ? -acc[i][j][r] : acc[i][j][r];
-                if (SYRK && out_img) out_img[(blk[i] * (blk[i] + 1) / 2 + j) * 256 + (fk + 4 * r) * 16 + fr] = v;
-                else Cw[(crow(i) + 4 * r) * ld + j * 16] = v;
+                Cw[(crow(i) + 4 * r) * ld + j * 16] = neg ? -acc[i][j][r] : acc[i][j][r];
             }
 }

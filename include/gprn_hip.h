@@ -205,18 +205,15 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
  * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel
  * wait timed out, in which case the call is re-run on events); "wait_budget_ms" (wall-clock budget of one
  * in-kernel wait); "withhold_inner" (test hook: the n-th in-panel completion flag of every following call is
- * never raised -- under the dataflow schedule: one node of the task graph never becomes ready); "queue" (1: the factorisation
- * runs as a task graph on a persistent worker kernel, csrc/queue.hip -- the default wherever "flags" is 1 --, 0: one launch
- * per family and tile step, csrc/factor.hip); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" / "chain_pad_kb" (KiB of
- * unused dynamic LDS the bulk tile launches -- batches above / up to two matrices -- and the chain's own tile launches
- * ask for, to keep CUs open for the latency chain; -2 returns to the environment's / default value; a pad that does not
- * fit a workgroup's LDS makes the factorising calls return GPRN_E_ARG instead of aborting the queue); "block_sched" (1: the
- * block schedule of the factorisation where it applies -- the chain factors the 512 x 512 diagonal block of an outer panel on
- * its own, one product with the block's inverse per panel and side, csrc/factor.hip factor_invert_blocks --, 0: the
- * step-synchronous launch schedule); "overlap" (bit mask of what runs beside the factorisations instead of before / behind
- * them: 1 B formed inside the first panel's update, 2 row reductions over X panel by panel, 4 node term beside the weight
- * phase, 8 log det B in the finalising kernel, 16 a sweep's end beside the next sweep's node phase, 32 ... with its X^T X
- * product; results are bit-identical for every value).  value == -1 only reads; *old (may be NULL) receives the previous
+ * never raised); "fallbacks" (read-only count of re-run calls); "bulk_pad_kb" / "small_pad_kb" (KiB of unused
+ * dynamic LDS the bulk tile launches -- batches above / up to two matrices -- ask for, to keep CUs open for the
+ * latency chain; -2 returns to the default; a pad that does not fit a workgroup's LDS makes the factorising calls
+ * return GPRN_E_ARG instead of aborting the queue); "overlap" (bit mask of what runs beside the factorisations
+ * instead of before / behind them: 1 B formed inside the first panel's update, 2 row reductions over X panel by
+ * panel, 4 node term beside the weight phase, 8 log det B in the finalising kernel, 16 a sweep's end beside the
+ * next sweep's node phase; results are bit-identical for every value); "small_path" (1: problems of at most two
+ * tiles -- N <= 256 -- run each phase of a sweep as ONE launch, one workgroup per latent GP, csrc/smalln.hip; 0: the
+ * launch schedule at every size; same results).  value == -1 only reads; *old (may be NULL) receives the previous
  * value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 
@@ -227,9 +224,8 @@ int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
  * 64x128, 128x64).  M, N multiples of 128; K multiple of 16. */
 int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
                    int c_mode, const double* A, const double* B, double* C);
-/* time (ms, average of reps) of C -= A.B^T, M x N x K on random device data, through the tile contraction: how 0 / 1 = one
- * launch with 64 x 64 / 128 x 128 workgroups, 2 / 3 = as independent nodes of the dataflow schedule's worker kernel
- * (csrc/queue.hip), one queue entry per 64 x 64 quarter / per 128 x 128 node */
+/* time (ms, average of reps) of C -= A.B^T, M x N x K on random device data, through the tile contraction: one launch
+ * with 64 x 64 (how 0) / 128 x 128 (how 1) workgroups */
 int gprn_test_gemm_rate(gprn_ctx* ctx, int M, int N, int K, int how, int reps, double* ms);
 /* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */
 int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
@@ -237,11 +233,6 @@ int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
 /* back-to-back v_mfma_f64_16x16x4_f64 from registers on every CU: the measured fp64 MFMA
  * ceiling of this device in TFLOP/s (what roofline fractions can be judged against) */
 int gprn_test_mfma_peak(gprn_ctx* ctx, int wg_per_cu, int iters, double* tflops);
-/* The task graph of the dataflow schedule (csrc/queue.hip) for T tile steps and outer panels of `outer` tiles, for
- * host-side checks (no GPU is touched): n_ops nodes x 12 int64 (kind 0 tile / 1 panel L / 2 panel X / 3 chain, priority
- * class, queue entries, flags, c_buf, a_buf, b_buf, modes, c_off, a_off, b_off, klen; ld = 128 T; chain nodes: c_buf =
- * 0 diag / 1 L_{k+1,k} / 2 update of B_{k+1,k+1}, klen = k) and n_edges x 2 (from, to).  Null arrays: counts only. */
-int gprn_test_queue_plan(int T, int outer, int64_t* n_ops, int64_t* n_edges, int64_t* ops_out, int64_t* edges_out);
 /* out = lower(X^T X) for lower-triangular X */
 int gprn_test_lauum(gprn_ctx* ctx, int n, const double* X, double* out);
 

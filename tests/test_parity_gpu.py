@@ -250,9 +250,8 @@ def test_cfg3_properties_full_size():
 def test_overlap_modes_are_bit_identical():
     """What runs beside the factorisations instead of before / behind them (option "overlap": B formed inside the first
     panel's update, the row reductions over X panel by panel, the node term beside the weight phase, log det B inside
-    k_finalize, a sweep's end -- and its X^T X -- beside the next sweep's node phase) changes WHEN kernels run, never a
-    rounding: four forced sweeps of an N = 4096, q = 2 problem (two outer-panel schedules per sweep, T = 32) give the same
-    bits for every mask.  The block schedule (option "block_sched") orders the additions differently: 1e-10."""
+    k_finalize, a sweep's end beside the next sweep's node phase) changes WHEN kernels run, never a rounding: four forced
+    sweeps of an N = 4096, q = 2 problem (two outer-panel schedules per sweep, T = 32) give the same bits for every mask."""
     N, p, q = 4096, 1, 2
     t, ys, es = synth.rv_series(N, p)
     spec = synth.component_spec(p, q, 'QuasiPeriodic')
@@ -263,7 +262,7 @@ def test_overlap_modes_are_bit_identical():
     mu0, var0 = g._initMuVar(nodes, weights, jit)
     out = {}
     try:
-        for mask in (0, 1, 2, 4 | 8, 16, 31, 63):
+        for mask in (0, 1, 2, 4 | 8, 16, 31):
             ctx.option('overlap', mask)
             ctx.set_muvar(mu0, var0)
             e, parts, info = ctx.sweep(4, commit=True)
@@ -272,15 +271,9 @@ def test_overlap_modes_are_bit_identical():
         for mask, res in out.items():
             for a, b in zip(res, out[0]):
                 assert np.array_equal(a, b), mask
-        ctx.option('block_sched', 1)
-        ctx.set_muvar(mu0, var0)
-        e, parts, info = ctx.sweep(4, commit=True)
-        assert info == 0
-        np.testing.assert_allclose(e, out[0][0], rtol=1e-10)
-        np.testing.assert_allclose(ctx.get_muvar()[0], out[0][2], rtol=1e-7, atol=1e-9)
+        _assert_default_schedule(ctx)
     finally:
         ctx.option('overlap', 31)
-        ctx.option('block_sched', 0)
 
 
 def test_cfg5_size_factorisation_against_lapack():
@@ -441,47 +434,21 @@ def test_sharded_prediction(tag, world, user, tmp_path):
         np.testing.assert_allclose(res['pred_var'], ref['var'], rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize('env', [{'GPRN_FLAGS': '0'}, {'GPRN_SCHED': '1'}, {'GPRN_SCHED': '2'},
-                                 {'GPRN_TRI': '0', 'GPRN_FILL_SYM': '0', 'GPRN_BULK_PAD_KB': '0'},
-                                 {'GPRN_QUEUE': '1'}],
+@pytest.mark.parametrize('tag', ['mid_N512_p3q2', 'cfg5shape_N2048'])
+@pytest.mark.parametrize('env', [{'GPRN_FLAGS': '0'}, {'GPRN_FILL_SYM': '0'}],
                          ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
-def test_schedule_and_kernel_variants_agree(env, tmp_path):
-    """The library's fallbacks (HIP events instead of device flags, the one- and three-stream
-    schedules without the lean panel boundary, full-matrix fill, no triangular skip, no LDS pad) and
-    the opt-in dataflow schedule (csrc/queue.hip: q = 2 nodes, so the previous phase's X^T X rides in
-    the weight phase's worker kernel) are switches read once per process: run each in its own
-    process against the golden values."""
-    tag = 'mid_N512_p3q2'
-    meta, d = _cases.load(tag)
-    res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
-    assert int(res['sw_info']) == 0
-    np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
-    np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
-    _cases.assert_state('variant %s %s' % (tag, sorted(env.items())), res['sw_mu'], d['mu_final'])
-    np.testing.assert_allclose(res['sw_mu'], d['mu_final'], rtol=1e-6, atol=1e-8)
-
-
-@pytest.mark.parametrize('env', [{'GPRN_LEFT': '1'}, {'GPRN_SPLIT_FIRST': '1'}, {'GPRN_LEFT': '1', 'GPRN_SPLIT_FIRST': '1'},
-                                 {'GPRN_BLOCK_SCHED': '1'}, {'GPRN_OVERLAP': '0'}, {'GPRN_OVERLAP': '63'},
-                                 {'GPRN_FIRST_ALONE': '8'}, {'GPRN_FLAGS': '0', 'GPRN_LEFT': '1'},
-                                 {'GPRN_MULTI_FLAG': '0', 'GPRN_MINIL_BY_U': '0', 'GPRN_LAST_WAIT': '0', 'GPRN_FUSED_FINALIZE': '0',
-                                  'GPRN_PANEL_SYNC': '0'},
-                                 {'GPRN_PANEL_SYNC': '16'}, {'GPRN_EAGER_NEXT': '16'}],
-                         ids=lambda e: ','.join(f'{k}={v}' for k, v in e.items()))
-def test_throughput_schedule_variants_agree(env, tmp_path):
-    """Round 3's switches of the throughput schedule (outer panels of four tiles: needs more than 32 batch x tiles) -- the
-    left-looking in-panel updates with the next-panel update in groups, the two-part "first" update, the block schedule,
-    the overlap masks, "first" alone, the flag operations as stream operations of their own (the form before the round's
-    last session), stream3's synchronisation folded into the panel launch for EVERY batch size and the next panel's share
-    of an outer update applied column by column -- each in a process of
-    its own against the golden values of BASELINE config 5's
-    shape at N = 2048 (T = 16, three nodes and twelve weights: four outer panels per factorisation)."""
-    tag = 'cfg5shape_N2048'
+def test_schedule_and_kernel_variants_agree(env, tag, tmp_path):
+    """The two switches of the library that are read once per process -- HIP events instead of device-side flags for
+    the factorisation's dependencies (what a serialising tool or a time-out falls back to), and the full-matrix
+    covariance fill instead of the symmetric one -- each in a process of its own against the golden values: the latency
+    set of task lists (mid_N512_p3q2: T = 4) and the throughput set (BASELINE config 5's shape at N = 2048: T = 16, three
+    nodes and twelve weights, four outer panels per factorisation)."""
     if not _cases.available(tag):
         pytest.skip('fixture not generated')
     meta, d = _cases.load(tag)
     res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
-    assert int(res['sw_info']) == 0
+    assert int(res['sw_info']) == 0 and int(res['fallbacks']) == 0
+    assert int(res['flags']) == (0 if env.get('GPRN_FLAGS') == '0' else 1)
     np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
     np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
     _cases.assert_state('variant %s %s' % (tag, sorted(env.items())), res['sw_mu'], d['mu_final'])
