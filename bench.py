@@ -230,6 +230,8 @@ def latency_cpu(t, ys, es, spec, xs, budget_s=20.0):
 def latency(a):
     """python bench.py --latency: nELBO evaluations per second at small N, one JSON line per shape."""
     for name, N, p, q, kind in LATENCY_SHAPES:
+        if a.latency_only and str(N) not in a.latency_only.split(','):
+            continue
         t, ys, es, spec = latency_problem(N, p, q, kind)
         nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
         g = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair])
@@ -350,6 +352,7 @@ def main():
     ap.add_argument('--latency', action='store_true',
                     help='the small-N regime instead: nELBO evaluations/s at N = 45, 200, 512, 2048 (one JSON line each)')
     ap.add_argument('--latency-reps', type=int, default=0, help='evaluations per shape (default 200, 40 at N = 2048)')
+    ap.add_argument('--latency-only', default='', help='comma-separated N of the shapes to run (default: all four)')
     ap.add_argument('--latency-cpu-s', type=float, default=20.0, help='seconds of CPU baseline per shape')
     a = ap.parse_args()
     if a.latency:

@@ -65,6 +65,8 @@ SIGNATURES = {
     'gprn_test_gemm_rate': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
+    'gprn_elbocalc': (c_int, [c_void_p, c_int, _dp, _dp, _dp, _dp, c_int, _dp, c_int, POINTER(c_int), POINTER(c_int),
+                      POINTER(c_int), _dp, _dp]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_grad_kernel': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_eval_kernel': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, _dp]),
@@ -319,6 +321,28 @@ class Context:
         out = np.empty(self.G)
         self._check(self._lib.gprn_get_logdet_K(self._h, _ptr(out)), 'get_logdet_K')
         return out
+
+    def elbocalc(self, max_iter, setup=False, y_resid=None, jitters=None, mu=None, var=None):
+        """ELBOcalc from its set-up block on (meanfield.py:618-649) in one call of the library: optionally the set-up
+        with the kernels last sent, y - mean, the jitters and the starting state (None: as set before), then the loop.
+        Returns (elboArray, iterNumber, converged, info, mu, var) with the state the loop ended in."""
+        cap = int(min(max_iter, 1 << 20)) + 1
+        hist = np.empty(cap)
+        d = (self.p + 1) * self.q * self.N
+        mu_out, var_out = np.empty(d), np.empty(d)
+        n, it, conv = c_int(0), c_int(0), c_int(0)
+        opt = lambda a, size: None if a is None else _ptr(_f64(np.ravel(a), (size,)))
+        keep = [None if a is None else _f64(np.ravel(a)) for a in (y_resid, jitters, mu, var)]
+        ptrs = [None if a is None else _ptr(a) for a in keep]
+        if (keep[0] is not None and keep[0].size != self.p * self.N) or (keep[1] is not None and keep[1].size != self.p) or \
+                (keep[2] is not None and (keep[2].size != d or keep[3] is None or keep[3].size != d)):
+            raise ValueError('elbocalc: y_resid (p, N), jitters (p,), mu and var (d,) expected')
+        info = self._check(self._lib.gprn_elbocalc(self._h, 1 if setup else 0, ptrs[0], ptrs[1], ptrs[2], ptrs[3],
+                                                   int(max_iter), _ptr(hist), cap, byref(n), byref(it), byref(conv),
+                                                   _ptr(mu_out), _ptr(var_out)), 'elbocalc')
+        shape = (self.p + 1, self.q, self.N)
+        return (hist[:min(n.value, cap)].copy(), it.value, bool(conv.value), info,
+                mu_out.reshape(shape), var_out.reshape(shape))
 
     def option(self, name, value=-1):
         """Read (value < 0) or set a per-context switch of the library; returns the previous value."""

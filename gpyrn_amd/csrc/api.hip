@@ -182,6 +182,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
+    else if (!strcmp(name, "small_path")) field = &c->small_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
@@ -206,6 +207,11 @@ static void free_problem(gprn_ctx* c)
     dev_free(c->d_time); dev_free(c->d_yraw); dev_free(c->d_yerr2); dev_free(c->d_yres);
     dev_free(c->d_variance); dev_free(c->d_mu); dev_free(c->d_var);
     dev_free(c->d_mu_save); dev_free(c->d_var_save);
+    dev_free(c->d_mu_alt); dev_free(c->d_var_alt);
+    if (c->d_loop_ctl) { hipFree(c->d_loop_ctl); c->d_loop_ctl = nullptr; }
+    if (c->h_pin_in) { hipHostFree(c->h_pin_in); c->h_pin_in = nullptr; c->pin_in_cap = 0; }
+    if (c->h_pin_out) { hipHostFree(c->h_pin_out); c->h_pin_out = nullptr; c->pin_out_cap = 0; }
+    dev_free(c->d_loop_hist);
     for (auto& p : c->K) dev_free(p);
     for (auto& p : c->KLinv) dev_free(p);
     for (auto& p : c->Kinv) dev_free(p);
@@ -214,6 +220,7 @@ static void free_problem(gprn_ctx* c)
     for (auto& p : c->wsX) dev_free(p);
     c->K.clear(); c->KLinv.clear(); c->Kinv.clear(); c->Sig.clear(); c->wsB.clear(); c->wsX.clear();
     dev_free(c->d_logdetK);
+    dev_free(c->d_kinv_tab); dev_free(c->d_kinv_out); dev_free(c->d_small_ticket); dev_free(c->d_small_stamps);
     for (auto& p : c->predKs) dev_free(p);
     for (auto& p : c->predWT) dev_free(p);
     c->predKs.clear(); c->predWT.clear(); c->pred_cap = 0;
@@ -392,8 +399,11 @@ extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* tim
     TRY(dev_alloc(c, &c->d_var, dn));
     TRY(dev_alloc(c, &c->d_mu_save, dn));
     TRY(dev_alloc(c, &c->d_var_save, dn));
+    TRY(dev_alloc(c, &c->d_mu_alt, dn));
+    TRY(dev_alloc(c, &c->d_var_alt, dn));
     TRY(dev_alloc(c, &c->d_logdetK, c->G));
     TRY(dev_alloc(c, &c->d_scal_base, 2 * (size_t)(3 * c->G + q * q)));
+    HIP_TRY(c, hipMemset(c->d_scal_base, 0, 2 * (size_t)(3 * c->G + q * q) * sizeof(double)));
     TRY(dev_alloc(c, &c->d_elbo_part, 2 * (size_t)GPRN_ELBO_PART_DOUBLES));
     c->d_scal = c->d_scal_base;
     c->d_logdetB = c->d_scal;
@@ -885,6 +895,7 @@ static int build_tables(gprn_ctx* c)
     if (!c->loc_weights.empty())
         HIP_TRY(c, hipMemcpy(c->d_slotgp_weight, c->loc_weights.data(), c->loc_weights.size() * sizeof(int), hipMemcpyHostToDevice));
     c->tables_ready = true;
+    c->small_tabs_ready = false;
     return GPRN_OK;
 }
 
@@ -914,8 +925,57 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
     return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); }, true);
 }
 
+// The set-up of a problem of one or two tiles on one rank (smalln.hip): the fills, then ONE launch -- a workgroup per latent
+// GP copies K, factors and inverts it, takes log det K and, where quirk Q1 needs it, forms K_j^-1 -- and one read-back.
+static int factor_priors_small(gprn_ctx* c, bool sync = true)
+{
+    TRY(build_tables(c));
+    c->info_gp = -1;
+    const size_t nn = (size_t)c->ld * c->ld;
+    std::vector<int> gps(c->loc_nodes);
+    gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
+    const int nj = (int)gps.size();
+    if (!c->small_tabs_ready) {
+        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr), kout(c->nslot, nullptr), ktab(c->q, nullptr);
+        for (int s = 0; s < nj; ++s) {
+            const int g = gps[s];
+            rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
+            rows[s * GPRN_NBUF + BUF_X] = c->KLinv[g];
+            rows[s * GPRN_NBUF + BUF_K] = c->K[g];
+            rows[s * GPRN_NBUF + BUF_KLINV] = c->KLinv[g];
+            if (g >= 1 && g < c->q) {                  // quirk Q1: node k < j needs K_j^-1
+                if (!c->Kinv[g]) TRY(dev_alloc(c, &c->Kinv[g], nn));
+                kout[s] = c->Kinv[g];
+                ktab[g] = c->Kinv[g];
+            }
+        }
+        TRY(upload_table(c, c->tab_setup, rows));
+        HIP_TRY(c, hipMemcpy(c->d_slotgp_setup, gps.data(), nj * sizeof(int), hipMemcpyHostToDevice));
+        dev_free(c->d_kinv_out); dev_free(c->d_kinv_tab);
+        TRY(dev_alloc(c, &c->d_kinv_out, (size_t)c->nslot));
+        TRY(dev_alloc(c, &c->d_kinv_tab, (size_t)c->q));
+        HIP_TRY(c, hipMemcpy(c->d_kinv_out, kout.data(), kout.size() * sizeof(double*), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_kinv_tab, ktab.data(), ktab.size() * sizeof(double*), hipMemcpyHostToDevice));
+        if (!c->d_small_ticket) {
+            TRY(dev_alloc(c, &c->d_small_ticket, 1));
+            HIP_TRY(c, hipMemset(c->d_small_ticket, 0, sizeof(unsigned)));
+        }
+        c->small_tabs_ready = true;
+    }
+    for (int g : gps)
+        if (!c->kspec[g].uploaded) TRY(launch_fill(c, c->kspec[g], c->K[g]));
+    TRY(small_prior(c, c->tab_setup, c->d_slotgp_setup, c->d_kinv_out, nj, c->d_info));    // (clears its info words itself)
+    c->factored = true;
+    if (!sync) return GPRN_OK;                             // gprn_elbocalc reads the pivot verdicts with its own results
+    int first_info = 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (the library's streams do not synchronise with the null stream's copies)
+    TRY(check_info(c, c->d_info, gps, &first_info));
+    return first_info;
+}
+
 static int factor_priors_impl(gprn_ctx* c)
 {
+    if (small_applies(c) && c->world == 1) return factor_priors_small(c);
     TRY(build_tables(c));
     TRY(ensure_tasks(c));
     c->info_gp = -1;
@@ -1006,6 +1066,21 @@ static int factor_priors_impl(gprn_ctx* c)
 static int overlap_mask(const gprn_ctx* c) { return c->overlap_opt >= 0 ? c->overlap_opt : 31; }
 
 static int mu_k_mu(gprn_ctx* c, bool weights, hipStream_t stream = nullptr, double* out = nullptr);
+
+// One sweep of the small path (smalln.hip): node half-sweep, weight half-sweep, tail -- three launches, no host step
+// between them.  (mu_in, var_in) is the state the sweep starts from, (mu_out, var_out) receives the new one.
+static int small_sweep(gprn_ctx* c, const double* mu_in, const double* var_in, double* mu_out, double* var_out,
+                       double* out4, double* scal, const SmallLoop* loop)
+{
+    c->d_scal = scal;
+    c->d_logdetB = scal; c->d_trBinv = scal + c->G; c->d_muKmu = scal + 2 * (size_t)c->G; c->d_q1 = scal + 3 * (size_t)c->G;
+    const int* done = loop ? loop->ctl : nullptr;
+    c->d_ptrs = c->tab_node; c->slot0 = 0; c->d_info_cur = c->d_info + (size_t)c->nslot;
+    TRY(small_phase(c, false, c->d_slotgp_node, (int)c->loc_nodes.size(), mu_in, var_in, mu_out, var_out, done));
+    c->d_ptrs = c->tab_weight; c->slot0 = (int)c->loc_nodes.size(); c->d_info_cur = c->d_info + 2 * (size_t)c->nslot;
+    TRY(small_phase(c, true, c->d_slotgp_weight, (int)c->loc_weights.size(), mu_in, var_in, mu_out, var_out, done));
+    return small_tail(c, out4, scal, mu_out, var_out, loop);
+}
 
 static int run_phase(gprn_ctx* c, bool weights)
 {
@@ -1140,15 +1215,18 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         c->out_cap = n_sweeps;
     }
     const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
-    // the state the call started from: what commit = 0 returns to, and what a re-run starts over from
-    if (retry) {
+    const bool small = small_applies(c);
+    // the state the call started from: what commit = 0 returns to, and what a re-run starts over from (the small path
+    // writes every new state into the OTHER copy: a committed call needs no snapshot, and it has nothing to re-run)
+    if (small && commit) { /* nothing to keep */ }
+    else if (retry) {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu, c->d_mu_save, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
     } else {
         HIP_TRY(c, hipMemcpyAsync(c->d_mu_save, c->d_mu, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    if (!small) HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
     // The end of a sweep -- mu_w^T K_w^-1 mu_w (one pass over the six L_K^-1), the ELBO assembly and the wait for the
     // Q1 traces, some 150 us on the chain stream -- reads only what the sweep has left behind, and the next sweep's node
     // phase reads none of its results: inside a call of several sweeps it runs beside that phase, on the bulk stream,
@@ -1165,8 +1243,8 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
     const bool node_joins = !c->outers[node_set].empty() && c->outers[node_set][0].nrest > 0;
     const bool may_defer = (overlap & 16) && !comm_active(c) && factor_use_flags(c) == 1 &&
                            !c->loc_nodes.empty() && !c->loc_weights.empty() && !c->keep_sigma && node_joins;
-    bool scal_cleared = false;
-    if (!comm_active(c)) {
+    bool scal_cleared = small;                     // (the small path's kernels write every entry they read)
+    if (!comm_active(c) && !small) {
         HIP_TRY(c, hipMemsetAsync(c->d_scal_base, 0, 2 * nscal * sizeof(double), c->stream));
         scal_cleared = true;
     }
@@ -1179,6 +1257,13 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         // sharded context the all-reduce leaves the other ranks' entries behind, so there it is cleared every sweep)
         if (comm_active(c) || !scal_cleared) HIP_TRY(c, hipMemsetAsync(scal, 0, nscal * sizeof(double), c->stream));
         c->node_term_done = false;
+        if (small) {
+            // three launches: the two half-sweeps read the state the sweep starts from and write the other copy
+            TRY(small_sweep(c, c->d_mu, c->d_var, c->d_mu_alt, c->d_var_alt, c->d_out + 4 * (size_t)it, scal, nullptr));
+            std::swap(c->d_mu, c->d_mu_alt);
+            std::swap(c->d_var, c->d_var_alt);
+            continue;
+        }
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));
         const bool defer = may_defer && it + 1 < n_sweeps;
@@ -1210,18 +1295,240 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         HIP_TRY(c, hipMemcpyAsync(c->d_var, c->d_var_save, dn, hipMemcpyDeviceToDevice, c->stream));
     }
     std::vector<double> h(4 * (size_t)n_sweeps);
+    std::vector<int> h_info;
+    if (small) {                                    // (the pivot verdicts ride along: one synchronisation per call)
+        h_info.resize(3 * (size_t)c->nslot);
+        HIP_TRY(c, hipMemcpyAsync(h_info.data(), c->d_info, h_info.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int it = 0; it < n_sweeps; ++it) {
         elbo_out[it] = h[4 * it];
         if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];
     }
-    TRY(factor_check_waits(c));
     int first = 0;
     c->info_gp = -1;
+    if (small) {
+        for (int ph = 1; ph <= 2; ++ph) {
+            const std::vector<int>& gps = ph == 1 ? c->loc_nodes : c->loc_weights;
+            for (size_t sl = 0; sl < gps.size(); ++sl) {
+                const int v = h_info[(size_t)ph * c->nslot + sl];
+                if (v > 0 && first == 0) { first = v; c->info_gp = gps[sl]; }
+            }
+        }
+        return first;
+    }
+    TRY(factor_check_waits(c));
     TRY(check_info(c, c->d_info + (size_t)c->nslot, c->loc_nodes, &first));
     TRY(check_info(c, c->d_info + 2 * (size_t)c->nslot, c->loc_weights, &first));
     return first;
+}
+
+// ------------------------------------------------------------------ the ELBOcalc loop
+extern "C" int gprn_factor_priors(gprn_ctx* c);
+extern "C" int gprn_get_muvar(gprn_ctx* c, double* mu, double* var);
+// meanfield.py:626-649 in one call: the first sweep's update is discarded and its ELBO kept as elboArray[0] (quirk Q7), then
+// sweeps until `iterNumber > 3 and |std(last3) / mean(last3)| < 1e-3 and != 0` (np.std: population) or max_iter.
+static bool stop_rule(double e0, double e1, double e2)
+{
+    volatile double sum = e0 + e1; sum = sum + e2;             // (volatile: one rounding per operation, as NumPy's ufuncs)
+    volatile double mean = sum / 3.0;
+    volatile double d0 = e0 - mean, d1 = e1 - mean, d2 = e2 - mean;
+    volatile double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    volatile double v = q0 + q1; v = v + q2; v = v / 3.0;
+    volatile double sd = sqrt(v);
+    volatile double ratio = sd / mean;
+    const double crit = fabs(ratio);
+    return crit < 1e-3 && crit != 0.0;
+}
+
+// the small path: ONE call, one synchronisation per batch of sweeps.  Inputs go through a pinned staging buffer and
+// asynchronous copies, the set-up (fills + k_small_prior) is enqueued without waiting for its verdict, the loop runs on the
+// device (k_small_tail applies the stop rule; sweeps enqueued ahead of the verdict become no-ops once it is in), and both
+// copies of the state come back with the batch's read-back, so the final one is there whichever trip ended the loop.
+struct ElboIo { int do_setup; const double *y_resid, *jitters, *mu, *var; double *mu_out, *var_out; };
+
+static int elbocalc_small(gprn_ctx* c, const ElboIo& io, int max_iter, std::vector<double>& hist, int* iters, int* conv, int* info)
+{
+    const int K = 8;                                           // sweeps per batch
+    static int stamps_env = -1;                                // GPRN_SMALL_STAMPS=1 (probes): where a half-sweep's time goes
+    if (stamps_env < 0) { const char* e = getenv("GPRN_SMALL_STAMPS"); stamps_env = e ? atoi(e) : 0; }
+    if (stamps_env && !c->d_small_stamps) {
+        HIP_TRY(c, hipMalloc(&c->d_small_stamps, 8 * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemset(c->d_small_stamps, 0, 8 * sizeof(unsigned long long)));
+    }
+    TRY(build_tables(c));
+    const size_t pn = (size_t)c->p * c->N, d = (size_t)(c->p + 1) * c->q * c->N;
+    const size_t n_info = 3 * (size_t)c->nslot;
+    // pinned staging: in = y_resid | variance | mu | var;  out = A | Av | B | Bv | batch history | ctl (4 ints) | info
+    const size_t in_doubles = 2 * pn + 2 * d, out_doubles = 4 * d + K + 4 + (n_info + 1) / 2 + 2;
+    if (c->pin_in_cap < in_doubles) {
+        if (c->h_pin_in) hipHostFree(c->h_pin_in);
+        c->h_pin_in = nullptr; c->pin_in_cap = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pin_in, in_doubles * sizeof(double), hipHostMallocDefault));
+        c->pin_in_cap = in_doubles;
+    }
+    if (c->pin_out_cap < out_doubles) {
+        if (c->h_pin_out) hipHostFree(c->h_pin_out);
+        c->h_pin_out = nullptr; c->pin_out_cap = 0;
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_pin_out, out_doubles * sizeof(double), hipHostMallocDefault));
+        c->pin_out_cap = out_doubles;
+    }
+    if (!c->d_loop_ctl) {
+        HIP_TRY(c, hipMalloc(&c->d_loop_ctl, 4 * sizeof(int)));
+        TRY(dev_alloc(c, &c->d_loop_hist, (size_t)K + 4));
+    }
+    // ---- inputs
+    double* const pin = c->h_pin_in;
+    if (io.y_resid) {
+        memcpy(pin, io.y_resid, pn * sizeof(double));
+        HIP_TRY(c, hipMemcpyAsync(c->d_yres, pin, pn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->have_yres = true;
+    }
+    if (io.jitters) {
+        double* v = pin + pn;
+        for (int i = 0; i < c->p; ++i)
+            for (int n = 0; n < c->N; ++n)
+                v[(size_t)i * c->N + n] = io.jitters[i] * io.jitters[i] + c->h_yerr2[(size_t)i * c->N + n];
+        HIP_TRY(c, hipMemcpyAsync(c->d_variance, v, pn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->have_jit = true;
+    }
+    if (io.mu && io.var) {
+        memcpy(pin + 2 * pn, io.mu, d * sizeof(double));
+        memcpy(pin + 2 * pn + d, io.var, d * sizeof(double));
+        HIP_TRY(c, hipMemcpyAsync(c->d_mu, pin + 2 * pn, d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_var, pin + 2 * pn + d, d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->have_muvar = true;
+    }
+    if (!c->have_yres || !c->have_jit || !c->have_muvar) return bad(c, "elbocalc: y_resid, jitters and the state must be given or set before");
+    if (io.do_setup) TRY(factor_priors_small(c, false));
+    else if (!c->factored) return bad(c, "elbocalc: no set-up yet (do_setup = 0)");
+    HIP_TRY(c, hipMemsetAsync(c->d_loop_ctl, 0, 4 * sizeof(int), c->stream));
+    double* const A = c->d_mu; double* const Av = c->d_var;
+    double* const B = c->d_mu_alt; double* const Bv = c->d_var_alt;
+    double* const scal = c->d_scal_base;
+    if (c->out_cap < 1) { dev_free(c->d_out); TRY(dev_alloc(c, &c->d_out, 4)); c->out_cap = 1; }
+    double* const po = c->h_pin_out;
+    double* const hb = po + 4 * d;
+    int* const ctl = reinterpret_cast<int*>(hb + K);
+    int* const h_info = reinterpret_cast<int*>(hb + K + 2);
+    int s = 0, iter = 0, done = 0;
+    *conv = 0; *info = 0; c->info_gp = -1;
+    hist.clear();
+    while (!done && s <= max_iter) {
+        const int s0 = s;
+        int nb = 0;
+        for (; nb < K && s <= max_iter; ++nb, ++s) {
+            // sweep 0 (discarded) and trip 1 both start from A; from then on the copies alternate
+            const bool from_a = s <= 1 || (s & 1);
+            SmallLoop loop{c->d_loop_ctl, c->d_loop_hist, c->d_loop_hist + K, s, nb, max_iter};
+            TRY(small_sweep(c, from_a ? A : B, from_a ? Av : Bv, from_a ? B : A, from_a ? Bv : Av, c->d_out, scal, &loop));
+        }
+        HIP_TRY(c, hipMemcpyAsync(ctl, c->d_loop_ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hb, c->d_loop_hist, nb * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(h_info, c->d_info, n_info * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (io.mu_out && io.var_out) {
+            HIP_TRY(c, hipMemcpyAsync(po, A, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(po + d, Av, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(po + 2 * d, B, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(po + 3 * d, Bv, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        done = ctl[0];
+        iter = ctl[1];
+        *conv = ctl[2];
+        const int ran = done ? std::min(nb, iter - s0 + 1) : nb;   // sweeps of the batch that were not no-ops
+        for (int i = 0; i < ran; ++i) hist.push_back(hb[i]);
+        for (int ph = 0; ph <= 2 && *info == 0; ++ph) {             // (row 0: the set-up's verdicts, slots = nodes then weights)
+            if (ph == 0 && !io.do_setup) continue;
+            for (int sl = 0; sl < c->nslot && *info == 0; ++sl) {
+                const int v = h_info[(size_t)ph * c->nslot + sl];
+                if (v <= 0) continue;
+                const size_t nn_ = c->loc_nodes.size();
+                int gp = -1;
+                if (ph == 0) gp = (size_t)sl < nn_ ? c->loc_nodes[sl] : ((size_t)sl - nn_ < c->loc_weights.size() ? c->loc_weights[sl - nn_] : -1);
+                else if (ph == 1) gp = (size_t)sl < nn_ ? c->loc_nodes[sl] : -1;
+                else gp = (size_t)sl < c->loc_weights.size() ? c->loc_weights[sl] : -1;
+                if (gp >= 0) { *info = v; c->info_gp = gp; }
+            }
+        }
+    }
+    if (c->d_small_stamps) {
+        static int printed = 0;
+        unsigned long long st[8];
+        if (printed < 6 && hipMemcpy(st, c->d_small_stamps, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess && st[0]) {
+            ++printed;
+            fprintf(stderr, "[gprn] node half-sweep (small path), us: prep %.1f build %.1f factor %.1f publish %.1f matvec %.1f "
+                            "colsums %.1f finalise %.1f | total %.1f\n", (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01,
+                    (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01, (st[6] - st[5]) * 0.01,
+                    (st[7] - st[6]) * 0.01, (st[7] - st[0]) * 0.01);
+        }
+    }
+    *iters = iter;
+    // the state the loop ended in: trip `iter` wrote it (A for even trips, B for odd ones; no trip: the state set by the caller)
+    const bool in_b = iter >= 1 && (iter & 1);
+    if (in_b) { c->d_mu = B; c->d_var = Bv; c->d_mu_alt = A; c->d_var_alt = Av; }
+    if (io.mu_out && io.var_out) {
+        memcpy(io.mu_out, po + (in_b ? 2 * d : 0), d * sizeof(double));
+        memcpy(io.var_out, po + (in_b ? 3 * d : d), d * sizeof(double));
+    }
+    return GPRN_OK;
+}
+
+extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, const double* jitters, const double* mu,
+                             const double* var, int max_iter, double* history, int cap, int* n_history, int* iterations,
+                             int* converged, double* mu_out, double* var_out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || max_iter < 0 || !history || cap < 1 || !n_history || !iterations || !converged || (!mu != !var) ||
+        (!mu_out != !var_out))
+        return bad(c, "elbocalc: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (do_setup) {
+        if (c->owner.empty()) return bad(c, "elbocalc: call set_owners first");
+        for (int g = 0; g < c->G; ++g)
+            if (!c->kspec[g].set) return bad(c, "elbocalc: a latent GP has no kernel");
+    }
+    std::vector<double> hist;
+    int iter = 0, conv = 0, info = 0;
+    if (small_applies(c)) {
+        const ElboIo io{do_setup, y_resid, jitters, mu, var, mu_out, var_out};
+        TRY(elbocalc_small(c, io, max_iter, hist, &iter, &conv, &info));
+    } else {
+        int rc;
+        if (y_resid && (rc = gprn_set_y_resid(c, y_resid))) return rc;
+        if (jitters && (rc = gprn_set_jitters(c, jitters))) return rc;
+        if (mu && (rc = gprn_set_muvar(c, mu, var))) return rc;
+        if (do_setup) {
+            rc = gprn_factor_priors(c);
+            if (rc < 0) return rc;
+            info = rc;
+        }
+        if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
+            return bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
+        double e = 0.0;
+        rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 0, &e, nullptr, retry); }, true);
+        if (rc < 0) return rc;
+        if (!info) info = rc;
+        hist.push_back(e);
+        while (iter < max_iter) {
+            rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 1, &e, nullptr, retry); }, true);
+            if (rc < 0) return rc;
+            if (!info) info = rc;
+            hist.push_back(e);
+            iter += 1;
+            const size_t n = hist.size();
+            if (iter > 3 && stop_rule(hist[n - 3], hist[n - 2], hist[n - 1])) { conv = 1; break; }
+        }
+        if (mu_out && (rc = gprn_get_muvar(c, mu_out, var_out))) return rc;
+    }
+    *n_history = (int)hist.size();
+    *iterations = iter;
+    *converged = conv;
+    // (a history longer than the caller's array keeps its LAST values: the first is elboArray[0] of a loop that ran to max_iter)
+    const int n = (int)hist.size(), keep = std::min(n, cap);
+    for (int i = 0; i < keep; ++i) history[i] = hist[(size_t)(n - keep) + i];
+    return info;
 }
 
 // ------------------------------------------------------------------ read-back

@@ -367,8 +367,14 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
     DG_STAMP(kb, 4);
 }
 
-template <int W>
-__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld)
+// where the tile's entries come from: its own memory (Bt), or -- the small-N path -- formed on the way in from K and s
+struct DiagFromTile {
+    gptr_t Bt; int ld;
+    __device__ __forceinline__ double operator()(int row, int col) const { return Bt[(size_t)row * ld + col]; }
+};
+
+template <int W, class LOAD>
+__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load)
 {
     // this wave's sub-tile rows (-1 = none): equal update counts
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
@@ -383,7 +389,7 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
                 const int P = ROWS[pp];
                 if (P < 0 || Q > P) { acc[pp][Q][t] = 0.0; continue; }
                 const int row = 16 * P + fk + 4 * t, col = 16 * Q + fr;
-                const double v = Bt[(size_t)row * ld + col];
+                const double v = load(row, col);
                 acc[pp][Q][t] = (Q < P || col <= row) ? v : 0.0;
             }
     // publish column 0 and the diagonal sub-tile 1 as they are
@@ -407,7 +413,8 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
-__device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, int* __restrict__ info, int slot,
+template <class LOAD>
+__device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int* __restrict__ info, int slot,
                                            int pivot0)
 {
     DG_STAMP(NSB, 0);
@@ -415,7 +422,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
         const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
         v4d c0;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) c0[t] = Bt[(size_t)(fk + 4 * t) * ld + fr];
+        for (int t = 0; t < 4; ++t) c0[t] = load(fk + 4 * t, fr);
         DG_STAMP(NSB, 1);
         base16_regs(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
     }
@@ -454,15 +461,23 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
     }
 }
 
-// potrf + inverse of the 128x128 tile at Bt (-> L, lower) with X = L^-1 -> Xt; `lds`: DIAG_LDS_DOUBLES doubles.
-// All 256 threads of the workgroup call it.
-__device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
-                                          int* __restrict__ info, int slot, int pivot0)
+// potrf + inverse of a 128x128 tile whose entries `load(row, col)` supplies: L (lower) -> Bt, X = L^-1 -> Xt;
+// `lds`: DIAG_LDS_DOUBLES doubles.  All 256 threads of the workgroup call it.
+template <class LOAD>
+__device__ __forceinline__ void diag_tile_from(double* __restrict__ lds, const LOAD& load, gptr_t Bt, gptr_t Xt, int ld,
+                                               int* __restrict__ info, int slot, int pivot0)
 {
     const DiagLds L(lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld);
-    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld);
-    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld);
-    else diag_pivot(L, Bt, Xt, ld, info, slot, pivot0);
+    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load);
+    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load);
+    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load);
+    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0);
+}
+
+// ... of the tile at Bt itself
+__device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
+                                          int* __restrict__ info, int slot, int pivot0)
+{
+    diag_tile_from(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0);
 }

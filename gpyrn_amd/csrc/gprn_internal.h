@@ -220,6 +220,18 @@ struct gprn_ctx {
     const double* ft_s_phase = nullptr;
     const double* ft_s_now = nullptr;
     int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: the default
+    // ---- small-N path (smalln.hip): problems of one or two tiles run a half-sweep as ONE launch, one workgroup per latent GP
+    int small_opt = -1;              // gprn_set_option "small_path": 0 never, else wherever it applies (small_applies)
+    double** d_kinv_tab = nullptr;   // [q] device pointers K_j^-1 (quirk Q1), for k_small_tail
+    double** d_kinv_out = nullptr;   // [nslot] per set-up job: where k_small_prior puts K^-1, or null
+    unsigned* d_small_ticket = nullptr;
+    unsigned long long* d_small_stamps = nullptr;   // GPRN_SMALL_STAMPS (probes): stage clocks of the node half-sweep's workgroup 0
+    double *d_mu_alt = nullptr, *d_var_alt = nullptr;   // the second copy of the state (smalln.hip: a sweep reads one, writes the other)
+    int* d_loop_ctl = nullptr;       // gprn_elbocalc on the small path: [0] done, [1] iterNumber, [2] converged (+ pad)
+    double* d_loop_hist = nullptr;   // ... the batch's ELBO values, then the loop's last three
+    double *h_pin_in = nullptr, *h_pin_out = nullptr;    // pinned staging of gprn_elbocalc's inputs / read-backs
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    bool small_tabs_ready = false;   // the set-up's tables for this problem are on the device (factor_priors_small)
 };
 
 struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)
@@ -355,4 +367,14 @@ int ensure_tasks(gprn_ctx* c);
 #define GPRN_E_WAIT_TIMEOUT (-100)
 int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel dependency wait timed out since the last check
 int factor_use_flags(gprn_ctx* c);
-
+// smalln.hip
+bool small_applies(const gprn_ctx* c);
+// one half-sweep against c->d_ptrs / slot0: reads the state (mu_in, var_in), writes this phase's rows of (mu_out, var_out);
+// the weight phase takes the node rows from the new state.  done: device word that makes the launch a no-op when set, or null
+int small_phase(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots, const double* mu_in, const double* var_in,
+                double* mu_out, double* var_out, const int* done = nullptr);
+// the loop of ELBOcalc on the device (gprn_elbocalc): control words, the batch's ELBO values, the loop's last three values
+struct SmallLoop { int* ctl; double *hist, *last3; int sweep, hist_at, max_iter; };
+// mu^T K^-1 mu, Q1 traces, ELBO assembly of the sweep whose new state is (mu, var); loop: the stop rule too, or null
+int small_tail(gprn_ctx* c, double* out4, double* scal, const double* mu, const double* var, const SmallLoop* loop = nullptr);
+int small_prior(gprn_ctx* c, double** d_tab, const int* d_job_gp, double** d_kinv_out, int njobs, int* d_info);

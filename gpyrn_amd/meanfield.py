@@ -471,33 +471,31 @@ class inference:
         if max_iter is None:
             max_iter = 10000
 
-        ctx = self._setup_device(nodes, weights, means, jitters)
-        ctx.set_muvar(np.asarray(mu, dtype=float), np.asarray(var, dtype=float))
-
-        # the first sweep's update is thrown away, only its ELBO is kept
-        first, _, info = ctx.sweep(1, commit=False)
+        # meanfield.py:618-649 in ONE call of the library: the set-up (when a hyper-parameter of a kernel has changed:
+        # unchanged ones keep their factors), y - mean and the jitters, the starting state, then the loop -- the first
+        # sweep's update thrown away and only its ELBO kept, sweeps to the stop rule or max_iter
+        ctx = self._backend()
+        specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
+        key = tuple(self._spec_key(s) for s in specs)
+        setup = key != self._prior_key
+        if setup:
+            for gp, spec in enumerate(specs):
+                self._send_spec(ctx, gp, spec)
+            self.last_info = 0
+        y = np.concatenate(self.y) - self._mean(means)
+        history, iterNumber, converged, info, mu, var = ctx.elbocalc(
+            max_iter, setup=setup, y_resid=y, jitters=np.asarray(jitters, dtype=float),
+            mu=np.asarray(mu, dtype=float), var=np.asarray(var, dtype=float))
+        if setup:
+            self._prior_key = key
         self.last_info = self.last_info or info
-        history = [first[0]]
-        ELBO = np.float64(first[0])
-        iterNumber = 0
-        while iterNumber < max_iter:
-            e, _, info = ctx.sweep(1, commit=True)
-            self.last_info = self.last_info or info
-            ELBO = np.float64(e[0])
-            history.append(ELBO)
-            iterNumber += 1
-            if iterNumber > 3:
-                last3 = np.array(history[-3:])
-                criteria = np.abs(np.std(last3) / np.mean(last3))
-                if criteria < 1e-3 and criteria != 0:
-                    mu, var = ctx.get_muvar()
-                    self._mu, self._var = mu, var
-                    self._elbo_history = np.array(history)
-                    return ELBO, mu, var, iterNumber
+        self._elbo_history = history
+        ELBO = np.float64(history[-1])
+        if converged:
+            self._mu, self._var = mu, var
+            return ELBO, mu, var, iterNumber
 
         print('\nMax iterations reached')
-        mu, var = ctx.get_muvar()
-        self._elbo_history = np.array(history)
         return ELBO, mu, var, iterNumber
 
     def ELBOaux(self, Kf, Kw, Lf, Lw, y, jitt2, mu, var):

@@ -200,6 +200,24 @@ int gprn_profile_enable(gprn_ctx* ctx, int family_mask);   /* bit f = time famil
 int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
                       int64_t* launches /*GPRN_T_COUNT*/, int reset);
 
+/* inference.ELBOcalc (meanfield.py:561-649) from its set-up block on, in one call.
+ *   do_setup != 0: first the set-up of gprn_factor_priors (:618-622) with the kernels last given by gprn_set_kernel /
+ *       gprn_upload_K; 0: the factors of the last set-up are kept (unchanged hyper-parameters).
+ *   y_resid (p x N, y minus the mean functions, :624), jitters (p), mu / var (the state the loop starts from, d each):
+ *       as gprn_set_y_resid / gprn_set_jitters / gprn_set_muvar; NULL keeps what was set before.
+ * Then the loop of :626-649: one sweep whose update is discarded and whose ELBO is kept as elboArray[0] (:627-628),
+ * committed sweeps until `iterNumber > 3 and |std(last3) / mean(last3)| < 1e-3 and != 0` (:640-643, np.std = population
+ * std) or max_iter trips.  history[0 .. *n_history) receives elboArray (if it is longer than cap, its last cap values),
+ * *iterations the trip count, *converged whether the stop rule fired, mu_out / var_out (d each, or both NULL) the state
+ * the loop ended in (it also stays on the device: gprn_get_muvar).  Returns as gprn_sweep; a pivot failure of the set-up
+ * is reported the same way.
+ * Problems of one tile (N <= 128) do all of this with ONE host synchronisation per eight sweeps (csrc/smalln.hip: inputs
+ * through pinned staging and asynchronous copies, the loop and its stop rule on the device, sweeps enqueued ahead of
+ * the verdict); larger ones run the entry points above in turn. */
+int gprn_elbocalc(gprn_ctx* ctx, int do_setup, const double* y_resid, const double* jitters, const double* mu,
+                  const double* var, int max_iter, double* history, int cap, int* n_history, int* iterations,
+                  int* converged, double* mu_out, double* var_out);
+
 /* ---- per-context switches (tests, experiments; nothing in the reference corresponds) ----
  * name: "flags" (1: the factorisation's cross-stream dependencies travel through device-side flags and
  * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel
@@ -211,9 +229,9 @@ int gprn_profile_read(gprn_ctx* ctx, double* ms /*GPRN_T_COUNT*/,
  * return GPRN_E_ARG instead of aborting the queue); "overlap" (bit mask of what runs beside the factorisations
  * instead of before / behind them: 1 B formed inside the first panel's update, 2 row reductions over X panel by
  * panel, 4 node term beside the weight phase, 8 log det B in the finalising kernel, 16 a sweep's end beside the
- * next sweep's node phase; results are bit-identical for every value); "small_path" (1: problems of at most two
- * tiles -- N <= 256 -- run each phase of a sweep as ONE launch, one workgroup per latent GP, csrc/smalln.hip; 0: the
- * launch schedule at every size; same results).  value == -1 only reads; *old (may be NULL) receives the previous
+ * next sweep's node phase; results are bit-identical for every value); "small_path" (1, the default: problems of
+ * one tile -- N <= 128 -- run each half-sweep as ONE launch, one workgroup per latent GP, csrc/smalln.hip; 2: problems
+ * of two tiles too; 0: the launch schedule at every size; same results to rounding).  value == -1 only reads; *old (may be NULL) receives the previous
  * value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 

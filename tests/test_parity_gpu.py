@@ -202,6 +202,94 @@ def test_elbocalc_at_sizes_around_the_tile_edges(n, p, q):
     np.testing.assert_allclose(var, var_ref, rtol=1e-6, atol=1e-10)
 
 
+@pytest.mark.parametrize('n,p,q,kind', [(45, 1, 1, 'SE'), (128, 2, 2, 'QP'), (130, 3, 3, 'QP'), (200, 1, 1, 'SE'), (256, 2, 3, 'QP')])
+def test_small_path_matches_launch_schedule(n, p, q, kind):
+    """Problems of one tile (N <= 128; of two tiles with option "small_path" = 2) run a half-sweep as ONE launch, one
+    workgroup per latent GP (csrc/smalln.hip); the launch schedule of the large problems (option 0) computes the same thing through two dozen
+    launches.  Same set-up values, same sweeps, same state: both paths use the same diagonal-block kernel and the same
+    order in every reduction, so they differ by the rounding of a few reassociated products at most."""
+    t, ys, es = synth.rv_series(n, p)
+    spec = synth.component_spec(p, q, kind)
+    out = {}
+    for small in (1, 0):
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        g._backend().option('small_path', 2 * small)         # (2: two tiles too, off by default -- slower there)
+        ctx = g._setup_device(nodes, weights, means, jit)
+        assert g.last_info == 0
+        mu0, var0 = g._initMuVar(nodes, weights, jit)
+        ctx.set_muvar(mu0, var0)
+        e, parts, info = ctx.sweep(3, commit=True)
+        assert info == 0
+        out[small] = (e, parts, ctx.get_logdet_K()) + ctx.get_muvar()
+        sc = ctx.get_scalars()
+        out[small] += (sc['logdetB'], sc['trBinv'], sc['muKmu'], sc['q1'])
+        _assert_default_schedule(ctx)
+    # (two tiles: L_10 comes from the tile contraction here and from the chain's 16 x 16 kernel there -- other summation
+    # orders, and cond(K) ~ 1e8 turns 1e-16 into 1e-9 on chol(K)^-1)
+    for name, a, b in zip(('elbo', 'parts', 'logdet K', 'mu', 'var', 'logdet B', 'tr B^-1', 'mu K^-1 mu', 'q1'), out[1], out[0]):
+        if name in ('mu', 'var'):
+            continue
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11 * max(1.0, float(np.abs(b).max())), err_msg=name)
+    _cases.assert_state('small path vs launch schedule N=%d p=%d q=%d' % (n, p, q), out[1][3], out[0][3], out[1][4], out[0][4], tol=1e-9)
+
+
+@pytest.mark.parametrize('max_iter', [0, 1, 3, 4, 9, 20, 10000])
+def test_elbocalc_loop_on_the_device_matches_the_host_loop(max_iter, capsys):
+    """ELBOcalc's loop (meanfield.py:626-649) runs on the device for one-tile problems -- k_small_tail applies the stop
+    rule, sweeps are enqueued eight at a time ahead of its verdict -- and sweep by sweep with the rule on the host
+    otherwise.  Same elboArray, same trip count, same final state for every max_iter: none (only the discarded sweep),
+    fewer than the rule needs, exactly at a batch boundary, beyond it, and the reference's default."""
+    n, p, q = 60, 2, 2
+    t, ys, es = synth.rv_series(n, p)
+    spec = synth.component_spec(p, q, 'QP')
+    res = {}
+    for small in (1, 0):
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        g._backend().option('small_path', small)
+        E, mu, var, it = g.ELBOcalc(max_iter=max_iter)
+        said_max = 'Max iterations reached' in capsys.readouterr().out
+        res[small] = (E, mu, var, it, g._elbo_history.copy(), said_max, g._mu is not None)
+        assert g.last_info == 0
+        # warm start from where the loop ended (meanfield.py:598-607)
+        E2, _, _, it2 = g.ELBOcalc(max_iter=max_iter, mu='previous', var='previous')
+        res[small] += (E2, it2)
+    a, b = res[1], res[0]
+    assert a[3] == b[3] and a[5] == b[5] and a[6] == b[6] and a[8] == b[8]
+    assert a[4].shape == b[4].shape == (a[3] + 1,)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-9)          # (dozens of sweeps: the two paths' roundings drift apart)
+    np.testing.assert_allclose([a[0], a[7]], [b[0], b[7]], rtol=1e-9)
+    _cases.assert_state('device loop vs host loop, max_iter %d' % max_iter, a[1], b[1], a[2], b[2], tol=1e-9)
+    if max_iter == 10000:
+        assert 3 < a[3] < 10000 and not a[5]
+
+
+def test_small_path_reports_a_failed_pivot():
+    """jnp.linalg.cholesky semantics on the small path too: a matrix that is not positive definite gives info > 0 (the
+    order of the failing minor, LAPACK style) and NaN downstream, no exception (meanfield.py:71-89)."""
+    n = 60
+    t, ys, es = synth.rv_series(n, 1)
+
+    class Indefinite(covfunc.covFunction):
+        _param_names = ('theta',)
+        _tag = 'bad'
+
+        def __call__(self, r):
+            k = self.pars[0] ** 2 * np.exp(-0.5 * r ** 2 / 30.0 ** 2)
+            if k.ndim == 2 and k.shape[0] == k.shape[1]:
+                k = k.copy()
+                k[40, 40] = -1.0
+            return k
+
+    g = gpyrn.inference(1, t, ys[0], es[0])
+    g.set_components(Indefinite(1.0), covfunc.SquaredExponential(1.0, 60.0), meanfunc.Constant(0.0), 0.5)
+    E, mu, var, it = g.ELBOcalc(max_iter=5)
+    assert g.last_info == 41 and not np.isfinite(E)
+
+
 def test_elboaux_shim_returns_sigma():
     meta, d, g = _model('step_p3q2')
     j2 = np.array(meta['jitters'])**2
@@ -322,6 +410,7 @@ def test_rccl_calls_on_a_one_rank_communicator(monkeypatch):
     from gpyrn_amd import sharding
     monkeypatch.setenv('GPRN_FORCE_RCCL', '1')
     meta, d, g_plain = _model('step_p3q2')
+    g_plain._backend().option('small_path', 0)         # (a context with a communicator runs the launch schedule at every size)
     ref = g_plain.ELBOcalc()
     meta, d, g = _model('step_p3q2')
 
