@@ -159,7 +159,9 @@ def cpu_baseline(N, p, q, kind):
     out = {'value': n_all / dt_all, 'unit': 'sweeps/s', 'cores': os.cpu_count(), 'kind': 'port',
            'sample': f'{n_all} consecutive reference-formulation sweeps of the configuration (N={N}, p={p}, q={q}: all {G} '
                      f'latent GPs, {dt_all:.1f} s) with NumPy/SciPy LAPACK on all host cores',
-           'blas': _blas_build()}
+           'blas': _blas_build(),
+           'note': 'the BLAS picks its own thread count (OpenBLAS builds cap it, e.g. 64 on a 256-core box): a stated baseline, '
+                   'not a tuned one'}
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
@@ -389,7 +391,7 @@ def main():
     ctx = g._setup_device(nodes, weights, means, jit)     # fill + chol(K): once per ELBOcalc
     ctx.barrier_max(0.0)
     t_setup = time.time() - t0
-    ms_fill, n_fill = 0.0, 0
+    ms_fill, n_fill, ms_fill_pass = 0.0, 0, 0.0
     mu0, var0 = g._initMuVar(nodes, weights, jit)
     ctx.set_muvar(mu0, var0)
 
@@ -414,6 +416,7 @@ def main():
         g._setup_device(nodes, weights, means, jit)
         ms_fill, n_fill = ctx.profile_read()['fill']
         ctx.profile_enable([])
+        ms_fill_pass = ctx.fill_rate(20)                        # the same fills, launch behind launch, in ONE event bracket
         calc = {'elbocalc_per_s': 1.0 / min(times), 'ms': 1e3 * min(times), 'loop_trips': trips[-1]}
         if world == 1:
             # GPRN prediction at 1000 new times from the converged state
@@ -501,7 +504,11 @@ def main():
             'cholesky_gflops': sweep_flops(N, p, q) * a.steps / dt / 1e9,
             # fused covariance fill at setup: 8 N^2 bytes written per matrix, against the HBM peak
             # (it is fp64-VALU-bound, not HBM-bound: a division and exp/sin per element)
-            'fill': ({'GBps': n_fill * 8.0 * N * N / (ms_fill * 1e-3) / 1e9, 'launches': n_fill,
+            # (kernel_GBps: the launches back to back inside one event bracket -- the rate the kernels run at; GBps: every
+            # launch bracketed by its own pair of events, gaps included)
+            'fill': ({'kernel_GBps': (n_fill * 8.0 * N * N / (ms_fill_pass * 1e-3) / 1e9) if ms_fill_pass > 0 else None,
+                      'kernel_frac': (n_fill * 8.0 * N * N / (ms_fill_pass * 1e-3) / 1e9 / HBM_PEAK_GBPS) if ms_fill_pass > 0 else None,
+                      'GBps': n_fill * 8.0 * N * N / (ms_fill * 1e-3) / 1e9, 'launches': n_fill,
                       'peak_GBps': HBM_PEAK_GBPS,
                       'frac': n_fill * 8.0 * N * N / (ms_fill * 1e-3) / 1e9 / HBM_PEAK_GBPS}
                      if ms_fill > 0 else None),

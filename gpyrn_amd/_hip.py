@@ -63,6 +63,7 @@ SIGNATURES = {
     'gprn_test_factor_invert': (c_int, [c_void_p, c_int, c_int, _dp, _dp, _dp]),
     'gprn_test_lauum': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_test_gemm_rate': (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, _dp]),
+    'gprn_test_fill_rate': (c_int, [c_void_p, c_int, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
     'gprn_elbocalc': (c_int, [c_void_p, c_int, _dp, _dp, _dp, _dp, c_int, _dp, c_int, POINTER(c_int), POINTER(c_int),
@@ -391,6 +392,12 @@ class Context:
         v = c_double(0.0)
         self._check(self._lib.gprn_test_gemm_rate(self._h, int(M), int(N), int(K), int(how), int(reps), byref(v)), 'test_gemm_rate')
         return 2.0 * M * N * K / (v.value * 1e-3) / 1e12
+
+    def fill_rate(self, reps=20):
+        """ms per pass over all local covariance fills (the kernels last sent), timed inside one pair of events."""
+        v = c_double(0.0)
+        self._check(self._lib.gprn_test_fill_rate(self._h, int(reps), byref(v)), 'test_fill_rate')
+        return v.value
 
     def mfma_peak(self, wg_per_cu=1, iters=2000):
         """Measured fp64 MFMA issue ceiling (TFLOP/s) of this device."""

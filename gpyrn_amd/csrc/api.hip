@@ -135,6 +135,29 @@ static int agree_on_timeout(gprn_ctx* c, int rc, bool* any)
     return GPRN_OK;
 }
 
+// First collective of every entry point that issues collectives: the ranks exchange the verdict of their
+// LOCAL checks -- arguments, preconditions -- before anybody starts the body.  A rank that would return early on its own
+// would leave the others in the body's broadcasts, which have no time-out.  Either all go on, or all return: the rank
+// with the finding its own code and text, the others GPRN_E_COMM.
+static int agree_to_start(gprn_ctx* c, int local_rc, const char* what)
+{
+    if (!comm_active(c)) return local_rc;
+    if (!c->d_agree && hipMalloc(&c->d_agree, sizeof(double)) != hipSuccess) { c->err = "hipMalloc: agreement word"; return GPRN_E_NOMEM; }
+    const double mine = local_rc ? 1.0 : 0.0;
+    double all = 0.0;
+    HIP_TRY(c, hipMemcpyAsync(c->d_agree, &mine, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int r = comm_allreduce(c, c->d_agree, 1, true);
+    if (r) return local_rc ? local_rc : r;
+    HIP_TRY(c, hipMemcpyAsync(&all, c->d_agree, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (local_rc) return local_rc;
+    if (all > 0.0) {
+        c->err = std::string(what) + ": another rank did not pass its checks; no rank started the call";
+        return GPRN_E_COMM;
+    }
+    return GPRN_OK;
+}
+
 template <class F>
 static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool collective = false)
 {
@@ -919,8 +942,10 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
     if (!c || !c->N) return bad(c, "factor_priors: call set_data first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->owner.empty()) return bad(c, "factor_priors: call set_owners first");
-    for (int g = 0; g < c->G; ++g)
-        if (!c->kspec[g].set) return bad(c, "factor_priors: a latent GP has no kernel");
+    int pre = GPRN_OK;
+    for (int g = 0; g < c->G && !pre; ++g)
+        if (!c->kspec[g].set) pre = bad(c, "factor_priors: a latent GP has no kernel");
+    if ((pre = agree_to_start(c, pre, "factor_priors"))) return pre;
     // (every K is refilled from its kernel spec -- or still holds the uploaded matrix -- so a re-run starts clean)
     return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); }, true);
 }
@@ -1199,10 +1224,13 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
 extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
 {
     DeviceLock lock_(c);
-    if (!c || n_sweeps <= 0 || !elbo_out) return bad(c, "sweep: bad argument");
-    if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
-        return bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
+    if (!c) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    int pre = GPRN_OK;
+    if (n_sweeps <= 0 || !elbo_out) pre = bad(c, "sweep: bad argument");
+    else if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
+        pre = bad(c, "sweep: needs factor_priors, set_y_resid, set_jitters and set_muvar first");
+    if ((pre = agree_to_start(c, pre, "sweep"))) return pre;
     return with_event_fallback(c, "sweep", [&](bool retry) {
         return sweep_impl(c, n_sweeps, commit, elbo_out, parts_out, retry); }, true);
 }
@@ -1504,8 +1532,10 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
             if (rc < 0) return rc;
             info = rc;
         }
+        int pre = GPRN_OK;
         if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
-            return bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
+            pre = bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
+        if ((pre = agree_to_start(c, pre, "elbocalc"))) return pre;
         double e = 0.0;
         rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 0, &e, nullptr, retry); }, true);
         if (rc < 0) return rc;
@@ -1616,10 +1646,23 @@ __global__ void k_add_to_diagonal(double* __restrict__ A, int ld, const double* 
 extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
 {
     DeviceLock lock_(c);
-    if (!c || !c->N || ns <= 0 || !tstar || !mean_out || !var_out) return bad(c, "predict: bad argument");
-    if (!c->have_muvar) return bad(c, "predict: set_muvar (or a sweep) first");
+    if (!c || !c->N) return bad(c, "predict: bad argument");
     if (c->owner.empty()) return bad(c, "predict: call set_owners first");
     HIP_TRY(c, hipSetDevice(c->device));
+    int pre = GPRN_OK;
+    if (ns <= 0 || !tstar || !mean_out || !var_out) pre = bad(c, "predict: bad argument");
+    else if (!c->have_muvar) pre = bad(c, "predict: set_muvar (or a sweep) first");
+    else
+        for (int g = 0; g < c->G && !pre; ++g) {
+            if (c->owner[g] != c->rank) continue;
+            if (!c->kspec[g].set) pre = bad(c, "predict: a latent GP has no kernel");
+            else if (c->kspec[g].uploaded) {
+                auto it = c->pred_stage.find(g);
+                if (it == c->pred_stage.end() || it->second.ns != ns)
+                    pre = bad(c, "predict: a host-evaluated kernel needs gprn_predict_upload (K, K*, k**) for this ns first");
+            }
+        }
+    if ((pre = agree_to_start(c, pre, "predict"))) { c->pred_stage.clear(); return pre; }
     // (everything it factors is refilled from the kernel specs, the staged matrices and the variational state)
     const int rc = with_event_fallback(c, "predict", [&](bool) { return predict_impl(c, ns, tstar, mean_out, var_out); },
                                        true);
@@ -2129,6 +2172,37 @@ extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, in
     hipStreamSynchronize(c->stream);
     hipFree(d_t); tab_forget(c, d_p); hipFree(d_p);
     *ms = t;
+    return rc;
+}
+
+// Time (ms per pass, average of `reps`) of the set-up's covariance fills -- every latent GP's kernel as last given by
+// gprn_set_kernel into its own K, launch behind launch -- inside ONE pair of events: the rate the kernels run at.
+// (The profiler's 'fill' family brackets every launch with events of its own: that figure includes the gaps between
+// launches and varies with the box.)
+extern "C" int gprn_test_fill_rate(gprn_ctx* c, int reps, double* ms)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || reps < 1 || !ms) return bad(c, "test_fill_rate: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(build_tables(c));
+    std::vector<int> gps(c->loc_nodes);
+    gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
+    for (int g : gps)
+        if (!c->kspec[g].set || c->kspec[g].uploaded) return bad(c, "test_fill_rate: every local latent GP needs a device kernel");
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    int rc = GPRN_OK;
+    for (int g : gps) if (!rc) rc = launch_fill(c, c->kspec[g], c->K[g]);          // warm
+    hipEventRecord(e0, c->stream);
+    for (int r = 0; r < reps && !rc; ++r)
+        for (int g : gps) if (!rc) rc = launch_fill(c, c->kspec[g], c->K[g]);
+    hipEventRecord(e1, c->stream);
+    hipEventSynchronize(e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms = t / reps;
     return rc;
 }
 

@@ -245,6 +245,9 @@ int gprn_test_gemm(gprn_ctx* ctx, int M, int N, int K, int a_mode, int b_mode,
 /* time (ms, average of reps) of C -= A.B^T, M x N x K on random device data, through the tile contraction: one launch
  * with 64 x 64 (how 0) / 128 x 128 (how 1) workgroups */
 int gprn_test_gemm_rate(gprn_ctx* ctx, int M, int N, int K, int how, int reps, double* ms);
+/* time (ms per pass, average of reps) of the set-up's covariance fills -- every local latent GP's kernel into its K,
+ * launch behind launch -- inside one pair of events: the rate the fill kernels themselves run at */
+int gprn_test_fill_rate(gprn_ctx* ctx, int reps, double* ms);
 /* in: SPD A (n x n, n multiple of 128); out: L (lower, upper zeroed) and L^-1 */
 int gprn_test_factor_invert(gprn_ctx* ctx, int n, int batch, const double* A,
                             double* L, double* Linv);

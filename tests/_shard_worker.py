@@ -35,6 +35,22 @@ def main(tag, out, uid_tag):
     res = {}
     # forced sweeps from the reference's own initial state
     ctx = g._setup_device(g.nodes, g.weights, g.means, g.jitters)
+    bad_rank = int(os.environ.get('GPRN_TEST_BAD_RANK', -1))
+    if bad_rank >= 0:
+        # ONE rank fails a local check (here: it never set the state).  The ranks agree on their checks before
+        # anybody issues a collective, so every rank returns -- the one with the finding its own error, the others "another
+        # rank did not pass its checks" -- instead of the others waiting in a broadcast for ever
+        from gpyrn_amd import _hip
+        if comm.rank != bad_rank:
+            ctx.set_muvar(d['mu_init'], d['var_init'])
+        try:
+            ctx.sweep(1, commit=True)
+            msg = 'no error'
+        except _hip.BackendError as exc:
+            msg = str(exc)
+        np.savez(out, rank=comm.rank, world=comm.world, message=msg)
+        comm.cleanup()
+        return
     ctx.set_muvar(d['mu_init'], d['var_init'])
     hook_rank = int(os.environ.get('GPRN_TEST_WITHHOLD_RANK', -1))
     if hook_rank == comm.rank:
