@@ -256,6 +256,20 @@ def latency(a):
                 g.nELBO(x)
                 trips.append(len(g._elbo_history) - 1)
             dt = time.perf_counter() - t0
+        # the same walk's points as ONE call: side by side on the device (nELBO_batch -> gprn_elbocalc_batch; N <= 128)
+        side = None
+        if N <= 128:
+            with contextlib.redirect_stdout(io.StringIO()):
+                g.nELBO_batch(xs[:8])                            # buffers
+                nb = 256
+                xb = [x0 * (1.0 + 0.01 * rng.standard_normal(x0.size)) for _ in range(nb)]
+                t0 = time.perf_counter()
+                vals = g.nELBO_batch(xb)
+                dtb = time.perf_counter() - t0
+            side = {'value': nb / dtb, 'unit': 'evaluations/s', 'evaluations': nb, 'ms_total': 1e3 * dtb,
+                    'all_finite': bool(np.all(np.isfinite(vals))),
+                    'note': 'inference.nELBO_batch: every evaluation with its own matrices, state, loop and stop rule, all in the '
+                            'same launches (grid y = evaluation); what an optimiser population or emcee walkers ask for'}
         cpu = None
         if not a.no_cpu:
             # the CPU walk starts at x0 too.  Twice: with ONE BLAS thread (at these sizes the threads of a
@@ -283,6 +297,7 @@ def latency(a):
             'schedule': {'flags': int(ctx.option('flags')), 'fallbacks': int(ctx.option('fallbacks'))},
             'reference_note': ('one_dataset.ipynb cell 20 prints 2.79 ms per nELBO for this problem shape on its author\'s '
                                'machine (jax on CPU)' if kind == 'notebook' else None),
+            'side_by_side': side,
             'cpu_baseline': cpu}), flush=True)
 
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     'gprn_test_fill_rate': (c_int, [c_void_p, c_int, _dp]),
     'gprn_test_mfma_peak': (c_int, [c_void_p, c_int, c_int, _dp]),
     'gprn_set_option': (c_int, [c_void_p, c_char_p, c_int, POINTER(c_int)]),
+    'gprn_elbocalc_batch': (c_int, [c_void_p, c_int, _dp, c_int, _dp, _dp, _dp, _dp, c_int, _dp, POINTER(c_int), POINTER(c_int),
+                            POINTER(c_int), _dp, _dp]),
     'gprn_elbocalc': (c_int, [c_void_p, c_int, _dp, _dp, _dp, _dp, c_int, _dp, c_int, POINTER(c_int), POINTER(c_int),
                       POINTER(c_int), _dp, _dp]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
@@ -344,6 +346,33 @@ class Context:
         shape = (self.p + 1, self.q, self.N)
         return (hist[:min(n.value, cap)].copy(), it.value, bool(conv.value), info,
                 mu_out.reshape(shape), var_out.reshape(shape))
+
+    def elbocalc_batch(self, kernel_params, y_resid, jitters, mu, var, max_iter, want_state=False):
+        """B independent ELBOcalc loops side by side (gprn_elbocalc_batch): kernel_params (B, n_kpar), y_resid (B, p, N),
+        jitters (B, p), mu / var (B, d).  Returns (elbo[B], iterations[B], converged[B], info[B]) and, with want_state,
+        the final states (B, p+1, q, N) twice -- or None where the library has no batched form for this problem."""
+        kp = _f64(np.atleast_2d(kernel_params))
+        B = kp.shape[0]
+        d = (self.p + 1) * self.q * self.N
+        yr = _f64(np.reshape(y_resid, (B, self.p * self.N)))
+        jt = _f64(np.reshape(jitters, (B, self.p)))
+        m0, v0 = _f64(np.reshape(mu, (B, d))), _f64(np.reshape(var, (B, d)))
+        elbo = np.empty(B)
+        it, cv, info = (np.zeros(B, dtype=np.int32) for _ in range(3))
+        mo = np.empty((B, d)) if want_state else None
+        vo = np.empty((B, d)) if want_state else None
+        ip = lambda a: a.ctypes.data_as(POINTER(c_int))
+        rc = self._lib.gprn_elbocalc_batch(self._h, B, _ptr(kp), kp.shape[1], _ptr(yr), _ptr(jt), _ptr(m0), _ptr(v0),
+                                           int(max_iter), _ptr(elbo), ip(it), ip(cv), ip(info),
+                                           _ptr(mo) if want_state else None, _ptr(vo) if want_state else None)
+        if rc == GPRN_E_UNSUPPORTED:
+            return None
+        self._check(rc, 'elbocalc_batch')
+        out = (elbo, it.astype(int), cv.astype(bool), info.astype(int))
+        if want_state:
+            shape = (B, self.p + 1, self.q, self.N)
+            out += (mo.reshape(shape), vo.reshape(shape))
+        return out
 
     def option(self, name, value=-1):
         """Read (value < 0) or set a per-context switch of the library; returns the previous value."""

@@ -232,6 +232,7 @@ static void free_problem(gprn_ctx* c)
     dev_free(c->d_mu_save); dev_free(c->d_var_save);
     dev_free(c->d_mu_alt); dev_free(c->d_var_alt);
     if (c->d_loop_ctl) { hipFree(c->d_loop_ctl); c->d_loop_ctl = nullptr; }
+    small_batch_free(c);
     if (c->h_pin_in) { hipHostFree(c->h_pin_in); c->h_pin_in = nullptr; c->pin_in_cap = 0; }
     if (c->h_pin_out) { hipHostFree(c->h_pin_out); c->h_pin_out = nullptr; c->pin_out_cap = 0; }
     dev_free(c->d_loop_hist);
@@ -1559,6 +1560,23 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
     const int n = (int)hist.size(), keep = std::min(n, cap);
     for (int i = 0; i < keep; ++i) history[i] = hist[(size_t)(n - keep) + i];
     return info;
+}
+
+// B independent evaluations of the loop above, side by side on the device (smalln.hip): see include/gprn_hip.h
+extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel_params, int n_kernel_params,
+                                   const double* y_resid, const double* jitters, const double* mu, const double* var,
+                                   int max_iter, double* elbo, int* iterations, int* converged, int* info,
+                                   double* mu_out, double* var_out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || n_eval < 1 || !kernel_params || !y_resid || !jitters || !mu || !var || max_iter < 0 || !elbo ||
+        !iterations || !converged || !info || (!mu_out != !var_out))
+        return bad(c, "elbocalc_batch: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->owner.empty()) return bad(c, "elbocalc_batch: call set_owners first");
+    TRY(build_tables(c));
+    return small_batch_elbocalc(c, n_eval, kernel_params, n_kernel_params, y_resid, jitters, mu, var, max_iter, elbo,
+                                iterations, converged, info, mu_out, var_out);
 }
 
 // ------------------------------------------------------------------ read-back

@@ -13,6 +13,7 @@
 #include "gprn_internal.h"
 
 #include <math.h>
+#include <string.h>
 
 struct FillProgram {
     int n_ops;
@@ -459,6 +460,88 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val,
 #undef X
     default: hipLaunchKernelGGL(k_fill<-1>, grid, dim3(256), 0, c->stream, pg, c->d_time, K, c->N, c->ld, diag_add);
     }
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// ---- many small matrices in one launch (gprn_elbocalc_batch, smalln.hip): matrix b of the launch has its own program
+// (device memory) and its own destination; one workgroup per lower 64 x 64 block as in k_fill_sym.  The three kernels that
+// carry host-computed reciprocals (SE, Periodic, QP) are dispatched to their own evaluation, so that a matrix filled here
+// has the bits of one filled by launch_fill; everything else goes through the postfix program.
+__global__ __launch_bounds__(256)
+void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restrict__ t, double* const* __restrict__ Ks,
+                      int N, int ld)
+{
+    constexpr int TR = 64;
+    __shared__ double tile[TR][65];
+    const FillProgram& pg = pgs[blockIdx.y];
+    double* const K = Ks[blockIdx.y];
+    const int kid = (pg.n_ops == 1 && pg.ops[0] == GPRN_OP_PUSH) ? pg.ops[1] : -1;
+    const int L = blockIdx.x;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= L) ++bi;
+    const int bj = L - bi * (bi + 1) / 2;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n = bj * 64 + 2 * tx;
+    const double tn0 = (n < N) ? t[n] : 0.0, tn1 = (n + 1 < N) ? t[n + 1] : 0.0;
+    const int row0 = bi * 64;
+    auto eval = [&](double ti, double tj, bool diag) {
+        switch (kid) {
+        case GPRN_K_SE: return eval_any<GPRN_K_SE>(pg, ti, tj, diag);
+        case GPRN_K_PERIODIC: return eval_any<GPRN_K_PERIODIC>(pg, ti, tj, diag);
+        case GPRN_K_QP: return eval_any<GPRN_K_QP>(pg, ti, tj, diag);
+        default: return eval_program(pg, ti, tj, diag);
+        }
+    };
+#pragma unroll 1
+    for (int i = 0; i < TR / 8; ++i) {
+        const int r = ty + 8 * i, m = row0 + r;
+        const double tm = (m < N) ? t[m] : 0.0;
+        double v0 = eval(tm, tn0, m == n);
+        double v1 = eval(tm, tn1, m == n + 1);
+        if (m == n || m == n + 1) {
+            double d = (m == n) ? v0 : v1;
+            if (pg.nugget) d += pg.nugget_val;
+            if (m == n) v0 = d; else v1 = d;
+        }
+        if (m >= N || n >= N) v0 = (m == n) ? 1.0 : 0.0;
+        if (m >= N || n + 1 >= N) v1 = (m == n + 1) ? 1.0 : 0.0;
+        *(double2*)(K + (size_t)m * ld + n) = make_double2(v0, v1);
+        tile[r][2 * tx] = v0;
+        tile[r][2 * tx + 1] = v1;
+    }
+    if (bi == bj) return;
+    __syncthreads();
+    constexpr int CP = TR / 2;
+    for (int idx = threadIdx.x; idx < 64 * CP; idx += 256) {
+        const int c = idx / CP, rp = idx % CP;
+        *(double2*)(K + (size_t)(bj * 64 + c) * ld + row0 + 2 * rp) = make_double2(tile[2 * rp][c], tile[2 * rp + 1][c]);
+    }
+}
+
+size_t fill_program_bytes() { return sizeof(FillProgram); }
+
+// the program of `ks` (1e-6 nugget for one-argument kernels: meanfield.py:433) with other parameter values, written to dst;
+// false when the program is not an even function of t_i - t_j (Polynomial: the symmetric fill does not apply)
+bool fill_program_with(const KernelSpec& ks, const double* params, void* dst)
+{
+    KernelSpec k2 = ks;
+    for (int i = 0; i < ks.n_params; ++i) k2.params[i] = params[i];
+    FillProgram pg;
+    make_program(k2, 1e-6, pg);
+    memcpy(dst, &pg, sizeof(pg));
+    return program_is_even(pg);
+}
+
+// n_matrices matrices of the context's N (ld = 128 T) from d_programs[i] into d_Ks[i]
+int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices)
+{
+    if (n_matrices <= 0) return GPRN_OK;
+    prof_begin(c, GPRN_T_FILL);
+    const int nb = c->ld / 64;
+    hipLaunchKernelGGL(k_fill_sym_batch, dim3(nb * (nb + 1) / 2, n_matrices), dim3(256), 0, c->stream,
+                       (const FillProgram*)d_programs, c->d_time, d_Ks, c->N, c->ld);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

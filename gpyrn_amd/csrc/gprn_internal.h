@@ -230,6 +230,7 @@ struct gprn_ctx {
     int* d_loop_ctl = nullptr;       // gprn_elbocalc on the small path: [0] done, [1] iterNumber, [2] converged (+ pad)
     double* d_loop_hist = nullptr;   // ... the batch's ELBO values, then the loop's last three
     double *h_pin_in = nullptr, *h_pin_out = nullptr;    // pinned staging of gprn_elbocalc's inputs / read-backs
+    void* small_batch = nullptr;     // SmallBatchMem (smalln.hip): buffers of gprn_elbocalc_batch
     size_t pin_in_cap = 0, pin_out_cap = 0;
     bool small_tabs_ready = false;   // the set-up's tables for this problem are on the device (factor_priors_small)
 };
@@ -246,6 +247,10 @@ void prof_end(gprn_ctx* c);
 
 int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val = 1e-6,
                 const double* diag_add = nullptr);
+// many small matrices in one launch (fill.hip; gprn_elbocalc_batch)
+size_t fill_program_bytes();
+bool fill_program_with(const KernelSpec& ks, const double* params, void* dst);
+int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices);
 int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const double* d_tstar,
                      int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
@@ -378,3 +383,8 @@ struct SmallLoop { int* ctl; double *hist, *last3; int sweep, hist_at, max_iter;
 // mu^T K^-1 mu, Q1 traces, ELBO assembly of the sweep whose new state is (mu, var); loop: the stop rule too, or null
 int small_tail(gprn_ctx* c, double* out4, double* scal, const double* mu, const double* var, const SmallLoop* loop = nullptr);
 int small_prior(gprn_ctx* c, double** d_tab, const int* d_job_gp, double** d_kinv_out, int njobs, int* d_info);
+// n_eval independent evaluations of the ELBOcalc loop side by side (gprn_elbocalc_batch); GPRN_E_UNSUPPORTED where it does not apply
+int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpar, const double* y_resid, const double* jitters,
+                         const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
+                         double* mu_out, double* var_out);
+void small_batch_free(gprn_ctx* c);

@@ -20,8 +20,10 @@
 #include "vecops.h"
 
 #include <math.h>
+#include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #define SMALL_MAXLD 256
 // LDS: the diagonal-block kernel's buffers and the tile contraction's stages are used in turn
@@ -161,8 +163,7 @@ struct SmallPhaseArgs {
 
 // One half-sweep.  WEIGHTS: the weight phase (new mu_f, old mu_w) or the node phase; T: tiles per matrix edge.
 template <bool WEIGHTS, int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_small_phase(SmallPhaseArgs a)
+__device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
 {
     __shared__ __attribute__((aligned(16))) double lds[SMALL_LDS_DOUBLES];
     __shared__ double sS[SMALL_MAXLD], sZ[SMALL_MAXLD], sD[SMALL_MAXLD], sU[SMALL_MAXLD];
@@ -357,8 +358,7 @@ __device__ __forceinline__ void small_loglike(const SmallTailArgs& a, double* sh
 }
 
 template <int T>
-__global__ __launch_bounds__(256)
-void k_small_tail(SmallTailArgs a)
+__device__ __forceinline__ void small_tail_body(const SmallTailArgs& a)
 {
     __shared__ __attribute__((aligned(16))) double lds[SMALL_MMA_DOUBLES];
     __shared__ double sh4[4];
@@ -485,8 +485,7 @@ struct SmallPriorArgs {
 
 // chol(K) and its inverse for one latent GP per workgroup; log det K; K^-1 where asked
 template <int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_small_prior(SmallPriorArgs a)
+__device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
 {
     __shared__ __attribute__((aligned(16))) double lds[SMALL_LDS_DOUBLES];
     __shared__ double sh4[4];
@@ -516,6 +515,34 @@ void k_small_prior(SmallPriorArgs a)
             }
     }
 }
+
+// ---- the kernels: one problem per launch (grid x = latent GP), or -- gprn_elbocalc_batch -- many independent evaluations
+// of the same problem shape per launch (grid y = evaluation, its arguments in device memory)
+template <bool WEIGHTS, int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_small_phase(SmallPhaseArgs a) { small_phase_body<WEIGHTS, T>(a); }
+template <bool WEIGHTS, int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_small_phase_b(const SmallPhaseArgs* __restrict__ lanes) { small_phase_body<WEIGHTS, T>(lanes[blockIdx.y]); }
+
+template <int T>
+__global__ __launch_bounds__(256)
+void k_small_tail(SmallTailArgs a) { small_tail_body<T>(a); }
+template <int T>
+__global__ __launch_bounds__(256)
+void k_small_tail_b(const SmallTailArgs* __restrict__ lanes, int sweep, int hist_at, int max_iter)
+{
+    SmallTailArgs a = lanes[blockIdx.y];
+    a.sweep = sweep; a.hist_at = hist_at; a.max_iter = max_iter;
+    small_tail_body<T>(a);
+}
+
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_small_prior(SmallPriorArgs a) { small_prior_body<T>(a); }
+template <int T>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_small_prior_b(const SmallPriorArgs* __restrict__ lanes) { small_prior_body<T>(lanes[blockIdx.y]); }
 
 // ------------------------------------------------------------------ launchers
 // One tile (N <= 128) by default.  Two tiles work too (option "small_path" = 2; same tests) but do not pay: the four
@@ -572,5 +599,269 @@ int small_prior(gprn_ctx* c, double** d_tab, const int* d_job_gp, double** d_kin
     else hipLaunchKernelGGL(k_small_prior<2>, dim3(njobs), dim3(256), 0, c->stream, a);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// ------------------------------------------------------------------ many independent evaluations in one go
+// gprn_elbocalc_batch: B evaluations of inference.nELBO at B parameter vectors -- what an optimiser's population or
+// emcee's walkers ask for one by one (meanfield.py:1095-1111, 1222-1260) -- as ONE stream of launches: every launch
+// covers all B problems (grid y), each with its own matrices, state, loop control and stop rule; an evaluation that has
+// converged turns its workgroups into no-ops while the others go on.  A one-tile problem keeps G of the device's 256
+// CUs busy; B of them side by side fill it.
+struct SmallBatchMem {
+    int cap = 0;                      // evaluations the buffers hold
+    int G = 0, q = 0, p = 0, N = 0, ld = 0;
+    double *mats = nullptr;           // [cap][4 G + q][ld * ld]: K, KLinv, wsB, wsX per latent GP, K_j^-1 per node
+    double *vecs = nullptr;           // [cap][7][G * ld]
+    double *state = nullptr;          // [4][cap][d]: mu A, var A, mu B, var B
+    double *yv = nullptr;             // [2][cap][p N]: y - mean, variance
+    double *scal = nullptr, *logdetK = nullptr, *out4 = nullptr, *hist = nullptr;
+    int *ctl = nullptr, *info = nullptr, *gp_ids = nullptr;
+    unsigned* ticket = nullptr;
+    double** ptrs = nullptr;          // pointer tables: [cap] x (3 tables of G x 4, kinv_tab q, kinv_out G, K pointers G)
+    double** kptr_dense = nullptr;    // [cap][G]: where the fill puts evaluation b's matrix g
+    void* programs = nullptr;         // [cap][G] fill programs
+    SmallPhaseArgs* phase_args = nullptr;   // [2 parity][2 phase][cap]
+    SmallTailArgs* tail_args = nullptr;     // [2 parity][cap]
+    SmallPriorArgs* prior_args = nullptr;   // [cap]
+    char *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+};
+#define SB_K 8                         // sweeps per batch of launches (one synchronisation each)
+
+void small_batch_free(gprn_ctx* c)
+{
+    SmallBatchMem* m = (SmallBatchMem*)c->small_batch;
+    if (!m) return;
+    void* dev[] = {m->mats, m->vecs, m->state, m->yv, m->scal, m->logdetK, m->out4, m->hist, m->ctl, m->info, m->gp_ids,
+                   m->ticket, m->ptrs, m->kptr_dense, m->programs, m->phase_args, m->tail_args, m->prior_args};
+    for (void* ptr : dev) if (ptr) hipFree(ptr);
+    if (m->pin_in) hipHostFree(m->pin_in);
+    if (m->pin_out) hipHostFree(m->pin_out);
+    delete m;
+    c->small_batch = nullptr;
+}
+
+template <typename TT>
+static int sb_alloc(gprn_ctx* c, TT** ptr, size_t count)
+{
+    *ptr = nullptr;
+    if (hipMalloc((void**)ptr, std::max<size_t>(count, 1) * sizeof(TT)) != hipSuccess) { c->err = "hipMalloc (evaluation batch)"; return GPRN_E_NOMEM; }
+    return GPRN_OK;
+}
+#define SB_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+
+static int small_batch_ensure(gprn_ctx* c, int n_eval)
+{
+    SmallBatchMem* m = (SmallBatchMem*)c->small_batch;
+    const int G = c->G, q = c->q, p = c->p, N = c->N, ld = c->ld;
+    if (m && m->cap >= n_eval && m->G == G && m->q == q && m->p == p && m->N == N && m->ld == ld) return GPRN_OK;
+    small_batch_free(c);
+    m = new SmallBatchMem();
+    c->small_batch = m;
+    const int cap = std::max(n_eval, 16);
+    m->G = G; m->q = q; m->p = p; m->N = N; m->ld = ld;
+    const size_t nn = (size_t)ld * ld, d = (size_t)(p + 1) * q * N, pn = (size_t)p * N, nscal = 3 * (size_t)G + (size_t)q * q;
+    const size_t nmat = 4 * (size_t)G + q, nptr = 3 * (size_t)G * GPRN_NBUF + q + 2 * (size_t)G;
+    SB_TRY(sb_alloc(c, &m->mats, (size_t)cap * nmat * nn));
+    SB_TRY(sb_alloc(c, &m->vecs, (size_t)cap * 7 * G * ld));
+    SB_TRY(sb_alloc(c, &m->state, 4 * (size_t)cap * d));
+    SB_TRY(sb_alloc(c, &m->yv, 2 * (size_t)cap * pn));
+    SB_TRY(sb_alloc(c, &m->scal, (size_t)cap * nscal));
+    SB_TRY(sb_alloc(c, &m->logdetK, (size_t)cap * G));
+    SB_TRY(sb_alloc(c, &m->out4, (size_t)cap * 4));
+    SB_TRY(sb_alloc(c, &m->hist, (size_t)cap * (SB_K + 4)));
+    SB_TRY(sb_alloc(c, &m->ctl, (size_t)cap * 4));
+    SB_TRY(sb_alloc(c, &m->info, (size_t)cap * 3 * G));
+    SB_TRY(sb_alloc(c, &m->gp_ids, (size_t)G));
+    SB_TRY(sb_alloc(c, &m->ticket, (size_t)cap));
+    SB_TRY(sb_alloc(c, &m->ptrs, (size_t)cap * nptr));
+    SB_TRY(sb_alloc(c, &m->kptr_dense, (size_t)cap * G));
+    if (hipMalloc(&m->programs, (size_t)cap * G * fill_program_bytes()) != hipSuccess) { c->err = "hipMalloc (fill programs)"; return GPRN_E_NOMEM; }
+    SB_TRY(sb_alloc(c, &m->phase_args, 4 * (size_t)cap));
+    SB_TRY(sb_alloc(c, &m->tail_args, 2 * (size_t)cap));
+    SB_TRY(sb_alloc(c, &m->prior_args, (size_t)cap));
+    HIP_TRY(c, hipMemset(m->ticket, 0, (size_t)cap * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(m->scal, 0, (size_t)cap * nscal * sizeof(double)));
+    std::vector<int> ids(G);
+    for (int g = 0; g < G; ++g) ids[g] = g;
+    HIP_TRY(c, hipMemcpy(m->gp_ids, ids.data(), G * sizeof(int), hipMemcpyHostToDevice));
+    // ---- the fixed part of every evaluation's arguments: pointer tables and argument blocks
+    std::vector<double*> hp((size_t)cap * nptr, nullptr);
+    std::vector<SmallPhaseArgs> pa(4 * (size_t)cap);
+    std::vector<SmallTailArgs> ta(2 * (size_t)cap);
+    std::vector<SmallPriorArgs> pr((size_t)cap);
+    for (int b = 0; b < cap; ++b) {
+        double* const mb = m->mats + (size_t)b * nmat * nn;
+        auto Kp = [&](int g) { return mb + (size_t)g * nn; };
+        auto KLp = [&](int g) { return mb + ((size_t)G + g) * nn; };
+        auto Bp = [&](int g) { return mb + (2 * (size_t)G + g) * nn; };
+        auto Xp = [&](int g) { return mb + (3 * (size_t)G + g) * nn; };
+        auto Kinvp = [&](int j) { return mb + (4 * (size_t)G + j) * nn; };
+        double** const hb = hp.data() + (size_t)b * nptr;           // host image of this evaluation's tables
+        double** const db = m->ptrs + (size_t)b * nptr;             // ... and where it lies on the device
+        double** const h_setup = hb; double** const h_node = hb + (size_t)G * GPRN_NBUF; double** const h_weight = hb + 2 * (size_t)G * GPRN_NBUF;
+        double** const h_kinv_tab = hb + 3 * (size_t)G * GPRN_NBUF; double** const h_kinv_out = h_kinv_tab + q; double** const h_Kptr = h_kinv_out + G;
+        for (int g = 0; g < G; ++g) {
+            double* row[GPRN_NBUF] = {Bp(g), KLp(g), Kp(g), KLp(g)};      // set-up: BUF_B scratch, BUF_X = chol(K)^-1, BUF_K
+            for (int k = 0; k < GPRN_NBUF; ++k) h_setup[(size_t)g * GPRN_NBUF + k] = row[k];
+            double* srow[GPRN_NBUF] = {Bp(g), Xp(g), Kp(g), KLp(g)};       // sweeps: B, X, K, chol(K)^-1
+            double** const dst = g < q ? h_node + (size_t)g * GPRN_NBUF : h_weight + (size_t)(g - q) * GPRN_NBUF;
+            for (int k = 0; k < GPRN_NBUF; ++k) dst[k] = srow[k];
+            h_kinv_out[g] = (g >= 1 && g < q) ? Kinvp(g) : nullptr;
+            h_Kptr[g] = Kp(g);
+        }
+        for (int j = 0; j < q; ++j) h_kinv_tab[j] = j >= 1 ? Kinvp(j) : nullptr;
+        double** const d_setup = db; double** const d_node = db + (size_t)G * GPRN_NBUF; double** const d_weight = db + 2 * (size_t)G * GPRN_NBUF;
+        double** const d_kinv_tab = db + 3 * (size_t)G * GPRN_NBUF; double** const d_kinv_out = d_kinv_tab + q;
+        double* const vb = m->vecs + (size_t)b * 7 * G * ld;
+        auto vec = [&](int which, int slot0) { return vb + ((size_t)which * G + slot0) * ld; };
+        double* const yres = m->yv + (size_t)b * pn; double* const variance = m->yv + ((size_t)cap + b) * pn;
+        double* const st[4] = {m->state + (size_t)b * d, m->state + ((size_t)cap + b) * d, m->state + (2 * (size_t)cap + b) * d,
+                               m->state + (3 * (size_t)cap + b) * d};
+        double* const scal = m->scal + (size_t)b * nscal;
+        int* const ctl = m->ctl + (size_t)b * 4;
+        int* const info = m->info + (size_t)b * 3 * G;
+        for (int par = 0; par < 2; ++par) {
+            const double* mu_in = par ? st[2] : st[0]; const double* var_in = par ? st[3] : st[1];
+            double* mu_out = par ? st[0] : st[2]; double* var_out = par ? st[1] : st[3];
+            for (int ph = 0; ph < 2; ++ph) {
+                const int s0 = ph ? q : 0;
+                pa[((size_t)par * 2 + ph) * cap + b] = SmallPhaseArgs{
+                    (double* const*)(ph ? d_weight : d_node), m->gp_ids + s0, N, ld, p, q, yres, variance,
+                    mu_in, var_in, mu_out, var_out, ctl,
+                    vec(0, s0), vec(1, s0), vec(2, s0), vec(3, s0), vec(4, s0), vec(5, s0), vec(6, s0),
+                    scal + G, scal, info + (size_t)(1 + ph) * G, nullptr};
+            }
+            ta[(size_t)par * cap + b] = SmallTailArgs{
+                (double* const*)d_node, (double* const*)d_weight, m->gp_ids, m->gp_ids + q, q, G - q, N, ld, p, q, G,
+                mu_out, var_out, c->d_yraw, variance, vec(1, 0), (double* const*)d_kinv_tab, vec(4, 0), m->logdetK + (size_t)b * G,
+                scal, m->out4 + (size_t)b * 4, m->ticket + b, ctl, m->hist + (size_t)b * (SB_K + 4),
+                m->hist + (size_t)b * (SB_K + 4) + SB_K, 0, 0, 0};
+        }
+        pr[b] = SmallPriorArgs{(double* const*)d_setup, m->gp_ids, (double* const*)d_kinv_out, N, ld, m->logdetK + (size_t)b * G, info};
+    }
+    HIP_TRY(c, hipMemcpy(m->ptrs, hp.data(), hp.size() * sizeof(double*), hipMemcpyHostToDevice));
+    {
+        std::vector<double*> kd((size_t)cap * G);
+        for (int b = 0; b < cap; ++b)
+            for (int g = 0; g < G; ++g) kd[(size_t)b * G + g] = m->mats + ((size_t)b * nmat + g) * nn;
+        HIP_TRY(c, hipMemcpy(m->kptr_dense, kd.data(), kd.size() * sizeof(double*), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(c, hipMemcpy(m->phase_args, pa.data(), pa.size() * sizeof(SmallPhaseArgs), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(m->tail_args, ta.data(), ta.size() * sizeof(SmallTailArgs), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(m->prior_args, pr.data(), pr.size() * sizeof(SmallPriorArgs), hipMemcpyHostToDevice));
+    // pinned staging: in = programs | y - mean | variance | mu | var;  out = ctl | hist | info | the four state copies
+    m->pin_in_bytes = (size_t)cap * G * fill_program_bytes() + (2 * (size_t)cap * pn + 2 * (size_t)cap * d) * sizeof(double);
+    m->pin_out_bytes = (size_t)cap * (4 * sizeof(int) + (SB_K + 4) * sizeof(double) + 3 * G * sizeof(int)) + 4 * (size_t)cap * d * sizeof(double) + 64;
+    HIP_TRY(c, hipHostMalloc((void**)&m->pin_in, m->pin_in_bytes, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&m->pin_out, m->pin_out_bytes, hipHostMallocDefault));
+    m->cap = cap;
+    return GPRN_OK;
+}
+
+int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpar, const double* y_resid, const double* jitters,
+                         const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
+                         double* mu_out, double* var_out)
+{
+    if (c->T != 1 || !small_applies(c)) { c->err = "elbocalc_batch: one-tile problems on one rank only"; return GPRN_E_UNSUPPORTED; }
+    const int G = c->G, p = c->p, N = c->N, B = n_eval;
+    int kp_total = 0;
+    for (int g = 0; g < G; ++g) {
+        if (!c->kspec[g].set || c->kspec[g].uploaded) { c->err = "elbocalc_batch: every latent GP needs a device kernel program"; return GPRN_E_UNSUPPORTED; }
+        kp_total += c->kspec[g].n_params;
+    }
+    if (kp_total != n_kpar) { c->err = "elbocalc_batch: kernel_params has the wrong length per evaluation"; return GPRN_E_ARG; }
+    SB_TRY(small_batch_ensure(c, B));
+    SmallBatchMem* m = (SmallBatchMem*)c->small_batch;
+    const int cap = m->cap;
+    const size_t d = (size_t)(p + 1) * c->q * N, pn = (size_t)p * N, pb = fill_program_bytes();
+    // ---- inputs through the pinned buffer
+    char* const pg_h = m->pin_in;
+    double* const yres_h = (double*)(pg_h + (size_t)cap * G * pb);
+    double* const var_h = yres_h + (size_t)cap * pn;
+    double* const mu0_h = var_h + (size_t)cap * pn;
+    double* const v0_h = mu0_h + (size_t)cap * d;
+    for (int b = 0; b < B; ++b) {
+        const double* kp = kparams + (size_t)b * n_kpar;
+        for (int g = 0; g < G; ++g) {
+            if (!fill_program_with(c->kspec[g], kp, pg_h + ((size_t)b * G + g) * pb)) {
+                c->err = "elbocalc_batch: a kernel that is not an even function of t_i - t_j"; return GPRN_E_UNSUPPORTED;
+            }
+            kp += c->kspec[g].n_params;
+        }
+        memcpy(yres_h + (size_t)b * pn, y_resid + (size_t)b * pn, pn * sizeof(double));
+        for (int i = 0; i < p; ++i) {
+            const double j2 = jitters[(size_t)b * p + i] * jitters[(size_t)b * p + i];
+            for (int n = 0; n < N; ++n) var_h[(size_t)b * pn + (size_t)i * N + n] = j2 + c->h_yerr2[(size_t)i * N + n];
+        }
+        memcpy(mu0_h + (size_t)b * d, mu + (size_t)b * d, d * sizeof(double));
+        memcpy(v0_h + (size_t)b * d, var + (size_t)b * d, d * sizeof(double));
+    }
+    hipStream_t st = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(m->programs, pg_h, (size_t)B * G * pb, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(m->yv, yres_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(m->yv + (size_t)cap * pn, var_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(m->state, mu0_h, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemcpyAsync(m->state + (size_t)cap * d, v0_h, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync(m->ctl, 0, (size_t)B * 4 * sizeof(int), st));
+    // ---- set-up: every evaluation's G covariance matrices in one launch, their factors in another
+    SB_TRY(launch_fill_batch(c, m->programs, (double* const*)m->kptr_dense, B * G));
+    prof_begin(c, GPRN_T_DIAG);
+    hipLaunchKernelGGL(k_small_prior_b<1>, dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    // ---- the loop, SB_K sweeps per synchronisation
+    char* const po = m->pin_out;
+    int* const ctl_h = (int*)po;
+    double* const hist_h = (double*)(po + (size_t)cap * 4 * sizeof(int));
+    int* const info_h = (int*)(hist_h + (size_t)cap * (SB_K + 4));
+    double* const st_h = (double*)(((uintptr_t)(info_h + (size_t)cap * 3 * G) + 63) & ~(uintptr_t)63);
+    std::vector<char> was_done(B, 0);
+    for (int b = 0; b < B; ++b) { elbo[b] = 0.0; iters[b] = 0; conv[b] = 0; info[b] = 0; }
+    int s = 0;
+    bool all_done = false;
+    const int q = c->q;
+    while (!all_done && s <= max_iter) {
+        const int s0 = s;
+        int nb = 0;
+        for (; nb < SB_K && s <= max_iter; ++nb, ++s) {
+            const int par = (s <= 1 || (s & 1)) ? 0 : 1;          // sweep 0 and trip 1 start from copy A, then they alternate
+            prof_begin(c, GPRN_T_DIAG);
+            hipLaunchKernelGGL((k_small_phase_b<false, 1>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap));
+            hipLaunchKernelGGL((k_small_phase_b<true, 1>), dim3(G - q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 1) * cap));
+            prof_end(c);
+            prof_begin(c, GPRN_T_VEC);
+            hipLaunchKernelGGL(k_small_tail_b<1>, dim3(G, B), dim3(256), 0, st, (const SmallTailArgs*)(m->tail_args + (size_t)par * cap), s, nb, max_iter);
+            prof_end(c);
+        }
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(ctl_h, m->ctl, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(hist_h, m->hist, (size_t)B * (SB_K + 4) * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipMemcpyAsync(info_h, m->info, (size_t)B * 3 * G * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        all_done = true;
+        for (int b = 0; b < B; ++b) {
+            if (was_done[b]) continue;
+            const int* cb = ctl_h + (size_t)b * 4;
+            const int ran = cb[0] ? std::min(nb, cb[1] - s0 + 1) : nb;
+            if (ran > 0) elbo[b] = hist_h[(size_t)b * (SB_K + 4) + ran - 1];
+            iters[b] = cb[1];
+            conv[b] = cb[2];
+            for (int k = 0; k < 3 * G && !info[b]; ++k)
+                if (info_h[(size_t)b * 3 * G + k] > 0) info[b] = info_h[(size_t)b * 3 * G + k];
+            if (cb[0]) was_done[b] = 1;
+            else all_done = false;
+        }
+    }
+    if (mu_out && var_out) {
+        HIP_TRY(c, hipMemcpyAsync(st_h, m->state, 4 * (size_t)cap * d * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(c, hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) {
+            const bool in_b = iters[b] >= 1 && (iters[b] & 1);     // odd trips wrote copy B
+            memcpy(mu_out + (size_t)b * d, st_h + ((in_b ? 2 : 0) * (size_t)cap + b) * d, d * sizeof(double));
+            memcpy(var_out + (size_t)b * d, st_h + ((in_b ? 3 : 1) * (size_t)cap + b) * d, d * sizeof(double));
+        }
+    }
     return GPRN_OK;
 }

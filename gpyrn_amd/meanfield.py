@@ -664,7 +664,7 @@ class inference:
         mean, variance, parts = self._Prediction(tstar=tstar, separate=True)
         return tstar, mean, np.sqrt(variance), parts
 
-    def nELBO_batch(self, parameter_sets, max_iter=None, pool=None):
+    def nELBO_batch(self, parameter_sets, max_iter=None, pool=None, batch=True):
         """
         ``nELBO`` for several free-parameter vectors: ``[nELBO(p) for p in
         parameter_sets]``.  With ``pool`` (``sharding.EvalPool``; every rank holds
@@ -672,11 +672,68 @@ class inference:
         every rank returns the full list.  Not in the reference, which evaluates
         optimiser populations and emcee walkers one by one (meanfield.py:1222-1260).
         The parameters of ``self`` end up at the last vector this rank evaluated.
+
+        Without a pool, a problem of one tile (N <= 128) whose kernels all have device programs evaluates the whole list
+        SIDE BY SIDE on the GPU (``gprn_elbocalc_batch``): every evaluation with its own covariance matrices, state, loop
+        and stop rule, all of them starting from the state the object holds (``nELBO``'s warm start) -- where one
+        evaluation after the other starts each from its predecessor's result, which moves the values within the stop
+        rule's 1e-3.  ``batch=False`` forces the one-by-one form.
         """
         assert self._components_set, _NOT_SET
         sets = [np.array(x, dtype=float) for x in parameter_sets]
+        if pool is None and batch and len(sets) > 1:
+            out = self._nELBO_batch_device(sets, max_iter)
+            if out is not None:
+                return out
         f = lambda x: float(self.nELBO(x, max_iter=max_iter))
         return list(map(f, sets)) if pool is None else pool.map(f, sets)
+
+    def _nELBO_batch_device(self, sets, max_iter):
+        """``nELBO_batch`` through ``gprn_elbocalc_batch``, or None where that does not apply (larger problems, sharded
+        objects, user-defined kernels, kernel expressions that change shape from one vector to the next)."""
+        if self._comm is not None or self.N > 128:
+            return None
+        ctx = self._backend()
+        max_iter = 10000 if max_iter is None else int(max_iter)
+        kp, yr, jt, m0, v0 = [], [], [], [], []
+        shape_ref = None
+        y_raw = np.concatenate(self.y)
+        start = time_module.time()
+        for x in sets:
+            self.set_parameters(x)
+            nodes, weights, means, jitters = self._get_components()
+            specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
+            if any(sp[0] != 'device' for sp in specs):
+                return None
+            shape = tuple((sp[1], sp[3]) for sp in specs)
+            if shape_ref is None:
+                shape_ref = shape
+                for gp, sp in enumerate(specs):            # the programs the library substitutes the parameters into
+                    self._send_spec(ctx, gp, sp)
+                self._prior_key = None                     # (the object's own factors are stale now)
+            elif shape != shape_ref:
+                return None
+            kp.append(np.concatenate([sp[2] for sp in specs]))
+            yr.append(y_raw - self._mean(means))
+            jt.append(np.asarray(jitters, dtype=float))
+            if self._mu is not None:
+                mu, var = self._mu, self._var
+            else:
+                mu, var = self._initMuVar(nodes, weights, jitters)
+            m0.append(np.ravel(mu))
+            v0.append(np.ravel(var))
+        res = ctx.elbocalc_batch(np.array(kp), np.array(yr), np.array(jt), np.array(m0), np.array(v0), max_iter,
+                                 want_state=True)
+        if res is None:
+            return None
+        elbo, iters, conv, info, mu_f, var_f = res
+        self.last_info = int(info[np.flatnonzero(info)[0]]) if np.any(info) else 0
+        done = np.flatnonzero(conv)
+        if done.size:                                      # the warm start of whatever comes next (meanfield.py:644-646)
+            self._mu, self._var = mu_f[done[-1]], var_f[done[-1]]
+        took = 1e3 * (time_module.time() - start)
+        print(f'{len(sets)} ELBO evaluations side by side (took {took:5.2f} ms)' + 20 * ' ', end='\r', flush=True)
+        return [float(-e) for e in elbo]
 
     # ------------------------------------------------------------ gradients
     def grad_ELBO(self, mean_sweeps=8, mean_start=None, total=False):
@@ -861,6 +918,9 @@ class inference:
         every ten steps.  Beyond the reference: keyword arguments go on to ``emcee.EnsembleSampler`` (the
         reference accepts and drops them), so ``pool=sharding.EvalPool()`` spreads the walkers over the
         GPUs of a node; ``backend=`` replaces the HDF file, and without h5py emcee's in-memory backend is used.
+        ``batch=True`` hands emcee a VECTORISED log-probability: the walkers of a half-step are evaluated side by side
+        on the GPU (``nELBO_batch``; problems of N <= 128), each from the same warm-start state instead of from its
+        predecessor's -- the chain is then not the reference's walker for walker, the posterior it samples is.
         """
         assert self._components_set, _NOT_SET
         from emcee import EnsembleSampler, backends
@@ -879,6 +939,19 @@ class inference:
                 return -np.inf, -np.inf
             elbo = -self.nELBO(x, max_iter=100)
             return lp + elbo, elbo
+
+        def logposterior_batch(X):
+            X = np.atleast_2d(X)
+            lp = np.array([logprior(x) for x in X])
+            out = np.full((X.shape[0], 2), -np.inf)
+            ok = np.flatnonzero(~np.isneginf(lp))
+            if ok.size:
+                elbo = -np.array(self.nELBO_batch([X[i] for i in ok], max_iter=100))
+                out[ok, 0] = lp[ok] + elbo
+                out[ok, 1] = elbo
+            return out
+
+        batch = bool(kwargs.pop('batch', False))
 
         ndim = len(names)
         nwalkers = 2 * ndim
@@ -899,7 +972,7 @@ class inference:
                     p0[i] = draw()
         print('initial values for parameters are set')
         start = time_module.time()
-        _ = [logposterior(x) for x in p0]
+        _ = logposterior_batch(p0) if batch else [logposterior(x) for x in p0]
         print()
         print(f'evaluation for initial values took {time_module.time() - start:.0f} sec')
         print('- adjust your expectations accordingly')
@@ -915,7 +988,9 @@ class inference:
                 kwargs['backend'] = be
             except (ImportError, OSError):     # h5py missing or the file is locked: emcee's in-memory backend
                 pass
-        sampler = EnsembleSampler(nwalkers, ndim, logposterior, **kwargs)
+        if batch:
+            kwargs['vectorize'] = True
+        sampler = EnsembleSampler(nwalkers, ndim, logposterior_batch if batch else logposterior, **kwargs)
         old_tau = np.inf
         for sample in sampler.sample(p0, iterations=niter, progress=True):
             if sampler.iteration % 10 == 0:

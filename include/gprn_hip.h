@@ -218,6 +218,21 @@ int gprn_elbocalc(gprn_ctx* ctx, int do_setup, const double* y_resid, const doub
                   const double* var, int max_iter, double* history, int cap, int* n_history, int* iterations,
                   int* converged, double* mu_out, double* var_out);
 
+/* n_eval INDEPENDENT evaluations of the same problem at n_eval parameter vectors -- what scipy's simplex or emcee's
+ * walkers ask inference.nELBO for one after the other (meanfield.py:1095-1111, 1222-1260) -- side by side on the device:
+ * every launch covers all of them, each evaluation with its own covariance matrices, factors, state, loop and stop rule.
+ *   kernel_params [n_eval][n_kernel_params]: the parameters of every latent GP's kernel, concatenated in latent-GP order,
+ *       for the kernel PROGRAMS last given by gprn_set_kernel (same expression trees, other values);
+ *   y_resid [n_eval][p N], jitters [n_eval][p], mu / var [n_eval][d]: per evaluation, as for gprn_elbocalc.
+ * Out per evaluation: the last ELBO of its loop, its trip count, whether the stop rule fired, its info (> 0: a pivot
+ * failed, the ELBO is NaN), and (or both NULL) the state it ended in, [n_eval][d].
+ * One-tile problems (N <= 128) on one rank with device kernels only: GPRN_E_UNSUPPORTED otherwise (the caller evaluates
+ * one by one).  The context's own state and factors are not touched. */
+int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, int n_kernel_params,
+                        const double* y_resid, const double* jitters, const double* mu, const double* var,
+                        int max_iter, double* elbo, int* iterations, int* converged, int* info,
+                        double* mu_out, double* var_out);
+
 /* ---- per-context switches (tests, experiments; nothing in the reference corresponds) ----
  * name: "flags" (1: the factorisation's cross-stream dependencies travel through device-side flags and
  * in-kernel waits, 0: HIP events -- chosen automatically per context, and latched to 0 after an in-kernel

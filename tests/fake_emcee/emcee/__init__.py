@@ -21,15 +21,18 @@ class _State:
 
 
 class EnsembleSampler:
-    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, backend=None, a=2.0, **kwargs):
+    def __init__(self, nwalkers, ndim, log_prob_fn, pool=None, backend=None, a=2.0, vectorize=False, **kwargs):
         self.nwalkers, self.ndim, self.fn, self.a = int(nwalkers), int(ndim), log_prob_fn, float(a)
-        self.pool, self.backend = pool, backend
+        self.pool, self.backend, self.vectorize = pool, backend, bool(vectorize)
         self.iteration = 0
         self._chain, self._lp, self._blobs = [], [], []
 
     def _evaluate(self, points):
-        mapper = self.pool.map if self.pool is not None else map
-        res = list(mapper(self.fn, [np.array(p) for p in points]))
+        if self.vectorize:                       # emcee: the function gets all coordinates at once, one row per walker back
+            res = [tuple(row) for row in np.atleast_2d(self.fn(np.array(points)))]
+        else:
+            mapper = self.pool.map if self.pool is not None else map
+            res = list(mapper(self.fn, [np.array(p) for p in points]))
         lp = np.array([r[0] if isinstance(r, tuple) else r for r in res], dtype=float)
         bl = np.array([r[1] if isinstance(r, tuple) else np.nan for r in res], dtype=float)
         return lp, bl

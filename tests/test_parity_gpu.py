@@ -267,6 +267,55 @@ def test_elbocalc_loop_on_the_device_matches_the_host_loop(max_iter, capsys):
         assert 3 < a[3] < 10000 and not a[5]
 
 
+@pytest.mark.parametrize('n,p,q,kind,B', [(45, 1, 1, 'SE', 5), (60, 2, 2, 'QP', 12), (128, 3, 2, 'QP', 40)])
+def test_nelbo_batch_side_by_side(n, p, q, kind, B):
+    """inference.nELBO_batch on a one-tile problem: B evaluations of ELBOcalc at B parameter vectors in ONE stream of
+    launches (gprn_elbocalc_batch: grid y = evaluation, each with its own matrices, state, loop and stop rule) against
+    the same evaluations one by one from the same starting state -- values, and through them trip counts (a different
+    trip count moves the value by the stop rule's 1e-3)."""
+    t, ys, es = synth.rv_series(n, p)
+    spec = synth.component_spec(p, q, kind)
+
+    def fresh():
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        means = [meanfunc.Constant(0.3 * (i + 1)) for i in range(p)]
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        return g
+
+    g = fresh()
+    x0 = np.array(g.get_parameters(), dtype=float)
+    rng = np.random.RandomState(7)
+    sets = [x0 * (1.0 + 0.05 * rng.standard_normal(x0.size)) + 0.01 * rng.standard_normal(x0.size) * (x0 == 0)
+            for _ in range(B)]
+    # ---- cold: every evaluation from its own _initMuVar state
+    got = np.array(g.nELBO_batch(sets))
+    assert g.last_info == 0
+    gs = fresh()
+    want = []
+    for x in sets:
+        gs.set_parameters(x)
+        want.append(-gs.ELBOcalc()[0])                       # mu = var = 'init'
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # ---- warm: all from one converged state (nELBO's mu = 'previous'); the batch leaves the object's parameters at the
+    # last vector and a converged state behind, as a run of nELBO calls does
+    gs.set_parameters(x0)
+    _, mu_w, var_w, _ = gs.ELBOcalc()
+    g._mu, g._var = mu_w.copy(), var_w.copy()
+    got = np.array(g.nELBO_batch(sets))
+    want = []
+    for x in sets:
+        gs.set_parameters(x)
+        want.append(-gs.ELBOcalc(mu=mu_w, var=var_w)[0])
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    np.testing.assert_allclose(g.get_parameters(), sets[-1])
+    assert g._mu is not None and np.all(np.isfinite(g._mu))
+    # ---- and the one-by-one form of the same call is still there
+    one_by_one = np.array(g.nELBO_batch(sets[:3], batch=False))
+    np.testing.assert_allclose(one_by_one, want[:3], rtol=2e-2)       # (each from its predecessor's state)
+    _assert_default_schedule(g._backend())
+
+
 def test_small_path_reports_a_failed_pivot():
     """jnp.linalg.cholesky semantics on the small path too: a matrix that is not positive definite gives info > 0 (the
     order of the failing minor, LAPACK style) and NaN downstream, no exception (meanfield.py:71-89)."""
@@ -886,6 +935,41 @@ def test_mcmc_matches_reference_chain(monkeypatch, tmp_path):
         np.testing.assert_allclose(sampler.get_blobs(), want['blobs'], rtol=RTOL)       # the ELBO of every walker
         np.testing.assert_allclose(sampler.get_log_prob(), want['log_prob'], rtol=RTOL)
         np.testing.assert_allclose(g.get_parameters(include_frozen=True), want['final_parameters'], rtol=1e-9)
+
+
+def test_mcmc_with_the_walkers_side_by_side(monkeypatch, tmp_path):
+    """inference.mcmc(batch=True): emcee's vectorised log-probability, the walkers of a half-step evaluated side by side
+    (nELBO_batch -> gprn_elbocalc_batch).  Under the deterministic emcee stand-in: the sampler runs, every log-probability
+    and every ELBO blob is finite and the ensemble looks like the one-by-one chain's from the same seed."""
+    monkeypatch.syspath_prepend(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fake_emcee'))
+    monkeypatch.chdir(tmp_path)
+    from scipy import stats
+    n, p, q = 48, 1, 1
+    t, ys, es = synth.rv_series(n, p)
+
+    def fresh():
+        g = gpyrn.inference(q, t, ys[0], es[0])
+        g.set_components(covfunc.SquaredExponential(1.0, 20.0), covfunc.SquaredExponential(1.0, 60.0),
+                         meanfunc.Constant(0.0), 0.5)
+        g.freeze_parameter(name='mean1.c')
+        return g
+
+    priors = {'node1.theta': stats.uniform(0.5, 2.0), 'node1.ell': stats.uniform(10.0, 30.0),
+              'weight1.theta': stats.uniform(0.5, 2.0), 'weight1.ell': stats.uniform(30.0, 60.0),
+              'jitter1': stats.uniform(0.1, 1.0)}
+    chains = {}
+    for batch in (True, False):
+        np.random.seed(11)
+        g = fresh()
+        sampler = g.mcmc(priors, niter=3, batch=batch)
+        chains[batch] = (sampler.get_chain(), sampler.get_log_prob(), sampler.get_blobs())
+        assert np.all(np.isfinite(chains[batch][1]))
+    assert chains[True][0].shape == chains[False][0].shape == (3, 10, 5)
+    # (not the same chain walker for walker: 100 sweeps at most per evaluation, so a value depends on the state its loop
+    # started from -- the shared warm start here, its predecessor's result there -- and one different accept / reject
+    # decision sends the ensembles apart; the populations stay alike)
+    assert np.all(np.isfinite(chains[True][2]))
+    np.testing.assert_allclose(np.median(chains[True][2]), np.median(chains[False][2]), rtol=0.15)
 
 
 def test_kmatrix_and_tiny_nugget_on_device():
