@@ -894,6 +894,7 @@ static int build_tables(gprn_ctx* c)
         TRY(dev_alloc(c, &c->d_ct, vec));
         TRY(dev_alloc(c, &c->d_part, (size_t)want * c->T * 2 * c->ld));
         TRY(dev_alloc(c, &c->d_info, 3 * (size_t)want));
+        HIP_TRY(c, hipMemset(c->d_info, 0, 3 * (size_t)want * sizeof(int)));
         c->nslot = want;
     }
     for (int g : c->loc_nodes) TRY(ensure_gp_storage(c, g));

@@ -165,7 +165,9 @@ struct SmallPhaseArgs {
 template <bool WEIGHTS, int T>
 __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
 {
-    __shared__ __attribute__((aligned(16))) double lds[SMALL_LDS_DOUBLES];
+    // (one tile: the diagonal-block kernel's 46.6 KB only -- with the vectors 59 KB, two workgroups per CU when many
+    // evaluations run side by side)
+    __shared__ __attribute__((aligned(16))) double lds[T == 1 ? DIAG_LDS_DOUBLES : SMALL_LDS_DOUBLES];
     __shared__ double sS[SMALL_MAXLD], sZ[SMALL_MAXLD], sD[SMALL_MAXLD], sU[SMALL_MAXLD];
     __shared__ double shs[4][64], sht[4][64], sh4[4];
     if (a.done && *a.done) return;                   // (uniform)
@@ -521,9 +523,10 @@ __device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
 template <bool WEIGHTS, int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_small_phase(SmallPhaseArgs a) { small_phase_body<WEIGHTS, T>(a); }
-template <bool WEIGHTS, int T>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_small_phase_b(const SmallPhaseArgs* __restrict__ lanes) { small_phase_body<WEIGHTS, T>(lanes[blockIdx.y]); }
+// (one tile, many evaluations: up to two workgroups per CU -- 222 registers per lane fit twice)
+template <bool WEIGHTS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void k_small_phase_b(const SmallPhaseArgs* __restrict__ lanes) { small_phase_body<WEIGHTS, 1>(lanes[blockIdx.y]); }
 
 template <int T>
 __global__ __launch_bounds__(256)
@@ -682,6 +685,7 @@ static int small_batch_ensure(gprn_ctx* c, int n_eval)
     SB_TRY(sb_alloc(c, &m->tail_args, 2 * (size_t)cap));
     SB_TRY(sb_alloc(c, &m->prior_args, (size_t)cap));
     HIP_TRY(c, hipMemset(m->ticket, 0, (size_t)cap * sizeof(unsigned)));
+    HIP_TRY(c, hipMemset(m->info, 0, (size_t)cap * 3 * G * sizeof(int)));      // (the kernels write the entries they use)
     HIP_TRY(c, hipMemset(m->scal, 0, (size_t)cap * nscal * sizeof(double)));
     std::vector<int> ids(G);
     for (int g = 0; g < G; ++g) ids[g] = g;
@@ -828,8 +832,8 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         for (; nb < SB_K && s <= max_iter; ++nb, ++s) {
             const int par = (s <= 1 || (s & 1)) ? 0 : 1;          // sweep 0 and trip 1 start from copy A, then they alternate
             prof_begin(c, GPRN_T_DIAG);
-            hipLaunchKernelGGL((k_small_phase_b<false, 1>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap));
-            hipLaunchKernelGGL((k_small_phase_b<true, 1>), dim3(G - q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 1) * cap));
+            hipLaunchKernelGGL((k_small_phase_b<false>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap));
+            hipLaunchKernelGGL((k_small_phase_b<true>), dim3(G - q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 1) * cap));
             prof_end(c);
             prof_begin(c, GPRN_T_VEC);
             hipLaunchKernelGGL(k_small_tail_b<1>, dim3(G, B), dim3(256), 0, st, (const SmallTailArgs*)(m->tail_args + (size_t)par * cap), s, nb, max_iter);

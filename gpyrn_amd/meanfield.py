@@ -695,33 +695,59 @@ class inference:
             return None
         ctx = self._backend()
         max_iter = 10000 if max_iter is None else int(max_iter)
-        kp, yr, jt, m0, v0 = [], [], [], [], []
-        shape_ref = None
         y_raw = np.concatenate(self.y)
         start = time_module.time()
-        for x in sets:
-            self.set_parameters(x)
-            nodes, weights, means, jitters = self._get_components()
-            specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
-            if any(sp[0] != 'device' for sp in specs):
-                return None
-            shape = tuple((sp[1], sp[3]) for sp in specs)
-            if shape_ref is None:
-                shape_ref = shape
-                for gp, sp in enumerate(specs):            # the programs the library substitutes the parameters into
-                    self._send_spec(ctx, gp, sp)
-                self._prior_key = None                     # (the object's own factors are stale now)
-            elif shape != shape_ref:
-                return None
-            kp.append(np.concatenate([sp[2] for sp in specs]))
-            yr.append(y_raw - self._mean(means))
-            jt.append(np.asarray(jitters, dtype=float))
-            if self._mu is not None:
-                mu, var = self._mu, self._var
-            else:
-                mu, var = self._initMuVar(nodes, weights, jitters)
-            m0.append(np.ravel(mu))
-            v0.append(np.ravel(var))
+        B = len(sets)
+        # the first vector the ordinary way: it tells what the programs are and whether the rest can be laid out in one go
+        self.set_parameters(sets[0])
+        nodes, weights, means, jitters = self._get_components()
+        kernels = list(chain(nodes, weights))
+        specs = [self._kernel_spec(k) for k in kernels]
+        if any(sp[0] != 'device' for sp in specs):
+            return None
+        shape_ref = tuple((sp[1], sp[3]) for sp in specs)
+        for gp, sp in enumerate(specs):                        # the programs the library substitutes the parameters into
+            self._send_spec(ctx, gp, sp)
+        self._prior_key = None                                 # (the object's own factors are stale now)
+        n_k = sum(k.pars.size for k in kernels)
+        plain_kernels = all(sp[2].size == k.pars.size and np.array_equal(sp[2], k.pars) for sp, k in zip(specs, kernels))
+        plain_means = all(m_ is None or type(m_) is meanfunc.Constant for m_ in means)
+        if plain_kernels and plain_means and self._mu is not None:
+            # every program's parameters ARE its kernel's, the means are constants and the start is the stored state:
+            # the B problems are slices of the B full parameter vectors (nodes, weights, means, jitters: meanfield.py:193-202)
+            full = np.tile(self.get_parameters(include_frozen=True), (B, 1))
+            free = ~self.frozen_mask
+            full[:, free] = np.array(sets)
+            kp = full[:, :n_k]
+            n_m = sum(0 if m_ is None else 1 for m_ in means)
+            yr = np.tile(y_raw, (B, 1))
+            col = n_k
+            for i, m_ in enumerate(means):
+                if m_ is not None:
+                    yr[:, i * self.N:(i + 1) * self.N] -= full[:, col:col + 1]
+                    col += 1
+            jt = full[:, n_k + n_m:]
+            m0 = np.tile(np.ravel(self._mu), (B, 1))
+            v0 = np.tile(np.ravel(self._var), (B, 1))
+            self.set_parameters(sets[-1])
+        else:
+            kp, yr, jt, m0, v0 = [], [], [], [], []
+            for i, x in enumerate(sets):
+                if i:
+                    self.set_parameters(x)
+                    nodes, weights, means, jitters = self._get_components()
+                    specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
+                    if any(sp[0] != 'device' for sp in specs) or tuple((sp[1], sp[3]) for sp in specs) != shape_ref:
+                        return None
+                kp.append(np.concatenate([sp[2] for sp in specs]))
+                yr.append(y_raw - self._mean(means))
+                jt.append(np.asarray(jitters, dtype=float))
+                if self._mu is not None:
+                    mu, var = self._mu, self._var
+                else:
+                    mu, var = self._initMuVar(nodes, weights, jitters)
+                m0.append(np.ravel(mu))
+                v0.append(np.ravel(var))
         res = ctx.elbocalc_batch(np.array(kp), np.array(yr), np.array(jt), np.array(m0), np.array(v0), max_iter,
                                  want_state=True)
         if res is None:
