@@ -83,7 +83,7 @@ def pmc_traffic():
     """HBM bytes per bulk-update launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950).  Produced by profiles/summarize_pmc.py; None if absent."""
-    for rnd in ('r03', 'r02'):
+    for rnd in ('r04', 'r03', 'r02'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_bulk_update.json')) as f:
                 return json.load(f)['hbm_bytes_per_launch']
@@ -96,7 +96,7 @@ def pmc_mfma():
     """MFMA-pipe utilisation of the bulk-update launches from the committed rocprofv3 PMC pass
     (SQ_VALU_MFMA_BUSY_CYCLES against 1024 SIMDs x launch time x the clock GRBM_GUI_ACTIVE gives; kernels
     serialised by counter collection; profiles/summarize_r02.py)."""
-    for rnd in ('r03', 'r02'):
+    for rnd in ('r04', 'r03', 'r02'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_mfma_util.json')) as f:
                 d = json.load(f)
@@ -110,11 +110,15 @@ def pmc_mfma():
 
 def k512_union():
     """Union-time figures of the K = 512 launches from the committed kernel trace (profiles/summarize_r02.py union)."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_k512_union.json')) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    for rnd in ('r04', 'r03'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd + '_k512_union.json')) as f:
+                d = json.load(f)
+            d['source'] = 'profiles/%s_k512_union.json' % rnd
+            return d
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def sweep_flops(N, p, q):
@@ -550,7 +554,7 @@ def main():
                 'k512_union': ({'tflops': sum(per_sweep) / (uni['k512_union_us_per_sweep'] * 1e-6) / 1e12,
                                 'union_us_per_sweep': uni['k512_union_us_per_sweep'],
                                 'bulk_ahead_tflops': (per_sweep[0] + per_sweep[1]) / (uni['bulk_ahead_union_us_per_sweep'] * 1e-6) / 1e12,
-                                'source': 'profiles/r03_k512_union.json'} if uni else None),
+                                'source': uni.get('source')} if uni else None),
                 'launches': n_upd, 'avg_launch_ms': (ms_upd / n_upd) if n_upd else None,
                 'flops_per_launch': (fl / n_upd) if n_upd else None,
                 # the look-ahead part of the same updates (own launches, k_tile_gemm<..., TG_AHEAD>: the tiles the
