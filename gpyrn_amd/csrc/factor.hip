@@ -24,6 +24,7 @@
 #include "gprn_internal.h"
 #include "tile_mma.h"
 #include "diag_tile.h"
+#include "chain_helper.h"
 #include "vecops.h"
 
 #include <math.h>
@@ -52,6 +53,55 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
     diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
+}
+
+
+// A whole chain step in ONE launch (chain_helper.h): workgroup (0, slot) is the diagonal block of tile step kblk,
+// publishing its column blocks as they become final; workgroup (1, slot) -- when the grid has one -- is the helper that
+// turns tile (kblk+1, kblk) into L_{k+1,k} and updates tile (kblk+1, kblk+1) beside it.  The diagonal-block workgroups
+// raise `sig` (F_DIAG) among themselves: the panel products of the side stream need X_kk, not the helper.  The helper waits
+// for `wait_flag` (the side stream's update of the step before, which wrote its two tiles) itself.
+// raise_at_start: the flag of the launch BEFORE this one on the stream (L_{k,k-1} of the previous step: its helper's
+// stores are in memory by the time a workgroup of this launch runs).
+template <bool ARGS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_diag_step(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
+                 unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
+                 unsigned* wait_timed_out, unsigned* prog, unsigned base, unsigned* raise_at_start, unsigned raise_value)
+{
+    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    static_assert(HX_DOUBLES <= DIAG_LDS_DOUBLES, "the helper's exchange buffers live in the diagonal block's LDS");
+    if (raise_at_start && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        __hip_atomic_store(raise_at_start, raise_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int slot = blockIdx.y;
+    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
+    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
+    const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
+    if (blockIdx.x == 0) {
+        if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[0] = pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
+        diag_tile_pub(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE, DiagPub{prog + slot, base});
+        if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
+        if (!sig_slot) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (sig_value) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (atomicAdd(sig_slot, 1u) + 1 == gridDim.y) {
+                atomicExch(sig_slot, 0u);
+                if (sig_value) __hip_atomic_store(sig_slot + 1, sig_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    await_flag(wait_flag, wait_value, wait_timed_out);
+    const size_t below = off + (size_t)GPRN_TILE * ld;
+    if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[3] = __builtin_amdgcn_s_memrealtime();
+    chain_helper(lds, (gcptr_t)(Bm + off), (gcptr_t)(Xm + off), (gptr_t)(Bm + below), (gptr_t)(Bm + below + GPRN_TILE), ld,
+                 prog + slot, base, wait_timed_out);
+    if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[5] = __builtin_amdgcn_s_memrealtime();
 }
 
 
@@ -113,6 +163,13 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     size_t dyn = 0;
     if (nbatch * c->T <= GPRN_LAT_MAX)
         dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
+    else {
+        static int dyn_kb = -1;                    // experiment: GPRN_DIAG_DYN_KB / GPRN_DIAG_DYN_KB2 (batches <= 2 / above)
+        static int dyn_kb2 = -1;
+        if (dyn_kb < 0) { const char* e = getenv("GPRN_DIAG_DYN_KB"); dyn_kb = e ? atoi(e) : 0; }
+        if (dyn_kb2 < 0) { const char* e = getenv("GPRN_DIAG_DYN_KB2"); dyn_kb2 = e ? atoi(e) : 0; }
+        dyn = (size_t)(nbatch <= 2 ? dyn_kb : dyn_kb2) * 1024;
+    }
     pa.stamps = step_stamp_ptr(c, kblk, 0);
     if (tab_rows(c, d_ptrs, nbatch, &pa))
         hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
@@ -120,6 +177,41 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     else
         hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
                            d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+    prof_end(c);
+    HIP_TRY(c, hipGetLastError());
+    return GPRN_OK;
+}
+
+// ... and with the step's two products beside it (k_diag_step); helper = false: the diagonal block alone (last tile step)
+int launch_diag_step(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
+                     Signal sig, Await helper_wait, bool helper, unsigned* raise_at_start, unsigned raise_value)
+{
+    if (!stream) stream = c->stream;
+    if (nbatch > c->prog_cap) {
+        if (c->d_prog) hipFree(c->d_prog);
+        c->d_prog = nullptr;
+        const int cap = std::max(64, nbatch);
+        HIP_TRY(c, hipMalloc(&c->d_prog, (size_t)cap * sizeof(unsigned)));
+        HIP_TRY(c, hipMemset(c->d_prog, 0, (size_t)cap * sizeof(unsigned)));
+        c->prog_cap = cap;
+        c->prog_seq = 0;
+    }
+    c->prog_seq += 16;                             // (phase counts base + 1 .. base + 8; compared as differences: may wrap)
+    prof_begin(c, GPRN_T_DIAG, stream);
+    PtrArgs pa;
+    size_t dyn = 0;                                // (see launch_diag)
+    if (nbatch * c->T <= GPRN_LAT_MAX)
+        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
+    pa.stamps = step_stamp_ptr(c, kblk, 0);
+    const dim3 grid(helper ? 2 : 1, nbatch);
+    if (tab_rows(c, d_ptrs, nbatch, &pa))
+        hipLaunchKernelGGL(k_diag_step<true>, grid, dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info,
+                           sig.slot, sig.value, helper_wait.flag, helper_wait.value, helper_wait.timed_out, c->d_prog, c->prog_seq,
+                           raise_at_start, raise_value);
+    else
+        hipLaunchKernelGGL(k_diag_step<false>, grid, dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info,
+                           sig.slot, sig.value, helper_wait.flag, helper_wait.value, helper_wait.timed_out, c->d_prog, c->prog_seq,
+                           raise_at_start, raise_value);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -462,6 +554,10 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     bool tail_on_s2 = false;                       // rows_final ran on the bulk stream: joined at the end
     // "rest" as two launches with "next" on a stream of its own, beside the previous panel's whole "rest": +2.1 % sweeps/s
     // at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to 64 tile steps
+    // the chain step as one launch (k_diag_step) up to this many matrices
+    static int fuse_env = -2;
+    if (fuse_env == -2) { const char* e = getenv("GPRN_FUSE_MAX"); fuse_env = e ? atoi(e) : -1; }
+    const bool fused = nbatch <= (c->fuse_opt >= 0 ? c->fuse_opt : (fuse_env >= 0 ? fuse_env : GPRN_FUSE_MAX_BATCH));
     const bool sr = c->stream4 && c->T <= 64;
     hipStream_t sn = sr ? c->stream4 : s2;
 
@@ -597,8 +693,20 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             const gprn_ctx::StepRange& s = c->steps[set][k];
             if (pending_outer >= 0 && s.npanel_l == 0 && (rc = do_outer(pending_outer))) return rc;
             // ---- the chain
+            // fused: the step's diagonal block, L_{k+1,k} and the update of B_{k+1,k+1} are ONE launch (k_diag_step); the
+            // helper workgroups wait for stream3's update of the step before themselves, and L_{k+1,k}'s flag goes up with
+            // the first workgroup of the NEXT step's launch
+            if (fused) {
+                const bool helper = s.npanel_l > 0;
+                if (!use_flags && k > 0 && helper) HIP_TRY(c, await(s0, k - 1, F_INNER));
+                if ((rc = launch_diag_step(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG),
+                                           (use_flags && k > 0 && helper) ? in_kernel_wait(k - 1, F_INNER) : noaw, helper,
+                                           (use_flags && k > 0) ? slot(k - 1, F_MINIL) + 1 : (unsigned*)nullptr, epoch))) return rc;
+                if (!use_flags) { HIP_TRY(c, raise(s0, k, F_DIAG)); if (helper) HIP_TRY(c, raise(s0, k, F_MINIL)); }
+            } else {
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
+            }
             if (use_flags && k == 0 && c->chain_started) {
                 // work handed over by the caller for the bulk stream (run_phase: the previous phase's X^T X
                 // product, 528 long-running workgroups) goes behind the FIRST diagonal block: launched before
@@ -626,6 +734,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // bounds the phase) its 8 workgroups per matrix poll that flag themselves; with more, the phase is bound by
             // the tile kernels' throughput and 8 x batch resident 512-thread workgroups that only poll keep bulk
             // workgroups off their CUs: a one-wave kernel waits instead (+0.8 % at config 3, +2 % at config 4)
+            if (!fused) {
             const bool spin = use_flags && k > 0 && nbatch <= 2;
             if (use_flags && k > 0 && !spin && (rc = flag_sync(s0, nullptr, slot(k - 1, F_INNER) + 1))) return rc;
             if (k > 0 && !use_flags) HIP_TRY(c, await(s0, k - 1, F_INNER));
@@ -636,6 +745,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // instead of at the end of its own -- 1.7 us less between the two at every tile step)
             if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, s0, nosig, noaw,
                                        use_flags ? slot(k, F_MINIL) + 1 : (unsigned*)nullptr, epoch))) return rc;
+            }
             // The outer update of the previous panel is ENQUEUED here, behind the chain's three launches of this panel's
             // first step: its dozen stream operations and launches take the host 60-100 us, during which the chain stream
             // ran dry at every panel boundary (profiles/r02_chain_timeline_cfg3.txt)
@@ -756,9 +866,12 @@ int factor_check_waits(gprn_ctx* c)
                         }
                         fprintf(stderr, "\n");
                     }
+                    else if (l[0] && l[2])           // fused step: ... | helper: start after the diagonal block's start, end after its end
+                        fprintf(stderr, "  %3d | %6.1f %6.1f | helper %6.1f %6.1f | %7.1f\n", k, us(prev_end, d[0]), us(d[0], d[2]), us(d[0], l[0]),
+                                us(d[2], l[2]), us(prev_end, l[2] > d[2] ? l[2] : d[2]));
                     else
                         fprintf(stderr, "  %3d | %6.1f %6.1f |\n", k, us(prev_end, d[0]), us(d[0], d[2]));
-                    prev_end = u[0] ? u[2] : d[2];
+                    prev_end = u[0] ? u[2] : ((l[0] && l[2] > d[2]) ? l[2] : d[2]);
                 }
             }
         }
