@@ -205,7 +205,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
-    else if (!strcmp(name, "fuse_chain")) field = &c->fuse_opt;
+    else if (!strcmp(name, "pub_panel")) field = &c->pub_opt;
     else if (!strcmp(name, "small_path")) field = &c->small_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;

@@ -59,12 +59,12 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
     return __hiloint2double(hi, lo);
 }
 
-// ---- publication (round 4): a helper workgroup on ANOTHER CU consumes the tile's results while this kernel still runs
-// (chain_helper.h: L_{k+1,k} by substitution against L_kk's column blocks, and the B_{k+1,k+1} update).  With a DiagPub
-// the stores it reads -- the 16 x 16 diagonal blocks of X and L's column blocks -- go out at AGENT scope (sc1: written
-// through the XCD's L2, which is not coherent with the other XCDs' L2s), every wave has them acknowledged before the
-// barrier at a phase's end, and one lane then stores the phase count: flag base + j + 1 = "column block j of L and
-// X_jj are in memory".  No fence anywhere on the pivot chain.
+// ---- publication (round 4): workgroups on OTHER CUs consume the tile's results while this kernel still runs
+// (pub_helpers.h: the tile step's panel by substitution against L_kk's column blocks / by products with X_kk's row
+// blocks).  With a DiagPub every store of L and X goes out at AGENT scope (sc1: written through the XCD's L2, which is
+// not coherent with the other XCDs' L2s), every wave has its stores acknowledged before the barrier at a phase's end,
+// and one lane then stores the phase count: flag base + j + 1 = "column block j of L, X_jj and row block j of X are
+// in memory".  No fence anywhere on the pivot chain.
 struct DiagPub { unsigned* prog; unsigned base; };
 template <bool PUB>
 __device__ __forceinline__ void st_pub(gptr_t p, double v)
@@ -336,7 +336,7 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int r = fk + 4 * t;
-                Xt[(size_t)(16 * kb + r) * ld + 16 * P + fr] = L.PB[(16 * P + fr) * PP + r];
+                st_pub<PUB>(Xt + (size_t)(16 * kb + r) * ld + 16 * P + fr, L.PB[(16 * P + fr) * PP + r]);
                 Xt[(size_t)(16 * P + r) * ld + 16 * kb + fr] = 0.0;
             }
         }

@@ -16,7 +16,6 @@
 #define GPRN_NBUF 4            // per-GP buffer slots addressable by a tile task
 #define GPRN_OUTER 4           // tiles per outer panel: bulk updates contract over 4*128 = 512
 #define GPRN_OUTER_SMALL 16    // ... when batch x tiles <= 32 (latency-bound: measured +11 % at N=2048, batch 1)
-#define GPRN_FUSE_MAX_BATCH 16 // matrices up to which a chain step (diag, L_{k+1,k}, its update) is ONE launch (factor.hip k_diag_step)
 #define GPRN_LAT_MAX 32        // batch x tiles up to which a factorisation runs on the latency set of task lists
 #define GPRN_FEW_TASKS 4000    // tasks x batch above which a tile launch uses 128 x 128 workgroups (100 ... 8000 swept)
 #define GPRN_XCD_CHUNK_LOG2 4  // consecutive task-list entries that meet in one XCD's L2 (k_tile_gemm): 16
@@ -175,10 +174,10 @@ struct gprn_ctx {
     size_t test_cap[3] = {0, 0, 0};
     // tile-task lists for the factorisation at the current T (device)
     TileTask* d_tasks = nullptr;
-    unsigned* d_prog = nullptr;      // k_diag_step: per-slot phase counters the helper workgroups poll (sequence numbers)
+    unsigned* d_prog = nullptr;      // k_diag_pub: per-slot phase counters the panel workgroups follow (sequence numbers)
     int prog_cap = 0;
     unsigned prog_seq = 0;
-    int fuse_opt = -1;               // gprn_set_option "fuse_chain": matrices up to which a chain step is one launch; -1: default
+    int pub_opt = -1;                // gprn_set_option "pub_panel": 0 = panel launches wait for the whole diagonal block; -1: default (on)
     unsigned* d_sig = nullptr;       // completion signals of the chain: (tile step, kind) -> {counter, flag}
     int sig_T = 0;
     unsigned epoch = 0;              // value the flags take in the current factor_invert call
@@ -309,8 +308,9 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
                 Await aw = Await{nullptr, 0, nullptr});
-int launch_diag_step(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
-                     Signal sig, Await helper_wait, bool helper, unsigned* raise_at_start, unsigned raise_value);
+int launch_diag_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream, Signal sig);
+int launch_panel_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int n_l, int n_x, hipStream_t stream, Signal sig,
+                     unsigned* timed_out, unsigned* raise_at_start, unsigned raise_value, unsigned* raise_at_start2);
 
 #ifdef __HIPCC__
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
