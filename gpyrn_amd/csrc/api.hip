@@ -205,7 +205,6 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
-    else if (!strcmp(name, "pub_panel")) field = &c->pub_opt;
     else if (!strcmp(name, "small_path")) field = &c->small_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
@@ -372,7 +371,6 @@ extern "C" void gprn_destroy(gprn_ctx* c)
         free_problem(c);
         dev_free(c->d_tasks);
         if (c->d_sig) hipFree(c->d_sig);
-        if (c->d_prog) hipFree(c->d_prog);
         if (c->d_step_stamps) hipFree(c->d_step_stamps);
         if (c->d_side_stamps) hipFree(c->d_side_stamps);
         dev_free(c->d_agree);

@@ -59,20 +59,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
     return __hiloint2double(hi, lo);
 }
 
-// ---- publication (round 4): workgroups on OTHER CUs consume the tile's results while this kernel still runs
-// (pub_helpers.h: the tile step's panel by substitution against L_kk's column blocks / by products with X_kk's row
-// blocks).  With a DiagPub every store of L and X goes out at AGENT scope (sc1: written through the XCD's L2, which is
-// not coherent with the other XCDs' L2s), every wave has its stores acknowledged before the barrier at a phase's end,
-// and one lane then stores the phase count: flag base + j + 1 = "column block j of L, X_jj and row block j of X are
-// in memory".  No fence anywhere on the pivot chain.
-struct DiagPub { unsigned* prog; unsigned base; };
-template <bool PUB>
-__device__ __forceinline__ void st_pub(gptr_t p, double v)
-{
-    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
 // potf2 + trtri2 of a 16x16 block, the block in ONE MFMA accumulator (C layout: lane (fr = l&15, fk = l>>4), register
 // t holds S[fk + 4t][fr]; lower = B then L, strict upper = transposed right-hand side as in S), four pivots per round:
 //   1. the round's four columns go to LDS, [row][n] (the block's own rows as identity rows);
@@ -95,7 +81,6 @@ __device__ long long b16_stamps[4][8];
 #define B16_STAMP(R, i, dep) do {} while (0)
 #endif
 // c: the block in C layout (what lies above the diagonal is ignored); L -> St (lower), X -> xd and Xg
-template <bool PUB = false>
 __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pitch PP */,
                                             double* __restrict__ xd, gptr_t Xg, int ld,
                                             int* info, int slot, int pivot0,
@@ -167,7 +152,7 @@ __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pi
         if (below) St[fr * PP + k0 + fk] = w;
         const double xv = below ? 0.0 : w;
         xd[(k0 + fk) * PP + fr] = xv;
-        st_pub<PUB>(Xg + (size_t)(k0 + fk) * ld + fr, xv);
+        Xg[(size_t)(k0 + fk) * ld + fr] = xv;
         if (l == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -252,16 +237,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// ... and with this wave's global stores acknowledged first (all of them / all but the latest four)
-__device__ __forceinline__ void lds_barrier_stores_done()
-{
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-__device__ __forceinline__ void lds_barrier_stores_but4()
-{
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // MFMA operand of a 16-row block held [row][k] in LDS (pitch PP): lane (fr, fk) takes k = 4 fk .. 4 fk + 3 of row fr
 // (element s goes into the s-th of the four K = 4 products; A and B use the same assignment)
 struct Op16 { double v[4]; };
@@ -284,8 +259,8 @@ __device__ __forceinline__ Op16 op16_t(const double* __restrict__ T)
 // one phase of a compute wave; KB and the wave's rows are compile-time constants, so every acc[][] index is one too
 // (as a loop over kb the body stayed rolled once -- the unroll pragma is a hint -- and the accumulators went to
 // scratch memory: 150 us per block instead of 23)
-template <int W, int kb, bool PUB>
-__device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const DiagPub& pub)
+template <int W, int kb>
+__device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld)
 {
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -330,13 +305,13 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = 16 * P + fk + 4 * t, col = 16 * kb + fr;
-                if (P > kb || col <= row) st_pub<PUB>(Bt + (size_t)row * ld + col, acc[pp][kb][t]);
+                if (P > kb || col <= row) Bt[(size_t)row * ld + col] = acc[pp][kb][t];
             }
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int r = fk + 4 * t;
-                st_pub<PUB>(Xt + (size_t)(16 * kb + r) * ld + 16 * P + fr, L.PB[(16 * P + fr) * PP + r]);
+                Xt[(size_t)(16 * kb + r) * ld + 16 * P + fr] = L.PB[(16 * P + fr) * PP + r];
                 Xt[(size_t)(16 * P + r) * ld + 16 * kb + fr] = 0.0;
             }
         }
@@ -388,10 +363,6 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
         }
     }
     DG_STAMP(kb, 3);
-    if (PUB) {
-        lds_barrier_stores_done();                     // E, column kb acknowledged
-        if (W == 0 && lane == 0) __hip_atomic_store(pub.prog, pub.base + kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else
     lds_barrier();                                     // E
     DG_STAMP(kb, 4);
 }
@@ -402,8 +373,8 @@ struct DiagFromTile {
     __device__ __forceinline__ double operator()(int row, int col) const { return Bt[(size_t)row * ld + col]; }
 };
 
-template <int W, bool PUB, class LOAD>
-__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, const DiagPub& pub)
+template <int W, class LOAD>
+__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load)
 {
     // this wave's sub-tile rows (-1 = none): equal update counts
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
@@ -436,13 +407,13 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     lds_barrier();                                  // (the pivot wave factored sub-tile 0 in between)
     DG_STAMP(NSB, 3);
 
-    diag_phase<W, 0, PUB>(acc, L, Bt, Xt, ld, pub); diag_phase<W, 1, PUB>(acc, L, Bt, Xt, ld, pub);
-    diag_phase<W, 2, PUB>(acc, L, Bt, Xt, ld, pub); diag_phase<W, 3, PUB>(acc, L, Bt, Xt, ld, pub);
-    diag_phase<W, 4, PUB>(acc, L, Bt, Xt, ld, pub); diag_phase<W, 5, PUB>(acc, L, Bt, Xt, ld, pub);
-    diag_phase<W, 6, PUB>(acc, L, Bt, Xt, ld, pub); diag_phase<W, 7, PUB>(acc, L, Bt, Xt, ld, pub);
+    diag_phase<W, 0>(acc, L, Bt, Xt, ld); diag_phase<W, 1>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 2>(acc, L, Bt, Xt, ld); diag_phase<W, 3>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 4>(acc, L, Bt, Xt, ld); diag_phase<W, 5>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
-template <bool PUB, class LOAD>
+template <class LOAD>
 __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int* __restrict__ info, int slot,
                                            int pivot0)
 {
@@ -453,7 +424,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 #pragma unroll
         for (int t = 0; t < 4; ++t) c0[t] = load(fk + 4 * t, fr);
         DG_STAMP(NSB, 1);
-        base16_regs<PUB>(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
+        base16_regs(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
     }
     DG_STAMP(NSB, 2);
     lds_barrier();
@@ -482,13 +453,9 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
         lds_barrier();                                     // M
         DG_STAMP(kb, 2);
         if (kb < NSB - 1)                                  // ... then factor it, straight from the registers
-            base16_regs<PUB>(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
-                             info, slot, pivot0 + 16 * n, L.LINE);
+            base16_regs(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
+                        info, slot, pivot0 + 16 * n, L.LINE);
         DG_STAMP(kb, 3);
-        // E.  Publishing: X_kb (stored a phase ago by base16(kb)) must be acknowledged -- everything but the four stores
-        // of the base16(kb + 1) that has just run; the last phase stores nothing and waits for all
-        if (PUB) { if (kb < NSB - 1) lds_barrier_stores_but4(); else lds_barrier_stores_done(); }
-        else
         lds_barrier();                                     // E
         DG_STAMP(kb, 4);
     }
@@ -496,23 +463,16 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 
 // potrf + inverse of a 128x128 tile whose entries `load(row, col)` supplies: L (lower) -> Bt, X = L^-1 -> Xt;
 // `lds`: DIAG_LDS_DOUBLES doubles.  All 256 threads of the workgroup call it.
-template <bool PUB = false, class LOAD>
+template <class LOAD>
 __device__ __forceinline__ void diag_tile_from(double* __restrict__ lds, const LOAD& load, gptr_t Bt, gptr_t Xt, int ld,
-                                               int* __restrict__ info, int slot, int pivot0, DiagPub pub = DiagPub{nullptr, 0u})
+                                               int* __restrict__ info, int slot, int pivot0)
 {
     const DiagLds L(lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) diag_compute<0, PUB>(L, Bt, Xt, ld, load, pub);
-    else if (wave == 1) diag_compute<1, PUB>(L, Bt, Xt, ld, load, pub);
-    else if (wave == 2) diag_compute<2, PUB>(L, Bt, Xt, ld, load, pub);
-    else diag_pivot<PUB>(L, Bt, Xt, ld, load, info, slot, pivot0);
-}
-
-// ... of the tile at Bt itself, published phase by phase (see DiagPub)
-__device__ __forceinline__ void diag_tile_pub(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
-                                              int* __restrict__ info, int slot, int pivot0, DiagPub pub)
-{
-    diag_tile_from<true>(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0, pub);
+    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load);
+    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load);
+    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load);
+    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0);
 }
 
 // ... of the tile at Bt itself

@@ -24,7 +24,6 @@
 #include "gprn_internal.h"
 #include "tile_mma.h"
 #include "diag_tile.h"
-#include "pub_helpers.h"
 #include "vecops.h"
 
 #include <math.h>
@@ -53,57 +52,6 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
     diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
-}
-
-
-// The diagonal block of tile step kblk, PUBLISHING its results phase by phase (diag_tile.h DiagPub) for the panel
-// workgroups of k_panel_pub, which the side stream has launched beside it.
-// raise_at_start: a flag of the launch BEFORE this one on the stream, raised by the first workgroup (what that launch
-// wrote is in memory by the time a workgroup of this one runs).
-template <bool ARGS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_diag_pub(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
-                unsigned* sig_slot, unsigned sig_value, unsigned* prog, unsigned base)
-{
-    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
-    const int slot = blockIdx.x;
-    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
-    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
-    const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-    if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[0] = pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
-    diag_tile_pub(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE, DiagPub{prog + slot, base});
-    if (pa.stamps && slot == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-    signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
-}
-
-// A tile step's panel beside its diagonal block (pub_helpers.h): workgroup (x, slot), x < n_l, turns tile (kblk + 2 + x,
-// kblk) of B into L_ik = B_ik L_kk^-T; the others turn tile (kblk, x - n_l) of X (the running right-hand side) into
-// X_kc = X_kk R_kc.  Each loads its tile first and then follows the phase counter of its matrix' diagonal block.
-// The flags of the launches before this one on the side stream go up with the first workgroup (as in k_tile_panel with
-// the synchronisation folded in); sig / then_wait as there: the last workgroup holds the launch open until L_{k+1,k} is
-// in memory, so that the in-panel updates behind it need no wait of their own.
-template <bool ARGS>
-__global__ __launch_bounds__(256)
-void k_panel_pub(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int n_l, const unsigned* prog, unsigned base,
-                 unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value, unsigned* timed_out,
-                 unsigned* start_flag, unsigned start_value, unsigned* start_flag2)
-{
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        if (start_flag) __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (start_flag2) __hip_atomic_store(start_flag2, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    const int slot = blockIdx.y;
-    double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
-    double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
-    const size_t kk = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-    if ((int)blockIdx.x < n_l) {
-        const size_t ik = ((size_t)(kblk + 2 + blockIdx.x) * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
-        trsm_tile((gcptr_t)(Bm + kk), (gcptr_t)(Xm + kk), (gptr_t)(Bm + ik), ld, prog + slot, base, timed_out);
-    } else {
-        const size_t kc = ((size_t)kblk * GPRN_TILE) * ld + (size_t)((int)blockIdx.x - n_l) * GPRN_TILE;
-        xmul_tile((gcptr_t)(Xm + kk), (gptr_t)(Xm + kc), ld, prog + slot, base, timed_out);
-    }
-    signal_done(sig_slot, sig_value, then_wait, then_value, timed_out);
 }
 
 
@@ -172,59 +120,6 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     else
         hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
                            d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
-}
-
-// ... publishing its results phase by phase for the panel workgroups launched beside it (k_diag_pub / k_panel_pub)
-int launch_diag_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream, Signal sig)
-{
-    if (!stream) stream = c->stream;
-    if (nbatch > c->prog_cap) {
-        if (c->d_prog) hipFree(c->d_prog);
-        c->d_prog = nullptr;
-        const int cap = std::max(64, nbatch);
-        HIP_TRY(c, hipMalloc(&c->d_prog, (size_t)cap * sizeof(unsigned)));
-        HIP_TRY(c, hipMemset(c->d_prog, 0, (size_t)cap * sizeof(unsigned)));
-        c->prog_cap = cap;
-        c->prog_seq = 0;
-    }
-    c->prog_seq += 16;                             // (phase counts base + 1 .. base + 8; compared as differences: may wrap)
-    prof_begin(c, GPRN_T_DIAG, stream);
-    PtrArgs pa;
-    size_t dyn = 0;                                // (see launch_diag)
-    if (nbatch * c->T <= GPRN_LAT_MAX)
-        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
-    pa.stamps = step_stamp_ptr(c, kblk, 0);
-    if (tab_rows(c, d_ptrs, nbatch, &pa))
-        hipLaunchKernelGGL(k_diag_pub<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info,
-                           sig.slot, sig.value, c->d_prog, c->prog_seq);
-    else
-        hipLaunchKernelGGL(k_diag_pub<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, d_info,
-                           sig.slot, sig.value, c->d_prog, c->prog_seq);
-    prof_end(c);
-    HIP_TRY(c, hipGetLastError());
-    return GPRN_OK;
-}
-
-// the panel of tile step kblk beside the diagonal block that launch_diag_pub has just enqueued (same phase counters):
-// n_l tiles below the sub-diagonal one, n_x tiles of row kblk of the inverse
-int launch_panel_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int n_l, int n_x, hipStream_t stream, Signal sig,
-                     unsigned* timed_out, unsigned* raise_at_start, unsigned raise_value, unsigned* raise_at_start2)
-{
-    prof_begin(c, GPRN_T_PANEL, stream);
-    PtrArgs pa;
-    pa.stamps = nullptr;
-    const dim3 grid((unsigned)(n_l + n_x), (unsigned)nbatch);
-    if (tab_rows(c, d_ptrs, nbatch, &pa))
-        hipLaunchKernelGGL(k_panel_pub<true>, grid, dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk, n_l,
-                           (const unsigned*)c->d_prog, c->prog_seq, sig.slot, sig.value, sig.then_wait, sig.then_value, timed_out,
-                           raise_at_start, raise_value, raise_at_start2);
-    else
-        hipLaunchKernelGGL(k_panel_pub<false>, grid, dim3(256), 0, stream, (double* const*)d_ptrs, pa, ld, kblk, n_l,
-                           (const unsigned*)c->d_prog, c->prog_seq, sig.slot, sig.value, sig.then_wait, sig.then_value, timed_out,
-                           raise_at_start, raise_value, raise_at_start2);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -567,11 +462,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     bool tail_on_s2 = false;                       // rows_final ran on the bulk stream: joined at the end
     // "rest" as two launches with "next" on a stream of its own, beside the previous panel's whole "rest": +2.1 % sweeps/s
     // at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to 64 tile steps
-    // the panel launches of stream3 beside the diagonal blocks, following them phase by phase (k_panel_pub): wherever that
-    // launch polls in-kernel anyway (folds_sync: one or two matrices, few enough workgroups)
-    static int pub_env = -2;
-    if (pub_env == -2) { const char* e = getenv("GPRN_PUB_PANEL"); pub_env = e ? atoi(e) : -1; }
-    const bool pub_panel = use_flags && (c->pub_opt >= 0 ? c->pub_opt : (pub_env >= 0 ? pub_env : 1)) != 0;
     const bool sr = c->stream4 && c->T <= 64;
     hipStream_t sn = sr ? c->stream4 : s2;
 
@@ -707,13 +597,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             const gprn_ctx::StepRange& s = c->steps[set][k];
             if (pending_outer >= 0 && s.npanel_l == 0 && (rc = do_outer(pending_outer))) return rc;
             // ---- the chain
-            // pub: stream3's panel launch of this step follows the diagonal block phase by phase (k_panel_pub) instead of
-            // starting when it is done; the block then publishes its column blocks as they become final
-            // (not at the first step: its tiles come from the caller on the chain stream -- k_build_B --, and the panel
-            // workgroups load theirs as soon as they start; from then on every producer of a panel tile sits on stream3)
-            const bool pub = pub_panel && k > 0 && s.npanel_l > 0 && s.npanel > 1 && folds_sync(k);
-            if (pub) { if ((rc = launch_diag_pub(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG)))) return rc; }
-            else if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), noaw))) return rc;
+            if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             if (use_flags && k == 0 && c->chain_started) {
                 // work handed over by the caller for the bulk stream (run_phase: the previous phase's X^T X
@@ -774,10 +658,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
                     pending_up = nullptr;
                     aw_d = in_kernel_wait(k, F_DIAG);
                 }
-                if (pub) {
-                    if ((rc = launch_panel_pub(c, c->d_ptrs, nbatch, c->ld, k, (int)s.npanel_l - 1, (int)(s.npanel - s.npanel_l), s1,
-                                               x_part_then(k), timed_out, up, epoch, up2))) return rc;
-                } else
                 if ((rc = launch_panel(c, c->d_tasks + s.panel0 + 1, s.npanel_l - 1, s.npanel - s.npanel_l, c->d_ptrs,
                                        nbatch, c->ld, s1, x_part_then(k), aw_d, up, epoch, up2))) return rc;
             } else {
@@ -876,12 +756,9 @@ int factor_check_waits(gprn_ctx* c)
                         }
                         fprintf(stderr, "\n");
                     }
-                    else if (l[0] && l[2])           // fused step: ... | helper: start after the diagonal block's start, end after its end
-                        fprintf(stderr, "  %3d | %6.1f %6.1f | helper %6.1f %6.1f | %7.1f\n", k, us(prev_end, d[0]), us(d[0], d[2]), us(d[0], l[0]),
-                                us(d[2], l[2]), us(prev_end, l[2] > d[2] ? l[2] : d[2]));
                     else
                         fprintf(stderr, "  %3d | %6.1f %6.1f |\n", k, us(prev_end, d[0]), us(d[0], d[2]));
-                    prev_end = u[0] ? u[2] : ((l[0] && l[2] > d[2]) ? l[2] : d[2]);
+                    prev_end = u[0] ? u[2] : d[2];
                 }
             }
         }

@@ -174,10 +174,6 @@ struct gprn_ctx {
     size_t test_cap[3] = {0, 0, 0};
     // tile-task lists for the factorisation at the current T (device)
     TileTask* d_tasks = nullptr;
-    unsigned* d_prog = nullptr;      // k_diag_pub: per-slot phase counters the panel workgroups follow (sequence numbers)
-    int prog_cap = 0;
-    unsigned prog_seq = 0;
-    int pub_opt = -1;                // gprn_set_option "pub_panel": 0 = panel launches wait for the whole diagonal block; -1: default (on)
     unsigned* d_sig = nullptr;       // completion signals of the chain: (tile step, kind) -> {counter, flag}
     int sig_T = 0;
     unsigned epoch = 0;              // value the flags take in the current factor_invert call
@@ -308,9 +304,6 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
                 Await aw = Await{nullptr, 0, nullptr});
-int launch_diag_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream, Signal sig);
-int launch_panel_pub(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int n_l, int n_x, hipStream_t stream, Signal sig,
-                     unsigned* timed_out, unsigned* raise_at_start, unsigned raise_value, unsigned* raise_at_start2);
 
 #ifdef __HIPCC__
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
