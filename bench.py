@@ -305,6 +305,32 @@ def latency(a):
             'cpu_baseline': cpu}), flush=True)
 
 
+def golden_check(ctx, a, N, p, q, t, ys):
+    """The reference's own numbers for THIS workload, where tests/golden holds them (configs 1-4: forced sweeps from the
+    initial state, recorded from /root/reference by oracle/gen_golden.py): the first sweeps of the bench's context against
+    them, uncommitted, before the timed region.  `elbo_last` further down is the state after hundreds of sweeps and says
+    nothing by itself (at q >= 3 the reference's own iteration diverges: DESIGN.md 3); this does."""
+    tag = {1: 'cfg1_N200', 2: 'cfg2_N2048', 3: 'cfg3_N4096', 4: 'cfg4_N4096_q4'}.get(a.config)
+    path = os.path.join(ROOT, 'tests', 'golden', '%s.npz' % tag) if tag and not a.shape else None
+    if not path or not os.path.exists(path):
+        return None
+    d = np.load(path)
+    with open(path[:-4] + '.json') as f:
+        meta = json.load(f)
+    spec = synth.component_spec(p, q, synth.CONFIGS[a.config][3])
+    flat = lambda items: [[name, [float(x) for x in pars]] for name, pars in items]
+    same_model = all(flat(x) == flat(meta[k]) for x, k in zip(spec[:3], ('nodes', 'weights', 'means'))) and \
+        [float(j) for j in spec[3]] == [float(j) for j in meta['jitters']]
+    if not (same_model and np.array_equal(d['time'], t) and np.array_equal(d['y'], np.array(ys))):
+        return {'fixture': 'tests/golden/%s.npz' % tag, 'same_inputs': False}
+    ref = np.asarray(d['elbo_sweeps'], dtype=float)
+    elbo, parts, info = ctx.sweep(len(ref), commit=False)
+    return {'fixture': 'tests/golden/%s.npz' % tag, 'same_inputs': True, 'sweeps': int(len(ref)), 'info': int(info),
+            'elbo_rel_err': float(np.max(np.abs(elbo - ref) / np.abs(ref))),
+            'parts_rel_err': float(np.max(np.abs(parts - d['parts_sweeps']) / np.abs(d['parts_sweeps']))),
+            'bound': 1e-8}
+
+
 def self_launch(a):
     """--gpus N > 1 without a launcher: N child processes, one per rank, started BEFORE this
     process makes any HIP call (a process that has initialised the GPU must not exec or fork
@@ -472,6 +498,7 @@ def main():
     g.set_components(nodes, weights, means, jit)
     ctx = g._setup_device(nodes, weights, means, jit)
     ctx.set_muvar(mu0, var0)
+    golden = golden_check(ctx, a, N, p, q, t, ys) if world == 1 else None
     if a.warmup > 0:
         ctx.sweep(a.warmup, commit=True)
     ctx.profile_enable(['update', 'update_ahead'])
@@ -534,6 +561,9 @@ def main():
             'setup_s': t_setup,
             'full_elbocalc': calc,
             'independent_evaluations': pool,
+            # the first sweeps against the reference's recorded values for this workload (golden_check), then the ELBO the
+            # timed blocks ended on
+            'golden_check': golden,
             'elbo_last': float(elbo[-1]), 'info': int(info),
             # which schedule produced the line: 1 = device-side flags (the default), 0 = HIP events; fallbacks = calls of this
             # context that were re-run on events after an in-kernel wait timed out (0 in a healthy run)
