@@ -544,6 +544,8 @@ def test_sharded_fallback_is_rank_coherent(tmp_path):
     fallback each, flags latched off on both -- and both reproduce the reference's golden values."""
     tag = 'mid_N512_p3q2'
     meta, d = _cases.load(tag)
+    if os.environ.get('GPRN_FLAGS') == '0':
+        pytest.skip('GPRN_FLAGS=0: the event schedule has no in-kernel waits to time out')
     results = _run_ranks('tests._shard_worker', tag, 2, tmp_path, extra_env={'GPRN_TEST_WITHHOLD_RANK': '1'})
     if any(int(res['flags']) == 1 and int(res['fallbacks']) == 0 for res in results):
         pytest.skip('device-side flags are off on this box (nothing to time out)')
@@ -599,7 +601,8 @@ def test_schedule_and_kernel_variants_agree(env, tag, tmp_path):
     meta, d = _cases.load(tag)
     res = _run_ranks('tests._shard_worker', tag, 1, tmp_path, extra_env=env)[0]
     assert int(res['sw_info']) == 0 and int(res['fallbacks']) == 0
-    assert int(res['flags']) == (0 if env.get('GPRN_FLAGS') == '0' else 1)
+    # (the worker inherits this process' environment: the whole suite may itself be running under GPRN_FLAGS=0)
+    assert int(res['flags']) == (0 if env.get('GPRN_FLAGS', os.environ.get('GPRN_FLAGS')) == '0' else 1)
     np.testing.assert_allclose(res['sw_elbo'], d['elbo_sweeps'], rtol=RTOL)
     np.testing.assert_allclose(res['sw_parts'], d['parts_sweeps'], rtol=RTOL)
     _cases.assert_state('variant %s %s' % (tag, sorted(env.items())), res['sw_mu'], d['mu_final'])
