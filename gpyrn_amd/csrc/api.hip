@@ -195,8 +195,6 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //                    1 B formed inside the first update, 2 row reductions panel by panel, 4 node term beside the weight
 //                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep); 0 = everything in sequence
 //                    as in rounds 1-2; -1: the default (31).  Results are bit-identical for every value
-//   "linked_chain"   1/0: the latency chain of small factorisations (batch x tiles <= 32) as kernels that are resident
-//                    before their predecessors end and hand over through flags alone, or as plain launches; -1: default (1)
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -207,7 +205,6 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "wait_budget_ms")) field = &c->wait_budget_ms;
     else if (!strcmp(name, "withhold_inner")) field = &c->withhold_inner;
     else if (!strcmp(name, "overlap")) field = &c->overlap_opt;
-    else if (!strcmp(name, "linked_chain")) field = &c->linked_opt;
     else if (!strcmp(name, "small_path")) field = &c->small_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;

@@ -59,17 +59,6 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
     return __hiloint2double(hi, lo);
 }
 
-// ---- the linked chain (round 4, factor.hip): the kernel behind this one on the latency chain is already resident and
-// polls for this one's completion flag, so there is no kernel boundary to make the results visible.  With AG every store of
-// L and X goes out at AGENT scope (global_store ... sc1: written through this XCD's L2, which is not coherent with the
-// other XCDs' L2s) -- same instruction count, no fence: the flag may go up as soon as the stores are acknowledged.
-template <bool AG>
-__device__ __forceinline__ void st_ag(gptr_t p, double v)
-{
-    if (AG) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-
 // potf2 + trtri2 of a 16x16 block, the block in ONE MFMA accumulator (C layout: lane (fr = l&15, fk = l>>4), register
 // t holds S[fk + 4t][fr]; lower = B then L, strict upper = transposed right-hand side as in S), four pivots per round:
 //   1. the round's four columns go to LDS, [row][n] (the block's own rows as identity rows);
@@ -92,7 +81,6 @@ __device__ long long b16_stamps[4][8];
 #define B16_STAMP(R, i, dep) do {} while (0)
 #endif
 // c: the block in C layout (what lies above the diagonal is ignored); L -> St (lower), X -> xd and Xg
-template <bool AG = false>
 __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pitch PP */,
                                             double* __restrict__ xd, gptr_t Xg, int ld,
                                             int* info, int slot, int pivot0,
@@ -164,7 +152,7 @@ __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pi
         if (below) St[fr * PP + k0 + fk] = w;
         const double xv = below ? 0.0 : w;
         xd[(k0 + fk) * PP + fr] = xv;
-        st_ag<AG>(Xg + (size_t)(k0 + fk) * ld + fr, xv);
+        Xg[(size_t)(k0 + fk) * ld + fr] = xv;
         if (l == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -271,7 +259,7 @@ __device__ __forceinline__ Op16 op16_t(const double* __restrict__ T)
 // one phase of a compute wave; KB and the wave's rows are compile-time constants, so every acc[][] index is one too
 // (as a loop over kb the body stayed rolled once -- the unroll pragma is a hint -- and the accumulators went to
 // scratch memory: 150 us per block instead of 23)
-template <int W, int kb, bool AG>
+template <int W, int kb>
 __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld)
 {
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
@@ -317,14 +305,14 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int row = 16 * P + fk + 4 * t, col = 16 * kb + fr;
-                if (P > kb || col <= row) st_ag<AG>(Bt + (size_t)row * ld + col, acc[pp][kb][t]);
+                if (P > kb || col <= row) Bt[(size_t)row * ld + col] = acc[pp][kb][t];
             }
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int r = fk + 4 * t;
-                st_ag<AG>(Xt + (size_t)(16 * kb + r) * ld + 16 * P + fr, L.PB[(16 * P + fr) * PP + r]);
-                st_ag<AG>(Xt + (size_t)(16 * P + r) * ld + 16 * kb + fr, 0.0);
+                Xt[(size_t)(16 * kb + r) * ld + 16 * P + fr] = L.PB[(16 * P + fr) * PP + r];
+                Xt[(size_t)(16 * P + r) * ld + 16 * kb + fr] = 0.0;
             }
         }
     }
@@ -385,7 +373,7 @@ struct DiagFromTile {
     __device__ __forceinline__ double operator()(int row, int col) const { return Bt[(size_t)row * ld + col]; }
 };
 
-template <int W, bool AG, class LOAD>
+template <int W, class LOAD>
 __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load)
 {
     // this wave's sub-tile rows (-1 = none): equal update counts
@@ -419,13 +407,13 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     lds_barrier();                                  // (the pivot wave factored sub-tile 0 in between)
     DG_STAMP(NSB, 3);
 
-    diag_phase<W, 0, AG>(acc, L, Bt, Xt, ld); diag_phase<W, 1, AG>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 2, AG>(acc, L, Bt, Xt, ld); diag_phase<W, 3, AG>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 4, AG>(acc, L, Bt, Xt, ld); diag_phase<W, 5, AG>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 6, AG>(acc, L, Bt, Xt, ld); diag_phase<W, 7, AG>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 0>(acc, L, Bt, Xt, ld); diag_phase<W, 1>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 2>(acc, L, Bt, Xt, ld); diag_phase<W, 3>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 4>(acc, L, Bt, Xt, ld); diag_phase<W, 5>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
-template <bool AG, class LOAD>
+template <class LOAD>
 __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int* __restrict__ info, int slot,
                                            int pivot0)
 {
@@ -436,7 +424,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 #pragma unroll
         for (int t = 0; t < 4; ++t) c0[t] = load(fk + 4 * t, fr);
         DG_STAMP(NSB, 1);
-        base16_regs<AG>(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
+        base16_regs(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
     }
     DG_STAMP(NSB, 2);
     lds_barrier();
@@ -465,8 +453,8 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
         lds_barrier();                                     // M
         DG_STAMP(kb, 2);
         if (kb < NSB - 1)                                  // ... then factor it, straight from the registers
-            base16_regs<AG>(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
-                            info, slot, pivot0 + 16 * n, L.LINE);
+            base16_regs(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
+                        info, slot, pivot0 + 16 * n, L.LINE);
         DG_STAMP(kb, 3);
         lds_barrier();                                     // E
         DG_STAMP(kb, 4);
@@ -475,30 +463,16 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 
 // potrf + inverse of a 128x128 tile whose entries `load(row, col)` supplies: L (lower) -> Bt, X = L^-1 -> Xt;
 // `lds`: DIAG_LDS_DOUBLES doubles.  All 256 threads of the workgroup call it.
-template <bool AG = false, class LOAD>
+template <class LOAD>
 __device__ __forceinline__ void diag_tile_from(double* __restrict__ lds, const LOAD& load, gptr_t Bt, gptr_t Xt, int ld,
                                                int* __restrict__ info, int slot, int pivot0)
 {
     const DiagLds L(lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) diag_compute<0, AG>(L, Bt, Xt, ld, load);
-    else if (wave == 1) diag_compute<1, AG>(L, Bt, Xt, ld, load);
-    else if (wave == 2) diag_compute<2, AG>(L, Bt, Xt, ld, load);
-    else diag_pivot<AG>(L, Bt, Xt, ld, load, info, slot, pivot0);
-}
-
-// the tile as the kernel before this one on the linked chain stored it (agent scope on both sides), results at agent scope
-struct DiagFromTileAgent {
-    gptr_t Bt; int ld;
-    __device__ __forceinline__ double operator()(int row, int col) const
-    {
-        return __hip_atomic_load(Bt + (size_t)row * ld + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-};
-__device__ __forceinline__ void diag_tile_linked(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
-                                                 int* __restrict__ info, int slot, int pivot0)
-{
-    diag_tile_from<true>(lds, DiagFromTileAgent{Bt, ld}, Bt, Xt, ld, info, slot, pivot0);
+    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load);
+    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load);
+    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load);
+    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0);
 }
 
 // ... of the tile at Bt itself

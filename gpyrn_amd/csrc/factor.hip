@@ -35,10 +35,7 @@
 // PTRS: the two pointers per matrix come as kernel arguments (launch_diag), else from the table
 // (one wave per SIMD: the register-resident tile needs ~290 VGPRs per lane; without the second bound the compiler sizes
 // the allocation for the three workgroups per CU the LDS would allow and spills)
-// LINKED: a link of the linked chain (factor_invert_launches) -- resident while the update before it still runs, it
-// polls for that one's flag, reads its tile at agent scope, stores L and X at agent scope and raises its own flag
-// without a fence
-template <bool ARGS, bool LINKED>
+template <bool ARGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
@@ -46,18 +43,15 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
-    if (LINKED) await_flag_relaxed(wait_flag, wait_value, wait_timed_out);
-    else await_flag(wait_flag, wait_value, wait_timed_out);
+    await_flag(wait_flag, wait_value, wait_timed_out);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     const int slot = blockIdx.x;
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
-    if (LINKED) diag_tile_linked(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
-    else diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
+    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-    if (LINKED) signal_linked(sig_slot, sig_value, nullptr);
-    else signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
+    signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
 }
 
 
@@ -106,7 +100,7 @@ unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which)
 }
 
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info, hipStream_t stream,
-                Signal sig, Await aw, bool linked)
+                Signal sig, Await aw)
 {
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_DIAG, stream);
@@ -120,12 +114,12 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     if (nbatch * c->T <= GPRN_LAT_MAX)
         dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
     pa.stamps = step_stamp_ptr(c, kblk, 0);
-    const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
-#define GO_D(A, L) hipLaunchKernelGGL((k_diag_block<A, L>), dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, \
-                                      d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out)
-    if (args) { if (linked) GO_D(true, true); else GO_D(true, false); }
-    else { if (linked) GO_D(false, true); else GO_D(false, false); }
-#undef GO_D
+    if (tab_rows(c, d_ptrs, nbatch, &pa))
+        hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+    else
+        hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -314,7 +308,7 @@ __global__ void k_flag_multi(FlagOps ops, unsigned value, unsigned* timed_out)
         if (ops.wait[i]) spin_until(ops.wait[i], value, timed_out);
 }
 
-#define GPRN_FLAG_KINDS 12          // flag kinds per tile step / outer panel (factor_invert_launches)
+#define GPRN_FLAG_KINDS 10          // flag kinds per tile step / outer panel (factor_invert_launches)
 
 // Flags or events for this context?  Kernels that wait for other kernels need those to be able to run
 // beside them: every switch that serialises kernels or starves the hardware queues means events.
@@ -372,20 +366,6 @@ int factor_use_flags(gprn_ctx* c)
     return c->use_flags = d ? d->use_flags : 1;
 }
 
-// the linked chain's second stream must sit on a hardware queue of its own too (probed once per device)
-static bool factor_probe_stream4(gprn_ctx* c)
-{
-    DeviceStreams* d = c->shared;
-    if (!d || !c->stream4) return false;
-    if (d->stream4_ok < 0) {
-        hipStream_t st[4] = {c->stream, c->stream2, c->stream3, c->stream4};
-        bool ok = true;
-        for (int i = 0; i < 3 && ok; ++i) ok = streams_overlap(st[3], st[i]) && streams_overlap(st[i], st[3]);
-        d->stream4_ok = ok ? 1 : 0;
-    }
-    return d->stream4_ok == 1;
-}
-
 
 // The launch schedule.  Three serial sequences and a background, on four streams:
 //   chain   (s0): per tile step k   diag(k)  ->  L_{k+1,k}  ->  B_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T
@@ -413,7 +393,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     auto side_stamp = [&](int k, int i) {          // GPRN_STEP_STAMPS=2: the clock on stream3 at this point of step k
         if (c->side_stamps) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(64), 0, s1, c->side_stamps + (size_t)k * 8 + i);
     };
-    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_RESTA, F_TAIL, F_LDONE, F_UDONE, F_KINDS };
+    enum { F_DIAG = 0, F_MINIL, F_INNER, F_PANEL, F_NEXT, F_REST, F_FIRST, F_XW, F_RESTA, F_TAIL, F_KINDS };
     static_assert(F_KINDS == GPRN_FLAG_KINDS, "factor_check_waits decodes the flag table by GPRN_FLAG_KINDS");
     if (use_flags && c->sig_T < c->T) {
         if (c->d_sig) hipFree(c->d_sig);
@@ -433,7 +413,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     }
     const unsigned epoch = ++c->epoch;
     hipEvent_t events[F_KINDS] = {c->ev_diag, c->ev_minil, c->ev_inner, c->ev_panel, c->ev_next, c->ev_rest, c->ev_first,
-                                  nullptr, c->ev_resta, c->ev_tail, nullptr, nullptr};
+                                  nullptr, c->ev_resta, c->ev_tail};
     auto slot = [&](int idx, int kind) { return c->d_sig + ((size_t)idx * F_KINDS + kind) * 2; };
     unsigned* const timed_out = c->d_sig ? c->d_sig + (size_t)c->sig_T * F_KINDS * 2 : nullptr;
     const Await noaw{nullptr, 0, nullptr};
@@ -482,20 +462,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     bool tail_on_s2 = false;                       // rows_final ran on the bulk stream: joined at the end
     // "rest" as two launches with "next" on a stream of its own, beside the previous panel's whole "rest": +2.1 % sweeps/s
     // at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to 64 tile steps
-    // THE LINKED CHAIN (latency set: batch x tiles <= GPRN_LAT_MAX, where a phase is its chain and the device is mostly
-    // idle): diag(k) -> L_{k+1,k} -> update of B_{k+1,k+1} -> diag(k+1) ... alternate between the chain stream and stream4,
-    // so that every kernel is enqueued behind its GRAND-predecessor and is resident, polling, when its predecessor ends:
-    // the three kernel boundaries of a tile step (2.2-3 us each: 8.8 of config 2's 38 us) become in-kernel hand-overs.
-    // Round 2 had this shape with fences and found no gain -- a release + an acquire cost what a boundary costs; here
-    // every link stores its results at agent scope (sc1: written through), its successor reads them at agent scope, and
-    // the flag goes up as soon as the stores are acknowledged (signal_linked): no write-back, no invalidate.
-    static int linked_env = -2;                    // GPRN_LINKED=0/1 (read once per process; the option overrides it)
-    if (linked_env == -2) { const char* e = getenv("GPRN_LINKED"); linked_env = e ? atoi(e) : -1; }
-    const int linked_want = c->linked_opt >= 0 ? c->linked_opt : (linked_env >= 0 ? linked_env : 1);
-    const bool linked = use_flags && set == 1 && c->stream4 && c->T > 1 && linked_want != 0 && factor_probe_stream4(c);
-    hipStream_t const sB = c->stream4;
-    auto link_stream = [&](int n) { return (n & 1) ? sB : s0; };     // n = 3 k + {0 diag, 1 L, 2 update}
-    const bool sr = c->stream4 && c->T <= 64 && !linked;
+    const bool sr = c->stream4 && c->T <= 64;
     hipStream_t sn = sr ? c->stream4 : s2;
 
     // stream3 at the start of step k: raise F_INNER of the step before, then wait for diag(k)
@@ -630,12 +597,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             const gprn_ctx::StepRange& s = c->steps[set][k];
             if (pending_outer >= 0 && s.npanel_l == 0 && (rc = do_outer(pending_outer))) return rc;
             // ---- the chain
-            if (linked) {
-                if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, link_stream(3 * k), in_kernel(k, F_DIAG),
-                                      k > 0 ? in_kernel_wait(k - 1, F_UDONE) : noaw, true))) return rc;
-                // what follows the LAST diagonal block does so on the chain stream
-                if (s.npanel_l == 0 && link_stream(3 * k) != s0) HIP_TRY(c, await(s0, k, F_DIAG));
-            } else
             if ((rc = launch_diag(c, c->d_ptrs, nbatch, c->ld, k, c->d_info_cur, s0, in_kernel(k, F_DIAG), noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_DIAG));
             if (use_flags && k == 0 && c->chain_started) {
@@ -665,15 +626,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // bounds the phase) its 8 workgroups per matrix poll that flag themselves; with more, the phase is bound by
             // the tile kernels' throughput and 8 x batch resident 512-thread workgroups that only poll keep bulk
             // workgroups off their CUs: a one-wave kernel waits instead (+0.8 % at config 3, +2 % at config 4)
-            if (linked) {
-                // L_{k+1,k}: waits for stream3's update of the step before (acquire), loads its row blocks, then polls for
-                // the diagonal block; raises its own flag and, for stream3, L_{k+1,k}'s.  The update polls for L's flag.
-                if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, link_stream(3 * k + 1), in_kernel(k, F_LDONE),
-                                           k > 0 ? in_kernel_wait(k - 1, F_INNER) : Await{nullptr, 0, timed_out}, nullptr, 0u, true,
-                                           in_kernel_wait(k, F_DIAG), slot(k, F_MINIL) + 1))) return rc;
-                if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, link_stream(3 * k + 2), in_kernel(k, F_UDONE),
-                                           in_kernel_wait(k, F_LDONE), nullptr, 0u, true))) return rc;
-            } else {
             const bool spin = use_flags && k > 0 && nbatch <= 2;
             if (use_flags && k > 0 && !spin && (rc = flag_sync(s0, nullptr, slot(k - 1, F_INNER) + 1))) return rc;
             if (k > 0 && !use_flags) HIP_TRY(c, await(s0, k - 1, F_INNER));
@@ -684,7 +636,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // instead of at the end of its own -- 1.7 us less between the two at every tile step)
             if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, s0, nosig, noaw,
                                        use_flags ? slot(k, F_MINIL) + 1 : (unsigned*)nullptr, epoch))) return rc;
-            }
             // The outer update of the previous panel is ENQUEUED here, behind the chain's three launches of this panel's
             // first step: its dozen stream operations and launches take the host 60-100 us, during which the chain stream
             // ran dry at every panel boundary (profiles/r02_chain_timeline_cfg3.txt)
@@ -818,8 +769,7 @@ int factor_check_waits(gprn_ctx* c)
     HIP_TRY(c, hipMemcpy(word, c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, sizeof(word), hipMemcpyDeviceToHost));
     if (word[0]) {
         hipMemset(c->d_sig + (size_t)c->sig_T * GPRN_FLAG_KINDS * 2, 0, sizeof(unsigned));
-        static const char* const kind_name[GPRN_FLAG_KINDS] = {"DIAG", "MINIL", "INNER", "PANEL", "NEXT", "REST", "FIRST", "XW", "RESTA", "TAIL",
-                                                               "LDONE", "UDONE"};
+        static const char* const kind_name[GPRN_FLAG_KINDS] = {"DIAG", "MINIL", "INNER", "PANEL", "NEXT", "REST", "FIRST", "XW", "RESTA", "TAIL"};
         const long long at = (long long)c->sig_T * GPRN_FLAG_KINDS * 2 + (long long)(int)word[2];
         char what[96];
         if (at >= 0 && at < (long long)c->sig_T * GPRN_FLAG_KINDS * 2)

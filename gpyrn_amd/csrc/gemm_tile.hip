@@ -198,27 +198,18 @@ __device__ unsigned long long rows_stamps[8];
 // rows, fully coalesced; eight waves fetching all of it themselves kept the CU's vector memory path busy for 3.5 us
 // -- and the X_kk rows come straight from global memory, 16 (Q + 1) columns of them.
 #define ROWS_PITCH 136                              // doubles per LDS row: 16-byte reads of 64 lanes spread over all banks
-// LINKED (the linked chain, factor_invert_launches): the kernel is resident before the diagonal block ends.  It waits for
-// the side stream's update first (wait_flag, with an acquire: that one's stores are ordinary), brings its row block into
-// LDS, and only then polls for the diagonal block (wait2_flag, no acquire): X_kk was stored at agent scope and is read at
-// agent scope.  Its own result leaves at agent scope, and the last workgroup raises the launch's flag and also_flag
-// (L_{k+1,k} for the side stream) without a fence.
-__device__ __forceinline__ double ld_ag(const double* p)
-{
-    return __hip_atomic_load((gcptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool ARGS, bool LINKED>
+template <bool ARGS>
 __global__ __launch_bounds__(512)
 void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t b_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-               unsigned* wait_timed_out, const unsigned* wait2_flag, unsigned wait2_value, unsigned* also_flag)
+               unsigned* wait_timed_out)
 {
     __shared__ __attribute__((aligned(16))) double rows[16 * ROWS_PITCH];
     RW_STAMP(0);
     const bool st = pa.stamps && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0;
     if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
     await_flag(wait_flag, wait_value, wait_timed_out);
-    if (st && !LINKED) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
+    if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     RW_STAMP(1);
     const int Q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), P = blockIdx.x;
     const int lane = threadIdx.x & 63, fr = lane & 15, fk = lane >> 4;
@@ -227,14 +218,12 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     const int nj = 2 * (Q + 1);
     const double* B = Xm + b_off + (size_t)(16 * Q + fr) * ld + 2 * fk;
     double b[32];
-    if (!LINKED) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < nj) {
-                const double2 bv = *(const double2*)(B + 8 * j);
-                b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
-            }
-    }
+    for (int j = 0; j < 16; ++j)
+        if (j < nj) {
+            const double2 bv = *(const double2*)(B + 8 * j);
+            b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
+        }
     {   // rows 2Q, 2Q+1 of the block: lane l takes 16 bytes at column 2 l
         const double* Ar = Bm + a_off + (size_t)(16 * P + 2 * Q) * ld + 2 * lane;
         const double2 r0 = *(const double2*)Ar, r1 = *(const double2*)(Ar + ld);
@@ -242,15 +231,6 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         *(double2*)(rows + (2 * Q + 1) * ROWS_PITCH + 2 * lane) = r1;
     }
     RW_STAMP(2);
-    if (LINKED) {
-        // (the workgroup barrier of the wait is also the one behind the LDS stores above)
-        if (threadIdx.x == 0 && wait2_flag) spin_until_relaxed(wait2_flag, wait2_value, wait_timed_out);
-        __syncthreads();
-        if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < nj) { b[2 * j] = ld_ag(B + 8 * j); b[2 * j + 1] = ld_ag(B + 8 * j + 1); }
-    } else
     __syncthreads();                 // the block is in LDS: from here on its memory may be overwritten (in place)
     RW_STAMP(3);
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -264,27 +244,20 @@ void k_chain_l(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         }
     gptr_t C = (gptr_t)(Bm + a_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        if (LINKED) __hip_atomic_store(C + (size_t)(4 * tt) * ld, acc[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else C[(size_t)(4 * tt) * ld] = acc[tt];
-    }
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
     RW_STAMP(4);
 #ifdef ROWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
     if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-    if (LINKED) signal_linked(sig_slot, sig_value, also_flag);
-    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 
 // MODE 1, one single-wave workgroup per lower 16 x 16 block (36 per matrix, each on a CU of its own: 32 KiB of
 // operands per CU instead of 256)
-// LINKED: resident before L_{k+1,k} is complete; polls for its flag (no acquire), reads every operand at agent scope (the
-// tile it updates was written by the side stream's update of the step before, whose completion the L kernel has seen),
-// stores at agent scope, raises its flag without a fence
-template <bool ARGS, bool LINKED>
+template <bool ARGS>
 __global__ __launch_bounds__(64)
 void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_off, int64_t c_off,
                unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
@@ -297,8 +270,7 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     const bool st = pa.stamps && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0 && threadIdx.x == 0;
     if (st) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
-    if (LINKED) await_flag_relaxed(wait_flag, wait_value, wait_timed_out);
-    else await_flag(wait_flag, wait_value, wait_timed_out);
+    await_flag(wait_flag, wait_value, wait_timed_out);
     if (st) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
     RW_STAMP(1);
     int P = 0;
@@ -311,42 +283,28 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     gptr_t C = (gptr_t)(Bm + c_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
     double a[32], b[32];
     v4d acc;
-    if (LINKED) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            a[2 * j] = ld_ag(A + 8 * j); a[2 * j + 1] = ld_ag(A + 8 * j + 1);
-            b[2 * j] = ld_ag(B + 8 * j); b[2 * j + 1] = ld_ag(B + 8 * j + 1);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[tt] = __hip_atomic_load(C + (size_t)(4 * tt) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double2 av = *(const double2*)(A + 8 * j), bv = *(const double2*)(B + 8 * j);
-            a[2 * j] = av.x; a[2 * j + 1] = av.y;
-            b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
+    for (int j = 0; j < 16; ++j) {
+        const double2 av = *(const double2*)(A + 8 * j), bv = *(const double2*)(B + 8 * j);
+        a[2 * j] = av.x; a[2 * j + 1] = av.y;
+        b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
     }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every load in flight before the first MFMA
     RW_STAMP(2);
     RW_STAMP(3);
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[j], b[j], acc, 0, 0, 0);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-        if (LINKED) __hip_atomic_store(C + (size_t)(4 * tt) * ld, acc[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else C[(size_t)(4 * tt) * ld] = acc[tt];
-    }
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
     RW_STAMP(4);
 #ifdef ROWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     RW_STAMP(5);
 #endif
     if (st) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
-    if (LINKED) signal_linked(sig_slot, sig_value, nullptr);
-    else signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
+    signal_done(sig_slot, sig_value, nullptr, 0, wait_timed_out);
     RW_STAMP(6);
 }
 
@@ -356,8 +314,7 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
 // flag, when the launch before it on the stream is that product: its own end-of-kernel signal (wait for the stores, barrier,
 // release, atomic: 1.7 us between the two launches of every tile step, profiles/r03_chain_stamps_c2.txt) is then not needed
 int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
-                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start, unsigned raise_value,
-                     bool linked, Await aw2, unsigned* also_flag)
+                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start, unsigned raise_value)
 {
     if (!stream) stream = c->stream;
     if (nbatch == 0) return GPRN_OK;
@@ -369,18 +326,13 @@ int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, in
     PtrArgs pa;
     pa.stamps = step_stamp_ptr(c, k, mode == 0 ? 1 : 2);
     const bool args = tab_rows(c, d_ptrs, nbatch, &pa);
-    unsigned* const tmo = aw.timed_out ? aw.timed_out : (aw2.timed_out ? aw2.timed_out : sig.timed_out);
-#define GO_L(A, L) hipLaunchKernelGGL((k_chain_l<A, L>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
-                                      b_off, sig.slot, sig.value, aw.flag, aw.value, tmo, aw2.flag, aw2.value, also_flag)
-#define GO_U(A, L) hipLaunchKernelGGL((k_chain_u<A, L>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
-                                      sig.slot, sig.value, aw.flag, aw.value, tmo, raise_at_start, raise_value)
-    if (mode == 0) {
-        if (args) { if (linked) GO_L(true, true); else GO_L(true, false); }
-        else { if (linked) GO_L(false, true); else GO_L(false, false); }
-    } else {
-        if (args) { if (linked) GO_U(true, true); else GO_U(true, false); }
-        else { if (linked) GO_U(false, true); else GO_U(false, false); }
-    }
+    unsigned* const tmo = aw.timed_out ? aw.timed_out : sig.timed_out;
+#define GO_L(A) hipLaunchKernelGGL((k_chain_l<A>), dim3(GPRN_TILE / 16, (unsigned)nbatch), dim3(512), 0, stream, tab, pa, ld, a_off, \
+                                   b_off, sig.slot, sig.value, aw.flag, aw.value, tmo)
+#define GO_U(A) hipLaunchKernelGGL((k_chain_u<A>), dim3(36, (unsigned)nbatch), dim3(64), 0, stream, tab, pa, ld, a_off, c_off, \
+                                   sig.slot, sig.value, aw.flag, aw.value, tmo, raise_at_start, raise_value)
+    if (mode == 0) { if (args) GO_L(true); else GO_L(false); }
+    else { if (args) GO_U(true); else GO_U(false); }
 #undef GO_L
 #undef GO_U
     prof_end(c);

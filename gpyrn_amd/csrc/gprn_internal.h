@@ -80,7 +80,6 @@ struct DeviceStreams {         // one per device and process, see gprn_create
     hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
     int device = 0, refs = 0;
     int use_flags = -1;        // the flag schedule's verdict for these streams (factor_use_flags), -1: not probed
-    int stream4_ok = -1;       // ... and for the fourth stream as the linked chain's second one (factor_probe_stream4)
     std::recursive_mutex mu;   // held for the length of every entry point
 };
 
@@ -221,7 +220,6 @@ struct gprn_ctx {
     const double* ft_s_phase = nullptr;
     const double* ft_s_now = nullptr;
     int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: the default
-    int linked_opt = -1;             // gprn_set_option "linked_chain": 0 = the latency chain as plain launches; -1: the default (on)
     // ---- small-N path (smalln.hip): problems of one or two tiles run a half-sweep as ONE launch, one workgroup per latent GP
     int small_opt = -1;              // gprn_set_option "small_path": 0 never, else wherever it applies (small_applies)
     double** d_kinv_tab = nullptr;   // [q] device pointers K_j^-1 (quirk Q1), for k_small_tail
@@ -301,16 +299,11 @@ unsigned long long* step_stamp_ptr(gprn_ctx* c, int k, int which);   // GPRN_STE
 
 // the chain's two products of a tile step at 16 x 16 granularity (gemm_tile.hip); mode 0: L_{k+1,k} in place, 1: the
 // update of B_{k+1,k+1}
-// linked (flag schedule only): the launch is part of a chain whose kernels are resident before their predecessors end --
-// its waits are in-kernel polls, its results leave at agent scope and its completion flag goes up without a fence
-// (diag_tile.h st_ag, signal_linked); aw2 (mode 0): the diagonal block's flag, aw: the side stream's update of the step
-// before; also_flag (mode 0): a second flag the launch raises with its own (L_{k+1,k} for the side stream)
 int launch_tile_rows(gprn_ctx* c, int k, double** d_ptrs, int nbatch, int ld, int mode, int fam,
-                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start = nullptr, unsigned raise_value = 0,
-                     bool linked = false, Await aw2 = Await{nullptr, 0, nullptr}, unsigned* also_flag = nullptr);
+                     hipStream_t stream, Signal sig, Await aw, unsigned* raise_at_start = nullptr, unsigned raise_value = 0);
 int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int* d_info,
                 hipStream_t stream = nullptr, Signal sig = Signal{nullptr, 0, nullptr, 0, nullptr},
-                Await aw = Await{nullptr, 0, nullptr}, bool linked = false);
+                Await aw = Await{nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
@@ -367,51 +360,6 @@ __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value, cons
             atomicExch(slot, 0u);
             if (value) __hip_atomic_store(slot + 1, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             if (then_wait) spin_until(then_wait, then_value, timed_out);
-        }
-    }
-}
-
-// ---- the linked chain (factor.hip): producer and consumer are both resident, the consumer polling.  The producer's
-// results went out at agent scope (sc1 stores: in memory once acknowledged), the consumer reads them at agent scope, so
-// neither side needs a fence: the flag goes up as soon as every wave's stores are acknowledged.
-// poll only -- no acquire: what the caller reads next it reads at agent scope
-__device__ __forceinline__ void spin_until_relaxed(const unsigned* flag, unsigned value, unsigned* timed_out)
-{
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long budget = timed_out ? (unsigned long long)timed_out[1] : 200000000ull;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
-            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= value) break;
-            if (timed_out && __hip_atomic_load(timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > budget) {
-                if (timed_out && atomicExch(timed_out, 1u) == 0u) timed_out[2] = (unsigned)(flag - timed_out);
-                break;
-            }
-        }
-    }
-    asm volatile("" ::: "memory");
-}
-// start of a kernel (or later): every thread of the workgroup calls it
-__device__ __forceinline__ void await_flag_relaxed(const unsigned* flag, unsigned value, unsigned* timed_out)
-{
-    if (!flag) return;                              // uniform
-    if (threadIdx.x == 0) spin_until_relaxed(flag, value, timed_out);
-    __syncthreads();
-}
-// end of a kernel whose stores all went out at agent scope: every thread of the workgroup calls it.  The last workgroup
-// raises the flag (and a second one, if given) -- relaxed stores at system scope, no write-back of the L2
-__device__ __forceinline__ void signal_linked(unsigned* slot, unsigned value, unsigned* also_flag)
-{
-    if (!slot) return;                              // uniform
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (__hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == total) {
-            __hip_atomic_store(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + 1, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (also_flag) __hip_atomic_store(also_flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
