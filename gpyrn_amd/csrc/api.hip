@@ -195,6 +195,7 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //                    1 B formed inside the first update, 2 row reductions panel by panel, 4 node term beside the weight
 //                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep); 0 = everything in sequence
 //                    as in rounds 1-2; -1: the default (31).  Results are bit-identical for every value
+//   "batch_mem_mb"   device memory (MiB) one chunk of gprn_elbocalc_batch's evaluations may take; longer lists run chunk by chunk
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -208,6 +209,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "small_path")) field = &c->small_opt;
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
+    else if (!strcmp(name, "batch_mem_mb")) field = &c->batch_mem_mb;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
@@ -220,6 +222,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
             if (!can) return bad(c, "set_option: this device has no stream memory operations");
         }
         if (field == &c->wait_budget_ms && value < 1) return bad(c, "set_option: wait_budget_ms >= 1");
+        if (field == &c->batch_mem_mb && value < 1) return bad(c, "set_option: batch_mem_mb >= 1");
         *field = value;
     }
     return GPRN_OK;
@@ -233,6 +236,7 @@ static void free_problem(gprn_ctx* c)
     dev_free(c->d_mu_alt); dev_free(c->d_var_alt);
     if (c->d_loop_ctl) { hipFree(c->d_loop_ctl); c->d_loop_ctl = nullptr; }
     small_batch_free(c);
+    mid_batch_free(c);
     if (c->h_pin_in) { hipHostFree(c->h_pin_in); c->h_pin_in = nullptr; c->pin_in_cap = 0; }
     if (c->h_pin_out) { hipHostFree(c->h_pin_out); c->h_pin_out = nullptr; c->pin_out_cap = 0; }
     dev_free(c->d_loop_hist);
@@ -1109,6 +1113,47 @@ static int small_sweep(gprn_ctx* c, const double* mu_in, const double* var_in, d
     return small_tail(c, out4, scal, mu_out, var_out, loop);
 }
 
+// One half-sweep's factorisation with its head and tail, against c->d_ptrs / slot0 / d_info_cur (set by the caller): d, s,
+// right-hand side -> B = I + D^1/2 K D^1/2 = L L^T, X = L^-1 -> u = X z, column sums over X -> the new rows of the state,
+// tr B^-1, log det B.  `ns` slots whose latent GPs are d_slot_gp[slot] (and, for a batch of evaluations, whose evaluation
+// is c->ev.slot_eval[slot]: midn.hip).
+int phase_core(gprn_ctx* c, bool weights, const int* slotgp, int ns)
+{
+    const size_t o = (size_t)c->slot0 * c->ld;
+    TRY(vec_prep(c, weights, slotgp, ns));
+    // B = I + D^1/2 K D^1/2: built by factor_invert -- only the tiles its first outer panel's tile steps touch; the
+    // others are formed from K inside that panel's K = 512 update (overlap bit 1).
+    // The reductions over the rows of X = L^-1 (u = X z, column norms, X^T u: 8 N^2 bytes per matrix) run outer
+    // panel by outer panel as the rows become final (rows_final, called by the schedule on the bulk stream: bit 2);
+    // behind the factorisation only the last panel's rows, the reduction over the partial sums and the new state
+    // are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
+    const int overlap = overlap_mask(c);
+    c->rows_done = 0;
+    c->build_pending = ns;
+    c->ft_s_phase = (overlap & 1) ? c->d_s + o : nullptr;
+    if (overlap & 2) {
+        c->rows_final = [c, o, slotgp, ns](int r0, int r1, hipStream_t st) -> int {
+            TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, st, r0 * GPRN_TILE,
+                                 (r1 - r0) * GPRN_TILE));
+            return vec_colops_partial(c, ns, st, r0, r1 - r0);
+        };
+    }
+    const int rc_f = factor_invert(c, ns);
+    c->ft_s_phase = nullptr; c->build_pending = 0;
+    const int rd = c->rows_done;
+    c->rows_final = nullptr; c->rows_done = 0;
+    TRY(rc_f);
+    TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, nullptr, rd * GPRN_TILE, -1));
+    TRY(vec_colops_partial(c, ns, nullptr, rd, -1));
+    if (overlap & 8) TRY(vec_reduce_finalize(c, slotgp, ns, true));     // column sums, new state, tr B^-1, log det B
+    else {
+        TRY(vec_colops_reduce(c, ns));
+        TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
+        TRY(vec_finalize(c, slotgp, ns, false));
+    }
+    return GPRN_OK;
+}
+
 static int run_phase(gprn_ctx* c, bool weights)
 {
     const std::vector<int>& gps = weights ? c->loc_weights : c->loc_nodes;
@@ -1119,37 +1164,8 @@ static int run_phase(gprn_ctx* c, bool weights)
     c->d_info_cur = c->d_info + (weights ? 2 : 1) * (size_t)c->nslot;
     const size_t o = (size_t)c->slot0 * c->ld;
     if (ns) {
-        TRY(vec_prep(c, weights, slotgp, ns));
-        // B = I + D^1/2 K D^1/2: built by factor_invert -- only the tiles its first outer panel's tile steps touch; the
-        // others are formed from K inside that panel's K = 512 update (overlap bit 1).
-        // The reductions over the rows of X = L^-1 (u = X z, column norms, X^T u: 8 N^2 bytes per matrix) run outer
-        // panel by outer panel as the rows become final (rows_final, called by the schedule on the bulk stream: bit 2);
-        // behind the factorisation only the last panel's rows, the reduction over the partial sums and the new state
-        // are left.  Same kernels, same partial sums, same order of every addition: bit-identical results.
+        TRY(phase_core(c, weights, slotgp, ns));
         const int overlap = overlap_mask(c);
-        c->rows_done = 0;
-        c->build_pending = ns;
-        c->ft_s_phase = (overlap & 1) ? c->d_s + o : nullptr;
-        if (overlap & 2) {
-            c->rows_final = [c, o, slotgp, ns](int r0, int r1, hipStream_t st) -> int {
-                TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, st, r0 * GPRN_TILE,
-                                     (r1 - r0) * GPRN_TILE));
-                return vec_colops_partial(c, ns, st, r0, r1 - r0);
-            };
-        }
-        const int rc_f = factor_invert(c, ns);
-        c->ft_s_phase = nullptr; c->build_pending = 0;
-        const int rd = c->rows_done;
-        c->rows_final = nullptr; c->rows_done = 0;
-        TRY(rc_f);
-        TRY(vec_lower_matvec(c, BUF_X, c->d_z + o, c->ld, 0, slotgp, ns, c->d_u + o, nullptr, rd * GPRN_TILE, -1));
-        TRY(vec_colops_partial(c, ns, nullptr, rd, -1));
-        if (overlap & 8) TRY(vec_reduce_finalize(c, slotgp, ns, true));     // column sums, new state, tr B^-1, log det B
-        else {
-            TRY(vec_colops_reduce(c, ns));
-            TRY(vec_logdet(c, BUF_B, slotgp, ns, c->d_logdetB));
-            TRY(vec_finalize(c, slotgp, ns, false));
-        }
         if (c->keep_sigma) {
             const size_t nn = (size_t)c->ld * c->ld;
             TRY(lauum_lower(c, ns));
@@ -1359,19 +1375,6 @@ extern "C" int gprn_factor_priors(gprn_ctx* c);
 extern "C" int gprn_get_muvar(gprn_ctx* c, double* mu, double* var);
 // meanfield.py:626-649 in one call: the first sweep's update is discarded and its ELBO kept as elboArray[0] (quirk Q7), then
 // sweeps until `iterNumber > 3 and |std(last3) / mean(last3)| < 1e-3 and != 0` (np.std: population) or max_iter.
-static bool stop_rule(double e0, double e1, double e2)
-{
-    volatile double sum = e0 + e1; sum = sum + e2;             // (volatile: one rounding per operation, as NumPy's ufuncs)
-    volatile double mean = sum / 3.0;
-    volatile double d0 = e0 - mean, d1 = e1 - mean, d2 = e2 - mean;
-    volatile double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
-    volatile double v = q0 + q1; v = v + q2; v = v / 3.0;
-    volatile double sd = sqrt(v);
-    volatile double ratio = sd / mean;
-    const double crit = fabs(ratio);
-    return crit < 1e-3 && crit != 0.0;
-}
-
 // the small path: ONE call, one synchronisation per batch of sweeps.  Inputs go through a pinned staging buffer and
 // asynchronous copies, the set-up (fills + k_small_prior) is enqueued without waiting for its verdict, the loop runs on the
 // device (k_small_tail applies the stop rule; sweeps enqueued ahead of the verdict become no-ops once it is in), and both
@@ -1539,10 +1542,16 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
             pre = bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
         if ((pre = agree_to_start(c, pre, "elbocalc"))) return pre;
         double e = 0.0;
-        rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 0, &e, nullptr, retry); }, true);
+        // Quirk Q7: the first ELBOaux call's update is discarded and its ELBO kept as elboArray[0] (:627-628); the loop's
+        // first trip then repeats that very call (same state in, :636) -- elboArray[1] == elboArray[0] by construction.
+        // The sweep is deterministic (no atomics in any reduction), so it runs ONCE, committed, and its ELBO is entered
+        // twice; only max_iter = 0 needs the uncommitted form.
+        const int first_commit = max_iter >= 1 ? 1 : 0;
+        rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, first_commit, &e, nullptr, retry); }, true);
         if (rc < 0) return rc;
         if (!info) info = rc;
         hist.push_back(e);
+        if (first_commit) { hist.push_back(e); iter = 1; }
         while (iter < max_iter) {
             rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 1, &e, nullptr, retry); }, true);
             if (rc < 0) return rc;
@@ -1550,7 +1559,7 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
             hist.push_back(e);
             iter += 1;
             const size_t n = hist.size();
-            if (iter > 3 && stop_rule(hist[n - 3], hist[n - 2], hist[n - 1])) { conv = 1; break; }
+            if (iter > 3 && elbo_stop_rule(hist[n - 3], hist[n - 2], hist[n - 1])) { conv = 1; break; }
         }
         if (mu_out && (rc = gprn_get_muvar(c, mu_out, var_out))) return rc;
     }
@@ -1563,7 +1572,19 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
     return info;
 }
 
-// B independent evaluations of the loop above, side by side on the device (smalln.hip): see include/gprn_hip.h
+// Device memory one chunk of side-by-side evaluations may take: option "batch_mem_mb", else half of what is free now, 48 GiB
+// at most (the card holds 288: the rest stays with the caller's other contexts)
+size_t batch_budget_bytes(gprn_ctx* c)
+{
+    if (c->batch_mem_mb > 0) return (size_t)c->batch_mem_mb << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)8 << 30;
+    return std::min<size_t>(free_b / 2, (size_t)48 << 30);
+}
+
+// B independent evaluations of the loop above, side by side on the device: see include/gprn_hip.h.  One-tile problems run a
+// half-sweep of ALL evaluations as one launch (smalln.hip); larger ones go through the launch schedule with
+// batch = evaluations x latent GPs (midn.hip).  Either way a list longer than the memory budget holds runs chunk by chunk.
 extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel_params, int n_kernel_params,
                                    const double* y_resid, const double* jitters, const double* mu, const double* var,
                                    int max_iter, double* elbo, int* iterations, int* converged, int* info,
@@ -1575,9 +1596,21 @@ extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel
         return bad(c, "elbocalc_batch: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->owner.empty()) return bad(c, "elbocalc_batch: call set_owners first");
+    if (comm_active(c) || c->world != 1) { c->err = "elbocalc_batch: one rank only (a pool of ranks splits the list itself)"; return GPRN_E_UNSUPPORTED; }
     TRY(build_tables(c));
-    return small_batch_elbocalc(c, n_eval, kernel_params, n_kernel_params, y_resid, jitters, mu, var, max_iter, elbo,
-                                iterations, converged, info, mu_out, var_out);
+    const bool small = c->T == 1 && small_applies(c);
+    const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;
+    const int chunk = small ? small_batch_chunk(c) : n_eval;       // (midn.hip sizes its own chunks: it knows what a matrix costs)
+    for (int e0 = 0; e0 < n_eval; e0 += chunk) {
+        const int ne = std::min(chunk, n_eval - e0);
+        const double* kp = kernel_params + (size_t)e0 * n_kernel_params;
+        double* mo = mu_out ? mu_out + (size_t)e0 * d : nullptr;
+        double* vo = var_out ? var_out + (size_t)e0 * d : nullptr;
+        auto run = small ? small_batch_elbocalc : mid_batch_elbocalc;
+        TRY(run(c, ne, kp, n_kernel_params, y_resid + (size_t)e0 * pn, jitters + (size_t)e0 * c->p, mu + (size_t)e0 * d,
+                var + (size_t)e0 * d, max_iter, elbo + e0, iterations + e0, converged + e0, info + e0, mo, vo));
+    }
+    return GPRN_OK;
 }
 
 // ------------------------------------------------------------------ read-back

@@ -76,6 +76,17 @@ struct KernelSpec {            // how latent GP g gets its K
     double params[GPRN_MAX_KPARAMS];
 };
 
+// Several evaluations of ONE problem side by side (midn.hip: an optimiser's simplex, emcee's walkers): the slots of a phase
+// then belong to different evaluations, each with its own copy of the per-problem arrays.  slot_eval: slot -> evaluation
+// (null: one evaluation, every stride unused); the strides are doubles between two evaluations' copies.
+struct EvalMap {
+    const int* slot_eval;
+    size_t state;              // mu, var: (p + 1) q N
+    size_t yv;                 // y - mean, variance: p N
+    size_t scal;               // per-GP scalars of a sweep: 3 G + q q
+    size_t G;                  // log det K: G
+};
+
 struct DeviceStreams {         // one per device and process, see gprn_create
     hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
     int device = 0, refs = 0;
@@ -233,6 +244,11 @@ struct gprn_ctx {
     void* small_batch = nullptr;     // SmallBatchMem (smalln.hip): buffers of gprn_elbocalc_batch
     size_t pin_in_cap = 0, pin_out_cap = 0;
     bool small_tabs_ready = false;   // the set-up's tables for this problem are on the device (factor_priors_small)
+    // ---- many evaluations side by side above one tile (midn.hip): a worker context holds the matrices and states of a
+    // chunk of evaluations; its kernels find an evaluation's arrays through `ev`
+    EvalMap ev = {nullptr, 0, 0, 0, 0};
+    void* mid_batch = nullptr;       // MidBatch (midn.hip): the worker context and its slabs, owned by the PARENT context
+    int batch_mem_mb = -1;           // gprn_set_option "batch_mem_mb": device memory one chunk of evaluations may take; -1: a share of what is free
 };
 
 struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)
@@ -306,6 +322,8 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
                 Await aw = Await{nullptr, 0, nullptr});
 
 #ifdef __HIPCC__
+__device__ __forceinline__ size_t ev_of(const EvalMap& e, int slot) { return e.slot_eval ? (size_t)e.slot_eval[slot] : 0; }
+
 // Spin of ONE thread until *flag >= value.  timed_out[0] is the sticky "a wait gave up" word of the call,
 // timed_out[1] the budget of one wait in ticks of the 100 MHz constant clock (s_memrealtime): a wall-clock
 // bound, not a spin count -- on a shared device a legitimate wait can be long.  Once any wait of the call
@@ -388,3 +406,27 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
                          const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
                          double* mu_out, double* var_out);
 void small_batch_free(gprn_ctx* c);
+// evaluations one chunk of gprn_elbocalc_batch may hold on the small path (memory budget), >= 1
+int small_batch_chunk(gprn_ctx* c);
+// midn.hip: the same for problems of more than one tile, through the launch schedule with batch = evaluations x latent GPs
+int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpar, const double* y_resid, const double* jitters,
+                       const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
+                       double* mu_out, double* var_out);
+void mid_batch_free(gprn_ctx* c);
+size_t batch_budget_bytes(gprn_ctx* c);        // device memory a chunk of evaluations may take (option "batch_mem_mb")
+// api.hip: one half-sweep's factorisation with its head and tail against c->d_ptrs / slot0 / d_info_cur (run_phase, midn.hip)
+int phase_core(gprn_ctx* c, bool weights, const int* d_slot_gp, int ns);
+
+// meanfield.py:640-643: np.std / np.mean of the last three values, operation by operation (one rounding each)
+static inline bool elbo_stop_rule(double e0, double e1, double e2)
+{
+    volatile double sum = e0 + e1; sum = sum + e2;
+    volatile double mean = sum / 3.0;
+    volatile double d0 = e0 - mean, d1 = e1 - mean, d2 = e2 - mean;
+    volatile double q0 = d0 * d0, q1 = d1 * d1, q2 = d2 * d2;
+    volatile double v = q0 + q1; v = v + q2; v = v / 3.0;
+    volatile double sd = __builtin_sqrt(v);
+    volatile double ratio = sd / mean;
+    const double crit = __builtin_fabs(ratio);
+    return crit < 1e-3 && crit != 0.0;
+}

@@ -654,6 +654,16 @@ static int sb_alloc(gprn_ctx* c, TT** ptr, size_t count)
 }
 #define SB_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
 
+// evaluations one chunk may hold: what the memory budget pays for (4 G + q matrices of ld^2 doubles each and small change
+// per evaluation), 16 at least -- an emcee run with thousands of walkers is split, not refused
+int small_batch_chunk(gprn_ctx* c)
+{
+    const size_t nn = (size_t)c->ld * c->ld, d = (size_t)(c->p + 1) * c->q * c->N;
+    const size_t per = ((4 * (size_t)c->G + c->q) * nn + 7 * (size_t)c->G * c->ld + 6 * d + 4 * (size_t)c->p * c->N + 256) * sizeof(double) +
+                       (size_t)c->G * fill_program_bytes() * 2;
+    return (int)std::max<size_t>(16, std::min<size_t>(batch_budget_bytes(c) / per, 1 << 16));
+}
+
 static int small_batch_ensure(gprn_ctx* c, int n_eval)
 {
     SmallBatchMem* m = (SmallBatchMem*)c->small_batch;

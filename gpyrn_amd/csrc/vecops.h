@@ -20,6 +20,10 @@ int vec_q1(gprn_ctx* c, const double* Kinv_j, const double* Binv_k, const double
 int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a, double* out, hipStream_t stream = nullptr);
 int vec_elbo(gprn_ctx* c, double* out4, const double* scal, double* part, hipStream_t stream = nullptr);
 #define GPRN_ELBO_PART_DOUBLES (3 * 32)
+// several evaluations side by side (midn.hip): the ELBO assembly for the evaluations listed in d_evals, and the Q1 traces of
+// their node slots (node-major: slot = k * n_eval + a; the traces go to c->d_q1 + evaluation * c->ev.scal)
+int vec_elbo_evals(gprn_ctx* c, const int* d_evals, int n, double* out4, const double* scal, double* part, hipStream_t stream = nullptr);
+int vec_q1_evals(gprn_ctx* c, const int* d_slot_eval, const double* Kinv_slab, int n_eval, double* scratch, hipStream_t stream = nullptr);
 int vec_sigma(gprn_ctx* c, const double* Binv, const double* s, double* out);
 int vec_pred_rows(gprn_ctx* c, int nslots, int ns, int ns_pad, const double* sol, const double* kss,
                   double* mean, double* var);

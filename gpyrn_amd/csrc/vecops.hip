@@ -45,11 +45,13 @@ void k_prep_nodes(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                   const double* __restrict__ mu, const double* __restrict__ var,
                   const double* __restrict__ yres, const double* __restrict__ variance,
                   double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred,
-                  double* __restrict__ z)
+                  double* __restrict__ z, EvalMap ev)
 {
     const int slot = blockIdx.y, j = slot_gp[slot];
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= ld) return;
+    const size_t eb = ev_of(ev, slot);               // (several evaluations side by side: this slot's copy of the problem)
+    mu += eb * ev.state; var += eb * ev.state; yres += eb * ev.yv; variance += eb * ev.yv;
     double dsum = 1.0, psum = 0.0;
     if (n < N) {
         dsum = 0.0;
@@ -77,12 +79,14 @@ void k_prep_weights(const int* __restrict__ slot_gp, int N, int ld, int p, int q
                     const double* __restrict__ mu, const double* __restrict__ var,
                     const double* __restrict__ yres, const double* __restrict__ variance,
                     double* __restrict__ d, double* __restrict__ s, double* __restrict__ pred,
-                    double* __restrict__ z)
+                    double* __restrict__ z, EvalMap ev)
 {
     const int slot = blockIdx.y, kk = slot_gp[slot] - q;
     const int j = kk / p, i = kk % p;
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= ld) return;
+    const size_t eb = ev_of(ev, slot);
+    mu += eb * ev.state; var += eb * ev.state; yres += eb * ev.yv; variance += eb * ev.yv;
     double dv = 1.0, pv = 0.0;
     if (n < N) {
         const double vi = variance[(size_t)i * N + n];
@@ -175,7 +179,7 @@ void k_build_B(double* const* __restrict__ ptrs, int N, int ld, const double* __
 // out[idx(slot)] = 2 * sum_{n<N} log M[n][n]
 __global__ __launch_bounds__(256)
 void k_logdet(double* const* __restrict__ ptrs, int buf, int N, int ld,
-              const int* __restrict__ slot_gp, double* __restrict__ out)
+              const int* __restrict__ slot_gp, double* __restrict__ out, EvalMap ev, size_t out_stride)
 {
     __shared__ double sh[4];
     const int slot = blockIdx.x;
@@ -183,7 +187,7 @@ void k_logdet(double* const* __restrict__ ptrs, int buf, int N, int ld,
     double acc = 0.0;
     for (int n = threadIdx.x; n < N; n += 256) acc += log(M[(size_t)n * ld + n]);
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) out[slot_gp[slot]] = 2.0 * acc;
+    if (threadIdx.x == 0) out[ev_of(ev, slot) * out_stride + slot_gp[slot]] = 2.0 * acc;
 }
 
 // out[slot][i] = sum_{c<=i} M[i][c] v[c]   (i < N), M = ptrs[slot][buf];
@@ -191,13 +195,14 @@ void k_logdet(double* const* __restrict__ ptrs, int buf, int N, int ld,
 __global__ __launch_bounds__(256)
 void k_lower_matvec(double* const* __restrict__ ptrs, int buf, int N, int ld,
                     const double* __restrict__ vin, size_t vstride, int vin_by_gp,
-                    const int* __restrict__ slot_gp, double* __restrict__ out, int row0)
+                    const int* __restrict__ slot_gp, double* __restrict__ out, int row0, EvalMap ev)
 {
     const int slot = blockIdx.y;
     const int i = row0 + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= ld) return;
     const double* M = ptrs[(size_t)slot * GPRN_NBUF + buf] + (size_t)i * ld;
-    const double* v = vin + (size_t)(vin_by_gp ? slot_gp[slot] : slot) * vstride;
+    // (vin_by_gp: a row of the state -- of this slot's evaluation)
+    const double* v = vin + (vin_by_gp ? ev_of(ev, slot) * ev.state + (size_t)slot_gp[slot] * vstride : (size_t)slot * vstride);
     double acc = 0.0;
     if (i < N) {
         for (int c = 2 * lane; c <= i; c += 128) {
@@ -271,10 +276,12 @@ void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
                 const double* __restrict__ d, const double* __restrict__ s,
                 const double* __restrict__ z, const double* __restrict__ cs, const double* __restrict__ ct,
                 double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv,
-                double* const* __restrict__ ptrs, double* __restrict__ logdetB)
+                double* const* __restrict__ ptrs, double* __restrict__ logdetB, EvalMap ev)
 {
     __shared__ double sh[4];
     const int slot = blockIdx.x, gp = slot_gp[slot];
+    const size_t eb = ev_of(ev, slot);
+    mu += eb * ev.state; var += eb * ev.state; trBinv += eb * ev.scal; logdetB += eb * ev.scal;
     size_t row;
     if (gp < q) row = gp;
     else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
@@ -310,11 +317,13 @@ void k_reduce_finalize(const int* __restrict__ slot_gp, int N, int ld, int T, in
                        const double* __restrict__ z, double* __restrict__ cs, double* __restrict__ ct,
                        double* __restrict__ mu, double* __restrict__ var, double* __restrict__ trBinv,
                        double* const* __restrict__ ptrs, double* __restrict__ logdetB,
-                       double* __restrict__ terms /* [slot][2][ld] */, unsigned* __restrict__ tickets /* [slot] */)
+                       double* __restrict__ terms /* [slot][2][ld] */, unsigned* __restrict__ tickets /* [slot] */, EvalMap ev)
 {
     __shared__ double sh[4];
     __shared__ unsigned last;
     const int slot = blockIdx.y, gp = slot_gp[slot], n = blockIdx.x * 256 + threadIdx.x;
+    const size_t eb = ev_of(ev, slot);
+    mu += eb * ev.state; var += eb * ev.state; trBinv += eb * ev.scal; logdetB += eb * ev.scal;
     size_t row;
     if (gp < q) row = gp;
     else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
@@ -386,7 +395,7 @@ void k_sum_to(const double* __restrict__ v, int n, double* __restrict__ out)
 
 __global__ __launch_bounds__(256)
 void k_dot_self(const int* __restrict__ slot_gp, int N, int ld, const double* __restrict__ a,
-                double* __restrict__ out)
+                double* __restrict__ out, EvalMap ev)
 {
     __shared__ double sh[4];
     const int slot = blockIdx.x;
@@ -396,7 +405,7 @@ void k_dot_self(const int* __restrict__ slot_gp, int N, int ld, const double* __
         acc += x * x;
     }
     acc = block_sum(acc, sh);
-    if (threadIdx.x == 0) out[slot_gp[slot]] = acc;
+    if (threadIdx.x == 0) out[ev_of(ev, slot) * ev.scal + slot_gp[slot]] = acc;
 }
 
 // Expected log-likelihood (meanfield.py:895-990; y_raw is the RAW data, quirk Q3): partial sums
@@ -405,10 +414,14 @@ void k_dot_self(const int* __restrict__ slot_gp, int N, int ld, const double* __
 __global__ __launch_bounds__(256)
 void k_loglike_partial(int N, int p, int q, const double* __restrict__ mu, const double* __restrict__ var,
                        const double* __restrict__ yraw, const double* __restrict__ variance,
-                       double* __restrict__ part /* [ELBO_BLOCKS][3] */)
+                       double* __restrict__ part /* [ELBO_BLOCKS][3] */, const int* __restrict__ evals, EvalMap ev)
 {
     __shared__ double sh[4];
     const double TWO_PI = 6.283185307179586;
+    // (several evaluations side by side: grid y = position in the list `evals` of evaluations still running)
+    const size_t eb = evals ? (size_t)evals[blockIdx.y] : 0;
+    mu += eb * ev.state; var += eb * ev.state; variance += eb * ev.yv;
+    part += (size_t)blockIdx.y * 3 * ELBO_BLOCKS;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += 256 * ELBO_BLOCKS) {
         for (int i = 0; i < p; ++i) {
@@ -442,10 +455,14 @@ void k_loglike_partial(int N, int p, int q, const double* __restrict__ mu, const
 __global__ void k_elbo_final(int N, int p, int q, const double* __restrict__ part,
                              const double* __restrict__ logdetK, const double* __restrict__ logdetB,
                              const double* __restrict__ trBinv, const double* __restrict__ muKmu,
-                             const double* __restrict__ q1, double* __restrict__ out)
+                             const double* __restrict__ q1, double* __restrict__ out, const int* __restrict__ evals, EvalMap ev)
 {
     if (threadIdx.x != 0) return;
     const double TWO_PI = 6.283185307179586;
+    const size_t eb = evals ? (size_t)evals[blockIdx.x] : 0;
+    part += (size_t)blockIdx.x * 3 * ELBO_BLOCKS;
+    logdetK += eb * ev.G; logdetB += eb * ev.scal; trBinv += eb * ev.scal; muKmu += eb * ev.scal; q1 += eb * ev.scal;
+    out += eb * 4;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     for (int b = 0; b < ELBO_BLOCKS; ++b) { t1 += part[3 * b]; t2 += part[3 * b + 1]; t3 += part[3 * b + 2]; }
     const int G = q + q * p;
@@ -479,11 +496,11 @@ int vec_prep(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots)
     if (weights)
         hipLaunchKernelGGL(k_prep_weights, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o);
+                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o, c->ev);
     else
         hipLaunchKernelGGL(k_prep_nodes, grid, dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                            c->p, c->q, c->d_mu, c->d_var, c->d_yres, c->d_variance,
-                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o);
+                           c->d_d + o, c->d_s + o, c->d_pred + o, c->d_z + o, c->ev);
     LAUNCH_END(c);
 }
 
@@ -509,7 +526,8 @@ int vec_logdet(gprn_ctx* c, int buf, const int* d_slot_gp, int nslots, double* o
     if (!nslots) return GPRN_OK;
     prof_begin(c, GPRN_T_VEC);
     hipLaunchKernelGGL(k_logdet, dim3(nslots), dim3(256), 0, c->stream,
-                       (double* const*)c->d_ptrs, buf, c->N, c->ld, d_slot_gp, out);
+                       (double* const*)c->d_ptrs, buf, c->N, c->ld, d_slot_gp, out, c->ev,
+                       out == c->d_logdetK ? c->ev.G : c->ev.scal);
     LAUNCH_END(c);
 }
 
@@ -523,7 +541,7 @@ int vec_lower_matvec(gprn_ctx* c, int buf, const double* vin, size_t vstride, in
     prof_begin(c, GPRN_T_VEC, stream);
     hipLaunchKernelGGL(k_lower_matvec, dim3((nrows + 3) / 4, nslots), dim3(256), 0, stream,
                        (double* const*)c->d_ptrs, buf, c->N, c->ld, vin, vstride, vin_by_gp,
-                       d_slot_gp, out, row0);
+                       d_slot_gp, out, row0, c->ev);
     LAUNCH_END(c);
 }
 
@@ -566,7 +584,7 @@ int vec_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with_logdet
     const size_t o = (size_t)c->slot0 * c->ld;
     hipLaunchKernelGGL(k_finalize, dim3(nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld,
                        c->p, c->q, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
-                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB);
+                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB, c->ev);
     LAUNCH_END(c);
 }
 
@@ -584,7 +602,7 @@ int vec_reduce_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with
     hipLaunchKernelGGL(k_reduce_finalize, dim3((c->ld + 255) / 256, nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld, c->T,
                        c->p, c->q, c->d_part + po, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
                        c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB,
-                       c->d_fin_terms + (size_t)c->slot0 * 2 * c->ld, c->d_fin_tickets + c->slot0);
+                       c->d_fin_terms + (size_t)c->slot0 * 2 * c->ld, c->d_fin_tickets + c->slot0, c->ev);
     LAUNCH_END(c);
 }
 
@@ -604,7 +622,7 @@ int vec_dot_self(gprn_ctx* c, const int* d_slot_gp, int nslots, const double* a,
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_VEC, stream);
     hipLaunchKernelGGL(k_dot_self, dim3(nslots), dim3(256), 0, stream, d_slot_gp, c->N, c->ld,
-                       a, out);
+                       a, out, c->ev);
     LAUNCH_END(c);
 }
 
@@ -614,9 +632,79 @@ int vec_elbo(gprn_ctx* c, double* out4, const double* scal, double* part, hipStr
     if (!stream) stream = c->stream;
     prof_begin(c, GPRN_T_VEC, stream);
     hipLaunchKernelGGL(k_loglike_partial, dim3(ELBO_BLOCKS), dim3(256), 0, stream, c->N, c->p, c->q,
-                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, part);
+                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, part, (const int*)nullptr, c->ev);
     hipLaunchKernelGGL(k_elbo_final, dim3(1), dim3(64), 0, stream, c->N, c->p, c->q, part,
-                       c->d_logdetK, scal, scal + c->G, scal + 2 * (size_t)c->G, scal + 3 * (size_t)c->G, out4);
+                       c->d_logdetK, scal, scal + c->G, scal + 2 * (size_t)c->G, scal + 3 * (size_t)c->G, out4,
+                       (const int*)nullptr, c->ev);
+    LAUNCH_END(c);
+}
+
+// the same for the n evaluations listed in d_evals (midn.hip): evaluation b reads its own state, variance and per-GP scalars
+// (strides c->ev) and writes out4 + 4 b; part: n x 3 * ELBO_BLOCKS doubles of scratch
+int vec_elbo_evals(gprn_ctx* c, const int* d_evals, int n, double* out4, const double* scal, double* part, hipStream_t stream)
+{
+    if (!n) return GPRN_OK;
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_loglike_partial, dim3(ELBO_BLOCKS, n), dim3(256), 0, stream, c->N, c->p, c->q,
+                       c->d_mu, c->d_var, c->d_yraw, c->d_variance, part, d_evals, c->ev);
+    hipLaunchKernelGGL(k_elbo_final, dim3(n), dim3(64), 0, stream, c->N, c->p, c->q, part,
+                       c->d_logdetK, scal, scal + c->G, scal + 2 * (size_t)c->G, scal + 3 * (size_t)c->G, out4, d_evals, c->ev);
+    LAUNCH_END(c);
+}
+
+// quirk Q1 for the evaluations of a batch (midn.hip; node slots node-major: slot = k * n_eval + a): per (node k, node j > k,
+// position a) the row sums of k_q1_rows and their sum (k_sum_to's order) into that evaluation's q1[j * q + k]
+__global__ __launch_bounds__(256)
+void k_q1_rows_evals(double* const* __restrict__ ptrs, const int* __restrict__ slot_eval, const double* __restrict__ Kinv_slab,
+                     size_t nn, int q, int n_eval, int N, int ld, const double* __restrict__ s, double* __restrict__ rowsum)
+{
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (m >= N) return;
+    int kj = blockIdx.y / n_eval, k = 0, j = 1;
+    const int a = blockIdx.y % n_eval;
+    while (kj >= q - 1 - k) { kj -= q - 1 - k; ++k; }
+    j = k + 1 + kj;
+    const int slot = k * n_eval + a;
+    const size_t b = (size_t)slot_eval[slot];
+    const double* kr = Kinv_slab + (b * (size_t)(q - 1) + (size_t)(j - 1)) * nn + (size_t)m * ld;
+    const double* br = ptrs[(size_t)slot * GPRN_NBUF + BUF_B] + (size_t)m * ld;
+    const double* sv = s + (size_t)slot * ld;
+    double acc = 0.0;
+    for (int n = lane; n < m; n += 64) acc -= kr[n] * br[n] / sv[n];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        const double sm = sv[m];
+        rowsum[(size_t)blockIdx.y * ld + m] = 2.0 * acc / sm + kr[m] * (1.0 - br[m]) / (sm * sm);
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_q1_sum_evals(const double* __restrict__ rowsum, const int* __restrict__ slot_eval, int q, int n_eval, int N, int ld,
+                    double* __restrict__ q1, size_t scal_stride)
+{
+    __shared__ double sh[4];
+    int kj = blockIdx.x / n_eval, k = 0;
+    const int a = blockIdx.x % n_eval;
+    while (kj >= q - 1 - k) { kj -= q - 1 - k; ++k; }
+    const int j = k + 1 + kj;
+    const double* v = rowsum + (size_t)blockIdx.x * ld;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) acc += v[i];
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) q1[(size_t)slot_eval[k * n_eval + a] * scal_stride + (size_t)j * q + k] = acc;
+}
+
+int vec_q1_evals(gprn_ctx* c, const int* d_slot_eval, const double* Kinv_slab, int n_eval, double* scratch, hipStream_t stream)
+{
+    const int npair = c->q * (c->q - 1) / 2;
+    if (!n_eval || !npair) return GPRN_OK;
+    if (!stream) stream = c->stream;
+    prof_begin(c, GPRN_T_VEC, stream);
+    hipLaunchKernelGGL(k_q1_rows_evals, dim3((c->N + 3) / 4, npair * n_eval), dim3(256), 0, stream, (double* const*)c->d_ptrs,
+                       d_slot_eval, Kinv_slab, (size_t)c->ld * c->ld, c->q, n_eval, c->N, c->ld, c->d_s, scratch);
+    hipLaunchKernelGGL(k_q1_sum_evals, dim3(npair * n_eval), dim3(256), 0, stream, (const double*)scratch, d_slot_eval, c->q,
+                       n_eval, c->N, c->ld, c->d_q1, c->ev.scal);
     LAUNCH_END(c);
 }
 

@@ -422,6 +422,7 @@ class inference:
         specs = [self._kernel_spec(k) for k in chain(nodes, weights)]
         key = tuple(self._spec_key(s) for s in specs)
         if key != self._prior_key:             # unchanged hyper-parameters keep their factors
+            self._prior_key = None             # (nothing names the device's kernels until the set-up has succeeded)
             for gp, spec in enumerate(specs):
                 self._send_spec(ctx, gp, spec)
             self.last_info = ctx.factor_priors()
@@ -479,6 +480,9 @@ class inference:
         key = tuple(self._spec_key(s) for s in specs)
         setup = key != self._prior_key
         if setup:
+            # (from here to the end of a successful set-up the device holds kernels -- possibly factors -- that no key
+            # names: a call that raises in between must not leave the old key standing for them)
+            self._prior_key = None
             for gp, spec in enumerate(specs):
                 self._send_spec(ctx, gp, spec)
             self.last_info = 0
@@ -664,6 +668,10 @@ class inference:
         mean, variance, parts = self._Prediction(tstar=tstar, separate=True)
         return tstar, mean, np.sqrt(variance), parts
 
+    #: largest N for which nELBO_batch / mcmc(batch=True) evaluate side by side on one GPU (beyond it a single evaluation
+    #: already fills the device, and a chunk of evaluations would be a few matrices)
+    batch_max_N = 2048
+
     def nELBO_batch(self, parameter_sets, max_iter=None, pool=None, batch=True):
         """
         ``nELBO`` for several free-parameter vectors: ``[nELBO(p) for p in
@@ -673,11 +681,13 @@ class inference:
         optimiser populations and emcee walkers one by one (meanfield.py:1222-1260).
         The parameters of ``self`` end up at the last vector this rank evaluated.
 
-        Without a pool, a problem of one tile (N <= 128) whose kernels all have device programs evaluates the whole list
-        SIDE BY SIDE on the GPU (``gprn_elbocalc_batch``): every evaluation with its own covariance matrices, state, loop
-        and stop rule, all of them starting from the state the object holds (``nELBO``'s warm start) -- where one
-        evaluation after the other starts each from its predecessor's result, which moves the values within the stop
-        rule's 1e-3.  ``batch=False`` forces the one-by-one form.
+        Without a pool, a problem whose kernels all have device programs evaluates the whole list SIDE BY SIDE on the GPU
+        (``gprn_elbocalc_batch``): every evaluation with its own covariance matrices, state, loop and stop rule, all of
+        them starting from the state the object holds (``nELBO``'s warm start) -- where one evaluation after the other
+        starts each from its predecessor's result, which moves the values within the stop rule's 1e-3.  One-tile problems
+        (N <= 128) run a half-sweep of all evaluations as ONE launch; larger ones (up to ``batch_max_N`` points) go
+        through the large problems' launch schedule with its batch dimension = evaluations x latent GPs, in chunks that
+        fit the library's memory budget.  ``batch=False`` forces the one-by-one form.
         """
         assert self._components_set, _NOT_SET
         sets = [np.array(x, dtype=float) for x in parameter_sets]
@@ -691,13 +701,20 @@ class inference:
     def _nELBO_batch_device(self, sets, max_iter):
         """``nELBO_batch`` through ``gprn_elbocalc_batch``, or None where that does not apply (larger problems, sharded
         objects, user-defined kernels, kernel expressions that change shape from one vector to the next)."""
-        if self._comm is not None or self.N > 128:
+        if self._comm is not None or self.N > self.batch_max_N:
             return None
         ctx = self._backend()
         max_iter = 10000 if max_iter is None else int(max_iter)
         y_raw = np.concatenate(self.y)
         start = time_module.time()
         B = len(sets)
+        # (set_parameters takes full-length vectors too, meanfield.py:223-259: the fast layout below wants them all alike)
+        n_free, n_all = int((~self.frozen_mask).sum()), int(self.frozen_mask.size)
+        if any(x.ndim != 1 or x.size not in (n_free, n_all) for x in sets):
+            return None                                        # (the one-by-one form raises the reference's ValueError)
+        if n_free != n_all and any(x.size == n_all for x in sets):
+            free_ = ~self.frozen_mask
+            sets = [x[free_] if x.size == n_all else x for x in sets]
         # the first vector the ordinary way: it tells what the programs are and whether the rest can be laid out in one go
         self.set_parameters(sets[0])
         nodes, weights, means, jitters = self._get_components()

@@ -316,6 +316,127 @@ def test_nelbo_batch_side_by_side(n, p, q, kind, B):
     _assert_default_schedule(g._backend())
 
 
+def _batch_inputs(g, sets):
+    """What inference._nELBO_batch_device hands the library, vector by vector (the general layout), with the starting state
+    `g` holds (or each vector's own _initMuVar state)."""
+    ctx = g._backend()
+    from itertools import chain
+    y_raw = np.concatenate(g.y)
+    kp, yr, jt, m0, v0 = [], [], [], [], []
+    for i, x in enumerate(sets):
+        g.set_parameters(x)
+        nodes, weights, means, jitters = g._get_components()
+        specs = [g._kernel_spec(k) for k in chain(nodes, weights)]
+        assert all(sp[0] == 'device' for sp in specs)
+        if i == 0:
+            for gp, sp in enumerate(specs):
+                g._send_spec(ctx, gp, sp)
+            g._prior_key = None
+        kp.append(np.concatenate([sp[2] for sp in specs]))
+        yr.append(y_raw - g._mean(means))
+        jt.append(np.asarray(jitters, dtype=float))
+        mu, var = (g._mu, g._var) if g._mu is not None else g._initMuVar(nodes, weights, jitters)
+        m0.append(np.ravel(mu))
+        v0.append(np.ravel(var))
+    return ctx, np.array(kp), np.array(yr), np.array(jt), np.array(m0), np.array(v0)
+
+
+@pytest.mark.parametrize('tag,B', [('mid_N300_p3q2', 7), ('mid_N512_p3q2', 32), ('cfg1_N200', 5), ('mid_N1024_p1q1', 6)])
+def test_every_slot_of_a_batch_above_one_tile_reproduces_the_reference(tag, B):
+    """gprn_elbocalc_batch above one tile (csrc/midn.hip): B evaluations go through the launch schedule with its batch
+    dimension = evaluations x latent GPs.  Every slot of a batch run AT THE FIXTURE'S PARAMETERS must reproduce what the
+    reference itself printed for them: the forced sweeps (max_iter = their number: the loop's trip i is forced sweep i - 1,
+    quirk Q7) -- last ELBO and final state to 1e-8 -- and, where the fixture holds it, the whole ELBOcalc (trip count,
+    converged value and state).  No fallback to the event schedule."""
+    meta, d, g = _model(tag)
+    x = np.array(g.get_parameters(), dtype=float)
+    ctx, kp, yr, jt, m0, v0 = _batch_inputs(g, [x] * B)
+    assert np.array_equal(m0[0], np.ravel(d['mu_init']))
+    k = int(meta['nsweeps'])                                   # (no fixture's loop stops before its forced sweeps end)
+    res = ctx.elbocalc_batch(kp, yr, jt, m0, v0, k, want_state=True)
+    assert res is not None, 'the library has no batched form for this problem'
+    elbo, iters, conv, info, mu, var = res
+    assert not info.any() and (iters == k).all()
+    np.testing.assert_allclose(elbo, np.full(B, d['elbo_sweeps'][k - 1]), rtol=RTOL)
+    for b in range(B):
+        _cases.assert_state('batch slot %d of %d, forced sweeps %s' % (b, B, tag), mu[b], d['mu_final'], var[b], d['var_final'])
+    res1 = ctx.elbocalc_batch(kp, yr, jt, m0, v0, 1, want_state=True)       # (the fixture's first-sweep state pins trip 1)
+    for b in range(B):
+        _cases.assert_state('batch slot %d of %d, first sweep %s' % (b, B, tag), res1[4][b], d['mu_1'], res1[5][b], d['var_1'])
+    # max_iter = 0: only the discarded call -- elboArray[0], no trip, the state as given
+    res0 = ctx.elbocalc_batch(kp, yr, jt, m0, v0, 0, want_state=True)
+    np.testing.assert_allclose(res0[0], np.full(B, d['elbo_sweeps'][0]), rtol=RTOL)
+    assert (res0[1] == 0).all() and np.array_equal(res0[4].reshape(B, -1), m0)
+    if 'calc_elbo' in d:
+        elbo, iters, conv, info, mu, var = ctx.elbocalc_batch(kp, yr, jt, m0, v0, 10000, want_state=True)
+        assert not info.any() and conv.all() and (iters == int(d['calc_iter'])).all()
+        np.testing.assert_allclose(elbo, np.full(B, float(d['calc_elbo'])), rtol=RTOL)
+        for b in range(B):
+            _cases.assert_state('batch slot %d of %d, ELBOcalc %s' % (b, B, tag), mu[b], d['calc_mu'], var[b], d['calc_var'])
+        # ... and the warm start from there (meanfield.py:598-607, 1102-1104)
+        mw = np.tile(np.ravel(d['calc_mu']), (B, 1))
+        vw = np.tile(np.ravel(d['calc_var']), (B, 1))
+        elbo, iters, conv, info = ctx.elbocalc_batch(kp, yr, jt, mw, vw, 10000)
+        assert (iters == int(d['warm_iter'])).all()
+        np.testing.assert_allclose(elbo, np.full(B, float(d['warm_elbo'])), rtol=RTOL)
+    _assert_default_schedule(ctx)
+
+
+@pytest.mark.parametrize('n,p,q,kind,B,budget_mb', [(200, 1, 1, 'SE', 6, 0), (300, 3, 2, 'QP', 9, 0), (512, 3, 2, 'QP', 32, 0),
+                                                    (260, 2, 3, 'QP', 5, 0), (300, 2, 2, 'QP', 11, 80), (1024, 1, 1, 'QP', 4, 0)])
+def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb):
+    """inference.nELBO_batch above one tile: B PERTURBED parameter vectors side by side against the same evaluations one by
+    one from the same starting state, cold (each from its own _initMuVar state) and warm (all from one converged state) --
+    values to 1e-9 and, through them, trip counts; evaluations that stop at different trips leave the launches one by one
+    (the tables are compacted); q = 2 and 3 bring the Q1 traces; a memory budget smaller than the list splits it into
+    chunks.  No fallback."""
+    t, ys, es = synth.rv_series(n, p)
+    spec = synth.component_spec(p, q, kind)
+
+    def fresh():
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        means = [meanfunc.Constant(0.3 * (i + 1)) for i in range(p)]
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        return g
+
+    g = fresh()
+    if budget_mb:
+        g._backend().option('batch_mem_mb', budget_mb)        # (a chunk then holds fewer evaluations than the list has)
+    max_iter = 6 if q >= 3 else None                           # (the reference's Jacobi iteration diverges at q = 3: DESIGN.md 3)
+    x0 = np.array(g.get_parameters(), dtype=float)
+    rng = np.random.RandomState(11)
+    sets = [x0 * (1.0 + 0.05 * rng.standard_normal(x0.size)) + 0.01 * rng.standard_normal(x0.size) * (x0 == 0)
+            for _ in range(B)]
+    got = np.array(g.nELBO_batch(sets, max_iter=max_iter))
+    assert g.last_info == 0 and np.all(np.isfinite(got))
+    gs = fresh()
+    want, trips = [], []
+    for x in sets:
+        gs.set_parameters(x)
+        e, _, _, it = gs.ELBOcalc(max_iter=max_iter)
+        want.append(-e)
+        trips.append(it)
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    # ---- warm
+    gs.set_parameters(x0)
+    _, mu_w, var_w, _ = gs.ELBOcalc(max_iter=max_iter)
+    g._mu, g._var = mu_w.copy(), var_w.copy()
+    got = np.array(g.nELBO_batch(sets, max_iter=max_iter))
+    want = []
+    for x in sets:
+        gs.set_parameters(x)
+        e, _, _, it = gs.ELBOcalc(max_iter=max_iter, mu=mu_w, var=var_w)
+        want.append(-e)
+        trips.append(it)
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    np.testing.assert_allclose(g.get_parameters(), sets[-1])
+    if q < 3 and B >= 9:
+        assert len(set(trips)) > 1, 'every evaluation stopped at the same trip: the compaction was not exercised'
+    _assert_default_schedule(g._backend())
+    _assert_default_schedule(gs._backend())
+
+
 def test_small_path_reports_a_failed_pivot():
     """jnp.linalg.cholesky semantics on the small path too: a matrix that is not positive definite gives info > 0 (the
     order of the failing minor, LAPACK style) and NaN downstream, no exception (meanfield.py:71-89)."""
