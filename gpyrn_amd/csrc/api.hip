@@ -266,6 +266,7 @@ static void free_problem(gprn_ctx* c)
     c->nslot = 0; c->out_cap = 0;
     c->factored = c->have_yres = c->have_jit = c->have_muvar = false;
     c->tables_ready = false;
+    c->small_tabs_ready = c->small_sweep_ready = false;
 }
 
 // ------------------------------------------------------------------ context
@@ -925,6 +926,7 @@ static int build_tables(gprn_ctx* c)
         HIP_TRY(c, hipMemcpy(c->d_slotgp_weight, c->loc_weights.data(), c->loc_weights.size() * sizeof(int), hipMemcpyHostToDevice));
     c->tables_ready = true;
     c->small_tabs_ready = false;
+    c->small_sweep_ready = false;
     return GPRN_OK;
 }
 
@@ -956,6 +958,29 @@ extern "C" int gprn_factor_priors(gprn_ctx* c)
     return with_event_fallback(c, "factor_priors", [&](bool) { return factor_priors_impl(c); }, true);
 }
 
+// What a SWEEP of the small path reads beside the phase tables: the ticket of k_small_tail and the table of K_j^-1 pointers
+// (quirk Q1).  Whichever set-up ran last -- the small one below or the launch schedule's (option "small_path" = 0 or
+// gprn_keep_sigma at that time; it fills Kinv[j], j >= 1, too) -- the sweep may take either path afterwards (a
+// set-up through the launch path followed by a sweep on the small path read a null ticket and a null table).
+static int ensure_small_sweep_tabs(gprn_ctx* c)
+{
+    if (c->small_sweep_ready) return GPRN_OK;
+    std::vector<double*> ktab(c->q, nullptr);
+    for (int j = 1; j < c->q; ++j) {
+        if (!c->Kinv[j]) return bad(c, "small path: K_j^-1 of a node is missing (no set-up yet?)");
+        ktab[j] = c->Kinv[j];
+    }
+    dev_free(c->d_kinv_tab);
+    TRY(dev_alloc(c, &c->d_kinv_tab, (size_t)c->q));
+    HIP_TRY(c, hipMemcpy(c->d_kinv_tab, ktab.data(), ktab.size() * sizeof(double*), hipMemcpyHostToDevice));
+    if (!c->d_small_ticket) {
+        TRY(dev_alloc(c, &c->d_small_ticket, 1));
+        HIP_TRY(c, hipMemset(c->d_small_ticket, 0, sizeof(unsigned)));
+    }
+    c->small_sweep_ready = true;
+    return GPRN_OK;
+}
+
 // The set-up of a problem of one or two tiles on one rank (smalln.hip): the fills, then ONE launch -- a workgroup per latent
 // GP copies K, factors and inverts it, takes log det K and, where quirk Q1 needs it, forms K_j^-1 -- and one read-back.
 static int factor_priors_small(gprn_ctx* c, bool sync = true)
@@ -967,7 +992,7 @@ static int factor_priors_small(gprn_ctx* c, bool sync = true)
     gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
     const int nj = (int)gps.size();
     if (!c->small_tabs_ready) {
-        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr), kout(c->nslot, nullptr), ktab(c->q, nullptr);
+        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr), kout(c->nslot, nullptr);
         for (int s = 0; s < nj; ++s) {
             const int g = gps[s];
             rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
@@ -975,27 +1000,22 @@ static int factor_priors_small(gprn_ctx* c, bool sync = true)
             rows[s * GPRN_NBUF + BUF_K] = c->K[g];
             rows[s * GPRN_NBUF + BUF_KLINV] = c->KLinv[g];
             if (g >= 1 && g < c->q) {                  // quirk Q1: node k < j needs K_j^-1
-                if (!c->Kinv[g]) TRY(dev_alloc(c, &c->Kinv[g], nn));
+                if (!c->Kinv[g]) { TRY(dev_alloc(c, &c->Kinv[g], nn)); c->small_sweep_ready = false; }
                 kout[s] = c->Kinv[g];
-                ktab[g] = c->Kinv[g];
             }
         }
         TRY(upload_table(c, c->tab_setup, rows));
         HIP_TRY(c, hipMemcpy(c->d_slotgp_setup, gps.data(), nj * sizeof(int), hipMemcpyHostToDevice));
-        dev_free(c->d_kinv_out); dev_free(c->d_kinv_tab);
+        dev_free(c->d_kinv_out);
         TRY(dev_alloc(c, &c->d_kinv_out, (size_t)c->nslot));
-        TRY(dev_alloc(c, &c->d_kinv_tab, (size_t)c->q));
         HIP_TRY(c, hipMemcpy(c->d_kinv_out, kout.data(), kout.size() * sizeof(double*), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_kinv_tab, ktab.data(), ktab.size() * sizeof(double*), hipMemcpyHostToDevice));
-        if (!c->d_small_ticket) {
-            TRY(dev_alloc(c, &c->d_small_ticket, 1));
-            HIP_TRY(c, hipMemset(c->d_small_ticket, 0, sizeof(unsigned)));
-        }
         c->small_tabs_ready = true;
     }
+    TRY(ensure_small_sweep_tabs(c));
     for (int g : gps)
         if (!c->kspec[g].uploaded) TRY(launch_fill(c, c->kspec[g], c->K[g]));
-    TRY(small_prior(c, c->tab_setup, c->d_slotgp_setup, c->d_kinv_out, nj, c->d_info));    // (clears its info words itself)
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, (size_t)c->nslot * sizeof(int), c->stream));    // (the kernels only raise the verdicts)
+    TRY(small_prior(c, c->tab_setup, c->d_slotgp_setup, c->d_kinv_out, nj, c->d_info));
     c->factored = true;
     if (!sync) return GPRN_OK;                             // gprn_elbocalc reads the pivot verdicts with its own results
     int first_info = 0;
@@ -1009,6 +1029,8 @@ static int factor_priors_impl(gprn_ctx* c)
     if (small_applies(c) && c->world == 1) return factor_priors_small(c);
     TRY(build_tables(c));
     TRY(ensure_tasks(c));
+    c->small_tabs_ready = false;               // (tab_setup gets this path's rows; Kinv[j] may be allocated below)
+    c->small_sweep_ready = false;
     c->info_gp = -1;
     const size_t nn = (size_t)c->ld * c->ld;
     HIP_TRY(c, hipMemsetAsync(c->d_logdetK, 0, c->G * sizeof(double), c->stream));
@@ -1106,6 +1128,7 @@ static int small_sweep(gprn_ctx* c, const double* mu_in, const double* var_in, d
     c->d_scal = scal;
     c->d_logdetB = scal; c->d_trBinv = scal + c->G; c->d_muKmu = scal + 2 * (size_t)c->G; c->d_q1 = scal + 3 * (size_t)c->G;
     const int* done = loop ? loop->ctl : nullptr;
+    TRY(ensure_small_sweep_tabs(c));
     c->d_ptrs = c->tab_node; c->slot0 = 0; c->d_info_cur = c->d_info + (size_t)c->nslot;
     TRY(small_phase(c, false, c->d_slotgp_node, (int)c->loc_nodes.size(), mu_in, var_in, mu_out, var_out, done));
     c->d_ptrs = c->tab_weight; c->slot0 = (int)c->loc_nodes.size(); c->d_info_cur = c->d_info + 2 * (size_t)c->nslot;
@@ -1272,7 +1295,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         HIP_TRY(c, hipMemcpyAsync(c->d_mu_save, c->d_mu, dn, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_var_save, c->d_var, dn, hipMemcpyDeviceToDevice, c->stream));
     }
-    if (!small) HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
     // The end of a sweep -- mu_w^T K_w^-1 mu_w (one pass over the six L_K^-1), the ELBO assembly and the wait for the
     // Q1 traces, some 150 us on the chain stream -- reads only what the sweep has left behind, and the next sweep's node
     // phase reads none of its results: inside a call of several sweeps it runs beside that phase, on the bulk stream,
@@ -1434,6 +1457,8 @@ static int elbocalc_small(gprn_ctx* c, const ElboIo& io, int max_iter, std::vect
         c->have_muvar = true;
     }
     if (!c->have_yres || !c->have_jit || !c->have_muvar) return bad(c, "elbocalc: y_resid, jitters and the state must be given or set before");
+    // (the pivot verdicts are raised by the kernels and cleared here, once per call: the set-up's row by the set-up)
+    HIP_TRY(c, hipMemsetAsync(c->d_info + (io.do_setup ? (size_t)c->nslot : 0), 0, (io.do_setup ? 2 : 3) * (size_t)c->nslot * sizeof(int), c->stream));
     if (io.do_setup) TRY(factor_priors_small(c, false));
     else if (!c->factored) return bad(c, "elbocalc: no set-up yet (do_setup = 0)");
     HIP_TRY(c, hipMemsetAsync(c->d_loop_ctl, 0, 4 * sizeof(int), c->stream));
@@ -1445,7 +1470,10 @@ static int elbocalc_small(gprn_ctx* c, const ElboIo& io, int max_iter, std::vect
     double* const hb = po + 4 * d;
     int* const ctl = reinterpret_cast<int*>(hb + K);
     int* const h_info = reinterpret_cast<int*>(hb + K + 2);
-    int s = 0, iter = 0, done = 0;
+    // Quirk Q7: sweep 0 (the first ELBOaux call: update discarded, ELBO kept as elboArray[0], :627-628) and trip 1 are the
+    // same computation on the same input -- it runs once, as trip 1, and its value is entered twice.  max_iter = 0 is the
+    // one case that enqueues sweep 0.
+    int s = max_iter >= 1 ? 1 : 0, iter = 0, done = 0;
     *conv = 0; *info = 0; c->info_gp = -1;
     hist.clear();
     while (!done && s <= max_iter) {
@@ -1470,7 +1498,8 @@ static int elbocalc_small(gprn_ctx* c, const ElboIo& io, int max_iter, std::vect
         done = ctl[0];
         iter = ctl[1];
         *conv = ctl[2];
-        const int ran = done ? std::min(nb, iter - s0 + 1) : nb;   // sweeps of the batch that were not no-ops
+        const int ran = done ? std::min(nb, ctl[3] - s0 + 1) : nb;   // sweeps of the batch that were not no-ops
+        if (s0 == 1 && ran > 0) hist.push_back(hb[0]);               // elboArray[0] == elboArray[1]
         for (int i = 0; i < ran; ++i) hist.push_back(hb[i]);
         for (int ph = 0; ph <= 2 && *info == 0; ++ph) {             // (row 0: the set-up's verdicts, slots = nodes then weights)
             if (ph == 0 && !io.do_setup) continue;

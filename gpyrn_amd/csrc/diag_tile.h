@@ -373,8 +373,10 @@ struct DiagFromTile {
     __device__ __forceinline__ double operator()(int row, int col) const { return Bt[(size_t)row * ld + col]; }
 };
 
+// nph: sub-tile columns (phases) that hold data -- beyond them the tile is its identity padding, whose factor and inverse
+// are the identity again (diag_identity_tail writes it); every wave of the workgroup gets the same value
 template <int W, class LOAD>
-__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load)
+__device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int nph)
 {
     // this wave's sub-tile rows (-1 = none): equal update counts
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
@@ -407,15 +409,20 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     lds_barrier();                                  // (the pivot wave factored sub-tile 0 in between)
     DG_STAMP(NSB, 3);
 
-    diag_phase<W, 0>(acc, L, Bt, Xt, ld); diag_phase<W, 1>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 2>(acc, L, Bt, Xt, ld); diag_phase<W, 3>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 4>(acc, L, Bt, Xt, ld); diag_phase<W, 5>(acc, L, Bt, Xt, ld);
-    diag_phase<W, 6>(acc, L, Bt, Xt, ld); diag_phase<W, 7>(acc, L, Bt, Xt, ld);
+    // (uniform branches around straight-line phases: every index into acc stays a compile-time constant)
+    diag_phase<W, 0>(acc, L, Bt, Xt, ld);
+    if (nph > 1) diag_phase<W, 1>(acc, L, Bt, Xt, ld);
+    if (nph > 2) diag_phase<W, 2>(acc, L, Bt, Xt, ld);
+    if (nph > 3) diag_phase<W, 3>(acc, L, Bt, Xt, ld);
+    if (nph > 4) diag_phase<W, 4>(acc, L, Bt, Xt, ld);
+    if (nph > 5) diag_phase<W, 5>(acc, L, Bt, Xt, ld);
+    if (nph > 6) diag_phase<W, 6>(acc, L, Bt, Xt, ld);
+    if (nph > 7) diag_phase<W, 7>(acc, L, Bt, Xt, ld);
 }
 
 template <class LOAD>
 __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int* __restrict__ info, int slot,
-                                           int pivot0)
+                                           int pivot0, int nph)
 {
     DG_STAMP(NSB, 0);
     {   // sub-tile (0,0) straight from memory and factored while the compute waves still fetch theirs
@@ -431,7 +438,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
     lds_barrier();
     DG_STAMP(NSB, 3);
 #pragma unroll 1
-    for (int kb = 0; kb < NSB; ++kb) {
+    for (int kb = 0; kb < nph; ++kb) {
         const double* xd = L.XD + (kb & 1) * 16 * PP;
         const double* pa = L.PA;
         const int n = kb + 1;
@@ -463,21 +470,47 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 
 // potrf + inverse of a 128x128 tile whose entries `load(row, col)` supplies: L (lower) -> Bt, X = L^-1 -> Xt;
 // `lds`: DIAG_LDS_DOUBLES doubles.  All 256 threads of the workgroup call it.
+// Sub-tile columns kb >= nph of a tile whose data end before them: identity padding in, identity out -- what the phases
+// kb >= nph of the full schedule would have stored (they multiply and subtract exact zeros): column kb of L (lower part:
+// ones on the diagonal), row block kb of X (zeros left of its diagonal sub-tile, the identity on it) and zeros in the
+// mirror block above the diagonal.  All 256 threads.
+__device__ __forceinline__ void diag_identity_tail(gptr_t Bt, gptr_t Xt, int ld, int nph)
+{
+    const int tid = threadIdx.x;
+    for (int kb = nph; kb < NSB; ++kb) {
+        const int c0 = 16 * kb;
+        for (int idx = tid; idx < (128 - c0) * 16; idx += 256) {
+            const int row = c0 + idx / 16, col = c0 + idx % 16;
+            if (col <= row) Bt[(size_t)row * ld + col] = row == col ? 1.0 : 0.0;
+        }
+        for (int idx = tid; idx < 16 * (c0 + 16); idx += 256) {
+            const int r = idx / (c0 + 16), col = idx % (c0 + 16);
+            Xt[(size_t)(c0 + r) * ld + col] = col == c0 + r ? 1.0 : 0.0;
+        }
+        for (int idx = tid; idx < c0 * 16; idx += 256) {
+            const int row = idx / 16, col = c0 + idx % 16;
+            Xt[(size_t)row * ld + col] = 0.0;
+        }
+    }
+}
+
 template <class LOAD>
 __device__ __forceinline__ void diag_tile_from(double* __restrict__ lds, const LOAD& load, gptr_t Bt, gptr_t Xt, int ld,
-                                               int* __restrict__ info, int slot, int pivot0)
+                                               int* __restrict__ info, int slot, int pivot0, int nph = NSB)
 {
     const DiagLds L(lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load);
-    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load);
-    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load);
-    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0);
+    nph = __builtin_amdgcn_readfirstlane(nph < 1 ? 1 : (nph > NSB ? NSB : nph));
+    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load, nph);
+    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load, nph);
+    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load, nph);
+    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0, nph);
+    if (nph < NSB) diag_identity_tail(Bt, Xt, ld, nph);
 }
 
 // ... of the tile at Bt itself
 __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
-                                          int* __restrict__ info, int slot, int pivot0)
+                                          int* __restrict__ info, int slot, int pivot0, int nph = NSB)
 {
-    diag_tile_from(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0);
+    diag_tile_from(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0, nph);
 }

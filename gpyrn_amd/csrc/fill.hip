@@ -36,6 +36,7 @@ struct FillProgram {
 // host over the benchmark's arguments, the same as the device library's exp, in 19 instead of ~30 instructions.
 __device__ __forceinline__ double exp_neg(double x)
 {
+    const double x_in = x;
     x = fmax(x, -800.0);
     const double n = rint(x * 1.4426950408889634);
     double r = fma(n, -6.93147180369123816490e-01, x);
@@ -54,7 +55,8 @@ __device__ __forceinline__ double exp_neg(double x)
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+    // (a NaN argument -- a NaN hyper-parameter -- stays NaN as in NumPy: fmax above would have turned it into exp(-800) = 0)
+    return x_in != x_in ? x_in : ldexp(p, (int)n);
 }
 
 // sin^2(pi x), x >= 0, the only form the periodic kernels use the sine in: the distance f of x to the nearest integer is
@@ -465,19 +467,28 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val,
     return GPRN_OK;
 }
 
-// ---- many small matrices in one launch (gprn_elbocalc_batch, smalln.hip): matrix b of the launch has its own program
-// (device memory) and its own destination; one workgroup per lower 64 x 64 block as in k_fill_sym.  The three kernels that
-// carry host-computed reciprocals (SE, Periodic, QP) are dispatched to their own evaluation, so that a matrix filled here
-// has the bits of one filled by launch_fill; everything else goes through the postfix program.
-__global__ __launch_bounds__(256)
-void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restrict__ t, double* const* __restrict__ Ks,
-                      int N, int ld)
+// ---- many matrices in one launch (gprn_elbocalc_batch: smalln.hip, midn.hip): matrix b of the launch has its own program
+// (device memory) and its own destination(s); one workgroup per lower 64 x 64 block as in k_fill_sym, the same two columns x
+// 8 rows per thread.  The program comes into LDS once per workgroup; the three kernels that carry host-computed reciprocals
+// (SE, Periodic, QP) take their handful of parameters into registers and run their own instruction stream, so that a
+// matrix filled here has the bits of one filled by launch_fill; everything else goes through the postfix program.
+// (The first version read the program from global memory inside the element loop: 1.04 ms for 256 matrices of 512^2,
+// 0.5 TB/s -- profiles/r05_batch512_first_kernel_stats.txt.)  K2: a second copy of every matrix (the set-up factors a
+// copy of K in place), or null.
+template <int KID>
+__device__ __forceinline__ void fill_sym_batch_block(const FillProgram& pg, const double* __restrict__ t, double* __restrict__ K,
+                                                     double* __restrict__ K2, int N, int ld, double (*tile)[65])
 {
     constexpr int TR = 64;
-    __shared__ double tile[TR][65];
-    const FillProgram& pg = pgs[blockIdx.y];
-    double* const K = Ks[blockIdx.y];
-    const int kid = (pg.n_ops == 1 && pg.ops[0] == GPRN_OP_PUSH) ? pg.ops[1] : -1;
+    double par[4] = {0.0, 0.0, 0.0, 0.0}, aux[3] = {0.0, 0.0, 0.0};
+    if (KID >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) par[i] = pg.par[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) aux[i] = pg.aux[i];
+    }
+    const int nugget = pg.nugget;
+    const double nugget_val = pg.nugget_val;
     const int L = blockIdx.x;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= L) ++bi;
@@ -487,14 +498,10 @@ void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restr
     const double tn0 = (n < N) ? t[n] : 0.0, tn1 = (n + 1 < N) ? t[n + 1] : 0.0;
     const int row0 = bi * 64;
     auto eval = [&](double ti, double tj, bool diag) {
-        switch (kid) {
-        case GPRN_K_SE: return eval_any<GPRN_K_SE>(pg, ti, tj, diag);
-        case GPRN_K_PERIODIC: return eval_any<GPRN_K_PERIODIC>(pg, ti, tj, diag);
-        case GPRN_K_QP: return eval_any<GPRN_K_QP>(pg, ti, tj, diag);
-        default: return eval_program(pg, ti, tj, diag);
-        }
+        if constexpr (KID >= 0) return eval_kernel(KID, par, ti, tj, diag, aux);
+        else return eval_program(pg, ti, tj, diag);
     };
-#pragma unroll 1
+#pragma unroll 2
     for (int i = 0; i < TR / 8; ++i) {
         const int r = ty + 8 * i, m = row0 + r;
         const double tm = (m < N) ? t[m] : 0.0;
@@ -502,12 +509,13 @@ void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restr
         double v1 = eval(tm, tn1, m == n + 1);
         if (m == n || m == n + 1) {
             double d = (m == n) ? v0 : v1;
-            if (pg.nugget) d += pg.nugget_val;
+            if (nugget) d += nugget_val;
             if (m == n) v0 = d; else v1 = d;
         }
         if (m >= N || n >= N) v0 = (m == n) ? 1.0 : 0.0;
         if (m >= N || n + 1 >= N) v1 = (m == n + 1) ? 1.0 : 0.0;
         *(double2*)(K + (size_t)m * ld + n) = make_double2(v0, v1);
+        if (K2) *(double2*)(K2 + (size_t)m * ld + n) = make_double2(v0, v1);
         tile[r][2 * tx] = v0;
         tile[r][2 * tx + 1] = v1;
     }
@@ -516,7 +524,33 @@ void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restr
     constexpr int CP = TR / 2;
     for (int idx = threadIdx.x; idx < 64 * CP; idx += 256) {
         const int c = idx / CP, rp = idx % CP;
-        *(double2*)(K + (size_t)(bj * 64 + c) * ld + row0 + 2 * rp) = make_double2(tile[2 * rp][c], tile[2 * rp + 1][c]);
+        const double2 v = make_double2(tile[2 * rp][c], tile[2 * rp + 1][c]);
+        *(double2*)(K + (size_t)(bj * 64 + c) * ld + row0 + 2 * rp) = v;
+        if (K2) *(double2*)(K2 + (size_t)(bj * 64 + c) * ld + row0 + 2 * rp) = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_fill_sym_batch(const FillProgram* __restrict__ pgs, const double* __restrict__ t, double* const* __restrict__ Ks,
+                      double* const* __restrict__ K2s, int N, int ld)
+{
+    __shared__ double tile[64][65];
+    __shared__ FillProgram spg;
+    {
+        const int* src = reinterpret_cast<const int*>(pgs + blockIdx.y);
+        int* dst = reinterpret_cast<int*>(&spg);
+        for (int i = threadIdx.x; i < (int)(sizeof(FillProgram) / sizeof(int)); i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    double* const K = Ks[blockIdx.y];
+    double* const K2 = K2s ? K2s[blockIdx.y] : nullptr;
+    // (uniform per workgroup: a scalar branch)
+    const int kid = (spg.n_ops == 1 && spg.ops[0] == GPRN_OP_PUSH && spg.ops[2] == 0) ? spg.ops[1] : -1;
+    switch (kid) {
+    case GPRN_K_SE: fill_sym_batch_block<GPRN_K_SE>(spg, t, K, K2, N, ld, tile); break;
+    case GPRN_K_PERIODIC: fill_sym_batch_block<GPRN_K_PERIODIC>(spg, t, K, K2, N, ld, tile); break;
+    case GPRN_K_QP: fill_sym_batch_block<GPRN_K_QP>(spg, t, K, K2, N, ld, tile); break;
+    default: fill_sym_batch_block<-1>(spg, t, K, K2, N, ld, tile);
     }
 }
 
@@ -535,13 +569,13 @@ bool fill_program_with(const KernelSpec& ks, const double* params, void* dst)
 }
 
 // n_matrices matrices of the context's N (ld = 128 T) from d_programs[i] into d_Ks[i]
-int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices)
+int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices, double* const* d_K2s)
 {
     if (n_matrices <= 0) return GPRN_OK;
     prof_begin(c, GPRN_T_FILL);
     const int nb = c->ld / 64;
     hipLaunchKernelGGL(k_fill_sym_batch, dim3(nb * (nb + 1) / 2, n_matrices), dim3(256), 0, c->stream,
-                       (const FillProgram*)d_programs, c->d_time, d_Ks, c->N, c->ld);
+                       (const FillProgram*)d_programs, c->d_time, d_Ks, d_K2s, c->N, c->ld);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;

@@ -244,6 +244,7 @@ struct gprn_ctx {
     void* small_batch = nullptr;     // SmallBatchMem (smalln.hip): buffers of gprn_elbocalc_batch
     size_t pin_in_cap = 0, pin_out_cap = 0;
     bool small_tabs_ready = false;   // the set-up's tables for this problem are on the device (factor_priors_small)
+    bool small_sweep_ready = false;  // ... and what a sweep of the small path reads beside the phase tables (ensure_small_sweep_tabs)
     // ---- many evaluations side by side above one tile (midn.hip): a worker context holds the matrices and states of a
     // chunk of evaluations; its kernels find an evaluation's arrays through `ev`
     EvalMap ev = {nullptr, 0, 0, 0, 0};
@@ -266,7 +267,8 @@ int launch_fill(gprn_ctx* c, const KernelSpec& ks, double* K, double nugget_val 
 // many small matrices in one launch (fill.hip; gprn_elbocalc_batch)
 size_t fill_program_bytes();
 bool fill_program_with(const KernelSpec& ks, const double* params, void* dst);
-int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices);
+int launch_fill_batch(gprn_ctx* c, const void* d_programs, double* const* d_Ks, int n_matrices,
+                      double* const* d_K2s = nullptr);      // d_K2s: a second copy of every matrix, or null
 int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const double* d_tstar,
                      int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)

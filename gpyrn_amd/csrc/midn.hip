@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #define MB_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
@@ -38,13 +39,13 @@ struct MidBatch {
     double *q1_scratch = nullptr;     // [cap q (q - 1) / 2][ld]
     void* programs = nullptr;         // [cap][G] fill programs
     // device tables, one allocation: pointers first, then ints
-    double** d_ptr_block = nullptr;   // kptr [cap G] | tab_setup [cap G][4] | tab_kinv [cap (q-1)][4] | tab_node [cap q][4] | tab_weight [cap qp][4]
+    double** d_ptr_block = nullptr;   // kptr [cap G] | kptr2 [cap G] | tab_setup [cap G][4] | tab_kinv [cap (q-1)][4] | tab_node [cap q][4] | tab_weight [cap qp][4]
     int* d_int_block = nullptr;       // gp_setup [cap G] | ev_setup [cap G] | gp_node, ev_node [cap q] | gp_weight, ev_weight [cap qp] | evals [cap]
     size_t n_ptr = 0, n_int = 0;
     char *pin_in = nullptr, *pin_out = nullptr, *pin_tab = nullptr;
     size_t pin_in_bytes = 0, pin_out_bytes = 0, pin_tab_bytes = 0;
     // offsets into the blocks
-    size_t o_kptr = 0, o_setup = 0, o_kinv = 0, o_node = 0, o_weight = 0;
+    size_t o_kptr = 0, o_kptr2 = 0, o_setup = 0, o_kinv = 0, o_node = 0, o_weight = 0;
     size_t i_gp_setup = 0, i_ev_setup = 0, i_gp_node = 0, i_ev_node = 0, i_gp_weight = 0, i_ev_weight = 0, i_evals = 0;
 };
 
@@ -169,7 +170,8 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
     // ---- tables
     const size_t qp = (size_t)q * p;
     m->o_kptr = 0;
-    m->o_setup = m->o_kptr + nslot;
+    m->o_kptr2 = m->o_kptr + nslot;
+    m->o_setup = m->o_kptr2 + nslot;
     m->o_kinv = m->o_setup + nslot * GPRN_NBUF;
     m->o_node = m->o_kinv + (size_t)cap * (q - 1) * GPRN_NBUF;
     m->o_weight = m->o_node + (size_t)cap * q * GPRN_NBUF;
@@ -195,6 +197,7 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
             for (int g = 0; g < G; ++g) {
                 const size_t s = (size_t)b * G + g;
                 hp[m->o_kptr + s] = m->K + s * nn;
+                hp[m->o_kptr2 + s] = m->Bw + s * nn;          // (the set-up factors a copy of K in place: the fill writes both)
                 double** row = hp + m->o_setup + s * GPRN_NBUF;
                 row[BUF_B] = m->Bw + s * nn; row[BUF_X] = m->KL + s * nn; row[BUF_K] = m->K + s * nn; row[BUF_KLINV] = m->KL + s * nn;
                 hi[m->i_gp_setup + s] = g;
@@ -281,12 +284,31 @@ static int mid_sweep(gprn_ctx* w, MidBatch* m, int nA)
     MB_TRY(mid_phase(w, m, false, nA));
     if (m->q > 1) {
         // quirk Q1 (:1039-1041): lower(B_k^-1) = lower(X^T X) of every node but the last into its B buffer (L is not needed
-        // any more: log det B is taken), then <K_j^-1, Sigma_k> for j > k
-        w->d_ptrs = m->d_ptr_block + m->o_node;
-        MB_TRY(lauum_lower(w, (m->q - 1) * nA));
-        MB_TRY(vec_q1_evals(w, m->d_int_block + m->i_ev_node, m->Kinv, nA, m->q1_scratch));
+        // any more: log det B is taken), then <K_j^-1, Sigma_k> for j > k.  Nothing in the weight phase reads it: it runs
+        // beside that phase on the bulk stream, handed to its factorisation (behind the first diagonal block, as run_phase
+        // does it for one evaluation), and is joined before the ELBO assembly.
+        HIP_TRY(w, hipEventRecord(w->ev_nodes, w->stream));
+        w->chain_started = [w, m, nA]() -> int {
+            double** const cur = w->d_ptrs;
+            const int cur_slot0 = w->slot0;
+            const int* const cur_ev = w->ev.slot_eval;
+            HIP_TRY(w, hipStreamWaitEvent(w->stream2, w->ev_nodes, 0));
+            w->d_ptrs = m->d_ptr_block + m->o_node;
+            int rc = lauum_lower(w, (m->q - 1) * nA, w->stream2);
+            if (!rc) rc = vec_q1_evals(w, m->d_int_block + m->i_ev_node, m->Kinv, nA, m->q1_scratch, w->stream2);
+            w->d_ptrs = cur; w->slot0 = cur_slot0; w->ev.slot_eval = cur_ev;
+            if (rc) return rc;
+            HIP_TRY(w, hipEventRecord(w->ev_q1, w->stream2));
+            return GPRN_OK;
+        };
     }
     MB_TRY(mid_phase(w, m, true, nA));
+    if (w->chain_started) {                              // (no factorisation took it along)
+        std::function<int()> f;
+        f.swap(w->chain_started);
+        MB_TRY(f());
+    }
+    if (m->q > 1) HIP_TRY(w, hipStreamWaitEvent(w->stream, w->ev_q1, 0));
     MB_TRY(mid_prior_term(w, m, false, nA));
     MB_TRY(mid_prior_term(w, m, true, nA));
     return vec_elbo_evals(w, m->d_int_block + m->i_evals, nA, w->d_out, w->d_scal_base, w->d_elbo_part);
@@ -302,7 +324,7 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
 {
     gprn_ctx* w = m->w;
     const int B = io.n, G = m->G, p = m->p, q = m->q, N = m->N;
-    const size_t nn = (size_t)m->ld * m->ld, d = (size_t)(p + 1) * q * N, pn = (size_t)p * N, pb = fill_program_bytes();
+    const size_t d = (size_t)(p + 1) * q * N, pn = (size_t)p * N, pb = fill_program_bytes();
     hipStream_t st = w->stream;
     // ---- inputs through the pinned buffer: programs | y - mean | variance | mu | var
     char* const pg_h = m->pin_in;
@@ -334,8 +356,8 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     // ---- set-up (meanfield.py:619-622): every evaluation's G covariance matrices in one launch, chol(K) and its inverse for
     // all of them in one factorisation, log det K, and K_j^-1 = X^T X for the nodes quirk Q1 needs
     w->ev.slot_eval = m->d_int_block + m->i_ev_setup;
-    MB_TRY(launch_fill_batch(w, m->programs, (double* const*)(m->d_ptr_block + m->o_kptr), B * G));
-    HIP_TRY(c, hipMemcpyAsync(m->Bw, m->K, (size_t)B * G * nn * sizeof(double), hipMemcpyDeviceToDevice, st));
+    MB_TRY(launch_fill_batch(w, m->programs, (double* const*)(m->d_ptr_block + m->o_kptr), B * G,
+                             (double* const*)(m->d_ptr_block + m->o_kptr2)));
     HIP_TRY(c, hipMemsetAsync(w->d_info, 0, 3 * (size_t)w->nslot * sizeof(int), st));
     w->d_ptrs = m->d_ptr_block + m->o_setup;
     w->slot0 = 0;

@@ -107,10 +107,12 @@ __device__ __forceinline__ void small_lower_matvec(const double* M, int ld, int 
 }
 
 // B = L L^T, X = L^-1 for T in {1, 2} tiles by one workgroup; tiles at Bm / Xm (leading dimension ld)
+// N: rows that hold data -- the 16-column phases of a diagonal tile beyond them are identity padding and are not run
+// (diag_tile's nph: at the reference's own N = 25 and 45 two and three of eight phases hold everything)
 template <int T>
-__device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm, int ld, int* info, int slot)
+__device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm, int ld, int* info, int slot, int N)
 {
-    diag_tile(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0);
+    diag_tile(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0, T == 1 ? (N + 15) / 16 : NSB);
     if (T == 1) return;
     sm_publish();
     const size_t t10 = (size_t)GPRN_TILE * ld, t11 = t10 + GPRN_TILE;
@@ -122,7 +124,7 @@ __device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm
     __syncthreads();
     tile_mma<128, 128, 2, 2, 0>(lds, Bm + t10, Xm, (gptr_t)(Xm + t10), ld, 0, 1, CM_SETNEG, GPRN_TILE, 0, 0);
     sm_publish();
-    diag_tile(lds, (gptr_t)(Bm + t11), (gptr_t)(Xm + t11), ld, info, slot, GPRN_TILE);
+    diag_tile(lds, (gptr_t)(Bm + t11), (gptr_t)(Xm + t11), ld, info, slot, GPRN_TILE, (N - GPRN_TILE + 15) / 16);
     sm_publish();
     // X_10 = X_11 R_10 (in place)
     tile_mma<128, 128, 2, 2, 2>(lds, Xm + t11, Xm + t10, (gptr_t)(Xm + t10), ld, 0, 1, CM_SET, GPRN_TILE, 0, 0);
@@ -173,7 +175,8 @@ __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
     if (a.done && *a.done) return;                   // (uniform)
     const int slot = blockIdx.x, gp = a.slot_gp[slot];
     const int N = a.N, ld = a.ld, p = a.p, q = a.q, tid = threadIdx.x;
-    if (tid == 0) a.info[slot] = 0;                  // (set by the pivot wave of diag_tile, long after this)
+    // (a.info[slot]: only ever RAISED here, by the pivot wave of diag_tile; the host clears the rows once per call, so a
+    // verdict of an early sweep of the call is still there when the host looks, as in the launch schedule)
 #define SM_STAMP(i) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     SM_STAMP(0);
     double* const Bm = a.ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
@@ -241,8 +244,8 @@ __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
     if (T > 1) sm_publish();
     SM_STAMP(2);
     // ---- B = L L^T, X = L^-1
-    if (T == 1) diag_tile_from(lds, DiagFromK{Km, sS, ld, N}, (gptr_t)Bm, (gptr_t)Xm, ld, a.info, slot, 0);
-    else small_factor<T>(lds, Bm, Xm, ld, a.info, slot);
+    if (T == 1) diag_tile_from(lds, DiagFromK{Km, sS, ld, N}, (gptr_t)Bm, (gptr_t)Xm, ld, a.info, slot, 0, (N + 15) / 16);
+    else small_factor<T>(lds, Bm, Xm, ld, a.info, slot, N);
     SM_STAMP(3);
     sm_publish();
     SM_STAMP(4);
@@ -325,9 +328,11 @@ struct SmallTailArgs {
     unsigned* ticket;
     // gprn_elbocalc (or null): the loop of meanfield.py:626-649 on the device.  ctl: [0] done, [1] iterNumber, [2] converged;
     // hist: the batch's ELBO values, this sweep's at hist[hist_at]; last3: the three latest values of the loop
-    int* ctl;
+    int* ctl;                   // [0] done, [1] iterNumber, [2] converged, [3] the last sweep that ran
     double *hist, *last3;
     int sweep, hist_at, max_iter;
+    const int* info;            // the pivot verdicts of this evaluation (set-up, node phase, weight phase), n_info words
+    int n_info;
 };
 
 // log-likelihood terms of k_loglike_partial for block 0 (with N <= 256 the other 31 blocks of that kernel are empty
@@ -456,8 +461,18 @@ __device__ __forceinline__ void small_tail_body(const SmallTailArgs& a)
             // update is not); sweep s >= 1 is loop trip s.  Stop rule :640-643 on the last three values: NumPy's
             // np.std / np.mean of three numbers, operation by operation (no contraction: every product and sum rounds)
             a.hist[a.hist_at] = elbo;
-            if (a.sweep >= 1) {
-                const double e0 = a.last3[1], e1 = a.last3[2], e2 = elbo;
+            a.ctl[3] = a.sweep;
+            // a matrix that was not positive definite, or a state that has left the finite numbers: NaN stays NaN (jax's
+            // cholesky semantics, meanfield.py:71-89), the stop rule never fires on it and the reference's loop runs to
+            // max_iter to return it -- so does this one, without the sweeps
+            bool failed = !(elbo == elbo);
+            for (int i = 0; i < a.n_info && !failed; ++i) failed = a.info[i] > 0;
+            if (failed) {
+                a.ctl[0] = 1; a.ctl[1] = a.max_iter; a.ctl[2] = 0;
+            } else if (a.sweep >= 1) {
+                // (quirk Q7: elboArray[0], the discarded first call's value, IS trip 1's -- same input, same arithmetic; the
+                // host enqueues sweep 0 only for max_iter = 0)
+                const double e0 = a.last3[1], e1 = a.sweep == 1 ? elbo : a.last3[2], e2 = elbo;
                 a.last3[0] = e0; a.last3[1] = e1; a.last3[2] = e2;
                 a.ctl[1] = a.sweep;
                 bool stop = false;
@@ -495,13 +510,12 @@ __device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
     double* const Bm = a.ptrs[(size_t)job * GPRN_NBUF + BUF_B];
     double* const Xm = a.ptrs[(size_t)job * GPRN_NBUF + BUF_X];
     const double* const Km = a.ptrs[(size_t)job * GPRN_NBUF + BUF_K];
-    if (tid == 0) a.info[job] = 0;
-    if (Bm != Km) {
+    if (Bm != Km) {                                  // (a.info[job]: raised here, cleared by the host before the launch)
         for (int i = tid * 2; i < ld * ld; i += 512)
             *reinterpret_cast<double2*>(Bm + i) = *reinterpret_cast<const double2*>(Km + i);
         sm_publish();
     }
-    small_factor<T>(lds, Bm, Xm, ld, a.info, job);
+    small_factor<T>(lds, Bm, Xm, ld, a.info, job, N);
     sm_publish();
     double acc = 0.0;
     for (int n = tid; n < N; n += 256) acc += log(Bm[(size_t)n * ld + n]);
@@ -585,7 +599,8 @@ int small_tail(gprn_ctx* c, double* out4, double* scal, const double* mu, const 
                     c->N, c->ld, c->p, c->q, c->G, mu, var, c->d_yraw, c->d_variance, c->d_s,
                     (double* const*)c->d_kinv_tab, c->d_u, c->d_logdetK, scal, out4, c->d_small_ticket,
                     loop ? loop->ctl : nullptr, loop ? loop->hist : nullptr, loop ? loop->last3 : nullptr,
-                    loop ? loop->sweep : 0, loop ? loop->hist_at : 0, loop ? loop->max_iter : 0};
+                    loop ? loop->sweep : 0, loop ? loop->hist_at : 0, loop ? loop->max_iter : 0,
+                    c->d_info, 3 * c->nslot};
     if (c->T == 1) hipLaunchKernelGGL(k_small_tail<1>, dim3(nn + nw), dim3(256), 0, c->stream, a);
     else hipLaunchKernelGGL(k_small_tail<2>, dim3(nn + nw), dim3(256), 0, c->stream, a);
     prof_end(c);
@@ -751,7 +766,7 @@ static int small_batch_ensure(gprn_ctx* c, int n_eval)
                 (double* const*)d_node, (double* const*)d_weight, m->gp_ids, m->gp_ids + q, q, G - q, N, ld, p, q, G,
                 mu_out, var_out, c->d_yraw, variance, vec(1, 0), (double* const*)d_kinv_tab, vec(4, 0), m->logdetK + (size_t)b * G,
                 scal, m->out4 + (size_t)b * 4, m->ticket + b, ctl, m->hist + (size_t)b * (SB_K + 4),
-                m->hist + (size_t)b * (SB_K + 4) + SB_K, 0, 0, 0};
+                m->hist + (size_t)b * (SB_K + 4) + SB_K, 0, 0, 0, info, 3 * G};
         }
         pr[b] = SmallPriorArgs{(double* const*)d_setup, m->gp_ids, (double* const*)d_kinv_out, N, ld, m->logdetK + (size_t)b * G, info};
     }
@@ -819,6 +834,7 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
     HIP_TRY(c, hipMemcpyAsync(m->state, mu0_h, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(m->state + (size_t)cap * d, v0_h, (size_t)B * d * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync(m->ctl, 0, (size_t)B * 4 * sizeof(int), st));
+    HIP_TRY(c, hipMemsetAsync(m->info, 0, (size_t)B * 3 * G * sizeof(int), st));    // (the kernels only raise them)
     // ---- set-up: every evaluation's G covariance matrices in one launch, their factors in another
     SB_TRY(launch_fill_batch(c, m->programs, (double* const*)m->kptr_dense, B * G));
     prof_begin(c, GPRN_T_DIAG);
@@ -833,7 +849,9 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
     double* const st_h = (double*)(((uintptr_t)(info_h + (size_t)cap * 3 * G) + 63) & ~(uintptr_t)63);
     std::vector<char> was_done(B, 0);
     for (int b = 0; b < B; ++b) { elbo[b] = 0.0; iters[b] = 0; conv[b] = 0; info[b] = 0; }
-    int s = 0;
+    // (quirk Q7: sweep 0 -- the first ELBOaux call, whose update is discarded -- and trip 1 are the same computation on the
+    // same input; it runs once, as trip 1.  Only max_iter = 0 enqueues sweep 0.)
+    int s = max_iter >= 1 ? 1 : 0;
     bool all_done = false;
     const int q = c->q;
     while (!all_done && s <= max_iter) {
@@ -858,18 +876,21 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         for (int b = 0; b < B; ++b) {
             if (was_done[b]) continue;
             const int* cb = ctl_h + (size_t)b * 4;
-            const int ran = cb[0] ? std::min(nb, cb[1] - s0 + 1) : nb;
+            const int ran = cb[0] ? std::min(nb, cb[3] - s0 + 1) : nb;
             if (ran > 0) elbo[b] = hist_h[(size_t)b * (SB_K + 4) + ran - 1];
             iters[b] = cb[1];
             conv[b] = cb[2];
             for (int k = 0; k < 3 * G && !info[b]; ++k)
                 if (info_h[(size_t)b * 3 * G + k] > 0) info[b] = info_h[(size_t)b * 3 * G + k];
+            if (info[b]) elbo[b] = NAN;                       // (jax's cholesky: NaN from the failed pivot on, no exception)
             if (cb[0]) was_done[b] = 1;
             else all_done = false;
         }
     }
     if (mu_out && var_out) {
-        HIP_TRY(c, hipMemcpyAsync(st_h, m->state, 4 * (size_t)cap * d * sizeof(double), hipMemcpyDeviceToHost, st));
+        for (int k = 0; k < 4; ++k)                            // (B evaluations of each copy, not the buffers' capacity)
+            HIP_TRY(c, hipMemcpyAsync(st_h + (size_t)k * cap * d, m->state + (size_t)k * cap * d, (size_t)B * d * sizeof(double),
+                                      hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipStreamSynchronize(st));
         for (int b = 0; b < B; ++b) {
             const bool in_b = iters[b] >= 1 && (iters[b] & 1);     // odd trips wrote copy B

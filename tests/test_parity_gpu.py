@@ -437,6 +437,107 @@ def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb):
     _assert_default_schedule(gs._backend())
 
 
+@pytest.mark.parametrize('n,p,q', [(60, 2, 2), (45, 1, 1)])
+def test_small_path_after_a_set_up_through_the_launch_schedule(n, p, q):
+    """a set-up that ran through the launch schedule (option "small_path" = 0, or gprn_keep_sigma at
+    that time) followed by sweeps on the small path -- the switch flipped in between -- used to read a null ticket and, for
+    q > 1, a null table of K_j^-1 pointers.  Either set-up now serves either kind of sweep: same values as the all-small
+    and the all-launch runs, for gprn_sweep and for gprn_elbocalc without a new set-up."""
+    t, ys, es = synth.rv_series(n, p)
+    spec = synth.component_spec(p, q, 'QP')
+
+    def run(setup_small, sweep_small, through_elbocalc):
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        ctx = g._backend()
+        ctx.option('small_path', setup_small)
+        ctx = g._setup_device(nodes, weights, means, jit)
+        assert g.last_info == 0
+        mu0, var0 = g._initMuVar(nodes, weights, jit)
+        ctx.option('small_path', sweep_small)
+        if through_elbocalc:
+            hist, it, conv, info, mu, var = ctx.elbocalc(7, setup=False, mu=mu0, var=var0)
+            assert info == 0
+            return np.array(hist), mu, var
+        ctx.set_muvar(mu0, var0)
+        e, parts, info = ctx.sweep(3, commit=True)
+        assert info == 0
+        mu, var = ctx.get_muvar()
+        return e, mu, var
+
+    for through in (False, True):
+        ref = run(1, 1, through)
+        for setup_small, sweep_small in ((0, 1), (1, 0), (0, 0)):
+            got = run(setup_small, sweep_small, through)
+            np.testing.assert_allclose(got[0], ref[0], rtol=1e-9)
+            _cases.assert_state('set-up %d / sweeps %d' % (setup_small, sweep_small), got[1], ref[1], got[2], ref[2], tol=1e-9)
+
+
+@pytest.mark.parametrize('n', [60, 300])
+def test_a_failed_evaluation_leaves_a_batch_at_once(n):
+    """an evaluation whose factorisation fails (here: a NaN jitter, so no pivot of B is positive) has a
+    NaN ELBO that never meets the stop rule; the reference's loop would run to max_iter and return NaN.  The batch returns
+    the same -- info > 0, NaN, not converged -- without the 10000 sweeps, and the evaluations beside it are untouched."""
+    import time
+    p, q, B = 2, 1, 6
+    t, ys, es = synth.rv_series(n, p)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, synth.component_spec(p, q, 'QP'))
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+    x0 = np.array(g.get_parameters(), dtype=float)
+    rng = np.random.RandomState(3)
+    sets = [x0 * (1.0 + 0.02 * rng.standard_normal(x0.size)) for _ in range(B)]
+    good = np.array(g.nELBO_batch(sets))
+    assert np.all(np.isfinite(good)) and g.last_info == 0
+    bad = [x.copy() for x in sets]
+    bad[2][-1] = np.nan                                        # a jitter: NaN variances, NaN B, no positive pivot
+    g._mu = g._var = None
+    g2 = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g2.set_components(*synth.build_components(covfunc, meanfunc, synth.component_spec(p, q, 'QP')))
+    g2.nELBO_batch(sets[:2])                                   # buffers
+    g2._mu = g2._var = None
+    t0 = time.perf_counter()
+    got = np.array(g2.nELBO_batch(bad))
+    dt = time.perf_counter() - t0
+    assert np.isnan(got[2]) and g2.last_info > 0
+    keep = [0, 1, 3, 4, 5]
+    np.testing.assert_allclose(got[keep], good[keep], rtol=1e-12)
+    assert dt < 2.0, 'the failed evaluation kept the batch sweeping (%.1f s)' % dt
+
+
+def test_nelbo_batch_takes_full_length_vectors_with_frozen_parameters():
+    """nELBO / set_parameters accept vectors of the free OR the full length (meanfield.py:223-259); with
+    frozen parameters the side-by-side form used to raise on the full-length ones instead of evaluating them."""
+    n, p, q = 60, 2, 1
+    t, ys, es = synth.rv_series(n, p)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, synth.component_spec(p, q, 'QP'))
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+    g.ELBOcalc()
+    g.freeze_parameter(name='*jitter*')
+    full0 = np.array(g.get_parameters(include_frozen=True), dtype=float)
+    free = ~g.frozen_mask
+    assert free.sum() < full0.size
+    rng = np.random.RandomState(5)
+    fulls = [full0.copy() for _ in range(4)]
+    for x in fulls:
+        x[free] *= 1.0 + 0.03 * rng.standard_normal(int(free.sum()))
+    mu_w, var_w = g._mu.copy(), g._var.copy()
+    a = np.array(g.nELBO_batch(fulls))                          # full length
+    g._mu, g._var = mu_w.copy(), var_w.copy()
+    b = np.array(g.nELBO_batch([x[free] for x in fulls]))       # free length
+    g._mu, g._var = mu_w.copy(), var_w.copy()
+    c = np.array(g.nELBO_batch([fulls[0], fulls[1][free], fulls[2], fulls[3][free]]))
+    np.testing.assert_allclose(a, b, rtol=1e-13)
+    np.testing.assert_allclose(c, b, rtol=1e-13)
+    want = []
+    for x in fulls:
+        g._mu, g._var = mu_w.copy(), var_w.copy()
+        want.append(g.nELBO(x))
+    np.testing.assert_allclose(b, want, rtol=1e-9)
+
+
 def test_small_path_reports_a_failed_pivot():
     """jnp.linalg.cholesky semantics on the small path too: a matrix that is not positive definite gives info > 0 (the
     order of the failing minor, LAPACK style) and NaN downstream, no exception (meanfield.py:71-89)."""
