@@ -22,9 +22,11 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <vector>
 
@@ -326,6 +328,14 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     const int B = io.n, G = m->G, p = m->p, q = m->q, N = m->N;
     const size_t d = (size_t)(p + 1) * q * N, pn = (size_t)p * N, pb = fill_program_bytes();
     hipStream_t st = w->stream;
+    // GPRN_BATCH_TIMERS=1 (probes): where the host's time of a chunk goes, on stderr
+    static int timers_env = -1;
+    if (timers_env < 0) { const char* e = getenv("GPRN_BATCH_TIMERS"); timers_env = e ? atoi(e) : 0; }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_mark = t_begin;
+    auto lap = [&]() { const auto now = std::chrono::steady_clock::now(); const double us = std::chrono::duration<double, std::micro>(now - t_mark).count(); t_mark = now; return us; };
+    double us_stage = 0.0, us_setup = 0.0, us_enqueue = 0.0, us_wait = 0.0, us_host = 0.0;
+    int n_sweeps = 0;
     // ---- inputs through the pinned buffer: programs | y - mean | variance | mu | var
     char* const pg_h = m->pin_in;
     double* const yres_h = (double*)(pg_h + (size_t)m->cap * G * pb);
@@ -348,6 +358,7 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     memcpy(yres_h, io.y_resid, (size_t)B * pn * sizeof(double));
     memcpy(mu0_h, io.mu, (size_t)B * d * sizeof(double));
     memcpy(v0_h, io.var, (size_t)B * d * sizeof(double));
+    us_stage = lap();
     HIP_TRY(c, hipMemcpyAsync(m->programs, pg_h, (size_t)B * G * pb, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(w->d_yres, yres_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(w->d_variance, var_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
@@ -371,6 +382,7 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     // ---- the loop of meanfield.py:626-649, per evaluation.  Quirk Q7: the first ELBOaux call (update discarded, ELBO kept
     // as elboArray[0]) and the loop's first trip are the same computation on the same input -- it runs once and its value
     // is entered twice (max_iter = 0: the sweep runs, the state the caller gave is what comes back).
+    us_setup = lap();
     std::vector<int> act(B);
     for (int b = 0; b < B; ++b) { act[b] = b; io.elbo[b] = 0.0; io.iters[b] = 0; io.conv[b] = 0; io.info[b] = 0; }
     std::vector<double> last3((size_t)3 * B, 0.0);
@@ -383,7 +395,10 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
         MB_TRY(mid_sweep(w, m, nA));
         HIP_TRY(c, hipMemcpyAsync(out_h, w->d_out, (size_t)m->cap * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(info_h, w->d_info, 3 * (size_t)w->nslot * sizeof(int), hipMemcpyDeviceToHost, st));
+        us_enqueue += lap();
         HIP_TRY(c, hipStreamSynchronize(st));
+        us_wait += lap();
+        n_sweeps += 1;
         MB_TRY(factor_check_waits(w));
         std::vector<int> next;
         next.reserve(nA);
@@ -420,6 +435,7 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
         if (next.size() != act.size()) tables_stale = true;
         act.swap(next);
         first = false;
+        us_host += lap();
     }
     if (io.mu_out && io.var_out) {
         double* const st_h = (double*)(((uintptr_t)(info_h + 3 * (size_t)w->nslot) + 63) & ~(uintptr_t)63);
@@ -433,6 +449,10 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
             memcpy(io.var_out, io.var, (size_t)B * d * sizeof(double));
         }
     }
+    if (timers_env)
+        fprintf(stderr, "[gprn] elbocalc_batch (N = %d, T = %d), %d evaluations, us: staging %.0f | set-up enqueued %.0f | %d sweeps: enqueue %.0f, "
+                        "waiting for the device %.0f, verdicts %.0f | states back %.0f | total %.0f\n", N, w->T, B, us_stage, us_setup, n_sweeps,
+                us_enqueue, us_wait, us_host, lap(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
     return GPRN_OK;
 }
 

@@ -20,9 +20,12 @@
 #include "vecops.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #define SMALL_MAXLD 256
@@ -50,12 +53,16 @@ __device__ __forceinline__ double sm_block_sum(double v, double* sh /* 4 doubles
     return r;
 }
 
-// what this workgroup wrote to global memory is visible to all of its threads (and, with the device-scope fence, to
-// the workgroups of later kernels without further ado)
+// What this workgroup wrote to global memory is visible to all of ITS threads: stores acknowledged, a workgroup-scope
+// fence (the waves of a workgroup share their CU's vector cache: nothing to write back or invalidate), the barrier.  Every
+// use below hands data to the same workgroup.  (Until round 5 this was __threadfence(): at agent scope that writes the
+// XCD's L2 back -- nothing when one evaluation's few workgroups run alone, but with 512 workgroups of a batch doing it
+// three times each on an L2 full of the phase kernels' freshly written matrices k_small_tail_b took 115 us per sweep,
+// 40 % of a batch: profiles/r05_batch_n45_breakdown.txt.)  Later kernels see everything at the kernel boundary.
 __device__ __forceinline__ void sm_publish()
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __syncthreads();
 }
 
@@ -424,13 +431,17 @@ __device__ __forceinline__ void small_tail_body(const SmallTailArgs& a)
             __syncthreads();
         }
     }
-    // ---- the last workgroup to get here assembles the ELBO (k_loglike_partial + k_elbo_final)
-    __threadfence();
+    // ---- the last workgroup to get here assembles the ELBO (k_loglike_partial + k_elbo_final).  What it reads of the
+    // others -- mu^T K^-1 mu and the Q1 traces -- thread 0 has stored: its release (agent scope: the reader may sit on
+    // another XCD) orders them before the ticket; the reader's loads of them are agent-scope atomics
     __syncthreads();
-    if (tid == 0) last = atomicAdd(a.ticket, 1u) + 1 == gridDim.x ? 1u : 0u;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        last = atomicAdd(a.ticket, 1u) + 1 == gridDim.x ? 1u : 0u;
+    }
     __syncthreads();
     if (!last) return;                              // (uniform)
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double t1, t2, t3;
     small_loglike(a, sh4, t1, t2, t3);
     if (tid == 0) {
@@ -801,9 +812,17 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         kp_total += c->kspec[g].n_params;
     }
     if (kp_total != n_kpar) { c->err = "elbocalc_batch: kernel_params has the wrong length per evaluation"; return GPRN_E_ARG; }
+    // GPRN_BATCH_TIMERS=1 (probes): where the host's time of a call goes -- staging, enqueue, waits, read-back -- on stderr
+    static int timers_env = -1;
+    if (timers_env < 0) { const char* e = getenv("GPRN_BATCH_TIMERS"); timers_env = e ? atoi(e) : 0; }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+    double us_stage = 0.0, us_enqueue = 0.0, us_wait = 0.0, us_host = 0.0;
     SB_TRY(small_batch_ensure(c, B));
     SmallBatchMem* m = (SmallBatchMem*)c->small_batch;
     const int cap = m->cap;
+    const double us_ensure = since(t_begin);
+    auto t_mark = std::chrono::steady_clock::now();
     const size_t d = (size_t)(p + 1) * c->q * N, pn = (size_t)p * N, pb = fill_program_bytes();
     // ---- inputs through the pinned buffer
     char* const pg_h = m->pin_in;
@@ -828,6 +847,7 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         memcpy(v0_h + (size_t)b * d, var + (size_t)b * d, d * sizeof(double));
     }
     hipStream_t st = c->stream;
+    us_stage = since(t_mark); t_mark = std::chrono::steady_clock::now();
     HIP_TRY(c, hipMemcpyAsync(m->programs, pg_h, (size_t)B * G * pb, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(m->yv, yres_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemcpyAsync(m->yv + (size_t)cap * pn, var_h, (size_t)B * pn * sizeof(double), hipMemcpyHostToDevice, st));
@@ -857,7 +877,8 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
     while (!all_done && s <= max_iter) {
         const int s0 = s;
         int nb = 0;
-        for (; nb < SB_K && s <= max_iter; ++nb, ++s) {
+        const int nb_max = s0 <= 1 ? 4 : SB_K;                 // (no verdict before trip 4, and most warm starts stop there)
+        for (; nb < nb_max && s <= max_iter; ++nb, ++s) {
             const int par = (s <= 1 || (s & 1)) ? 0 : 1;          // sweep 0 and trip 1 start from copy A, then they alternate
             prof_begin(c, GPRN_T_DIAG);
             hipLaunchKernelGGL((k_small_phase_b<false>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap));
@@ -871,7 +892,9 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         HIP_TRY(c, hipMemcpyAsync(ctl_h, m->ctl, (size_t)B * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(hist_h, m->hist, (size_t)B * (SB_K + 4) * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(info_h, m->info, (size_t)B * 3 * G * sizeof(int), hipMemcpyDeviceToHost, st));
+        us_enqueue += since(t_mark); t_mark = std::chrono::steady_clock::now();
         HIP_TRY(c, hipStreamSynchronize(st));
+        us_wait += since(t_mark); t_mark = std::chrono::steady_clock::now();
         all_done = true;
         for (int b = 0; b < B; ++b) {
             if (was_done[b]) continue;
@@ -886,6 +909,7 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
             if (cb[0]) was_done[b] = 1;
             else all_done = false;
         }
+        us_host += since(t_mark); t_mark = std::chrono::steady_clock::now();
     }
     if (mu_out && var_out) {
         for (int k = 0; k < 4; ++k)                            // (B evaluations of each copy, not the buffers' capacity)
@@ -898,5 +922,9 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
             memcpy(var_out + (size_t)b * d, st_h + ((in_b ? 3 : 1) * (size_t)cap + b) * d, d * sizeof(double));
         }
     }
+    if (timers_env)
+        fprintf(stderr, "[gprn] elbocalc_batch (one tile), %d evaluations, us: buffers %.0f | staging %.0f | enqueue %.0f | waiting for the device "
+                        "%.0f | verdicts %.0f | states back %.0f | total %.0f (%d launches of sweeps)\n", B, us_ensure, us_stage, us_enqueue,
+                us_wait, us_host, since(t_mark), since(t_begin), s - (max_iter >= 1 ? 1 : 0));
     return GPRN_OK;
 }

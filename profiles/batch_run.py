@@ -24,6 +24,19 @@ x0 = np.array(g.get_parameters(), dtype=float)
 rng = np.random.RandomState(1)
 xb = [x0 * (1.0 + 0.01 * rng.standard_normal(x0.size)) for _ in range(B)]
 best = None
+ctx = g._backend()
+lib_s = []
+inner = ctx.elbocalc_batch
+
+
+def timed(*a, **k):                                        # the library's share of a call (ctypes included)
+    t0 = time.perf_counter()
+    out = inner(*a, **k)
+    lib_s.append(time.perf_counter() - t0)
+    return out
+
+
+ctx.elbocalc_batch = timed
 with contextlib.redirect_stdout(io.StringIO()):
     g.nELBO(x0)
     g.nELBO_batch(xb)
@@ -31,7 +44,8 @@ with contextlib.redirect_stdout(io.StringIO()):
         t0 = time.perf_counter()
         g.nELBO_batch(xb)
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-ctx = g._backend()
+        if best is None or dt < best:
+            best, best_lib = dt, lib_s[-1]
+print('python side of the best call: %.0f us around %.0f us in gprn_elbocalc_batch' % (1e6 * (best - best_lib), 1e6 * best_lib))
 print('N=%d p=%d q=%d B=%d: %.3f ms per call, %.0f evaluations/s; flags %d fallbacks %d' % (
     N, p, q, B, 1e3 * best, B / best, ctx.option('flags'), ctx.option('fallbacks')))
