@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GPRN_HIP_LIB') or os.path.join(_HERE, 'libgprn_hip.so')
 
 GPRN_E_ARG, GPRN_E_HIP, GPRN_E_NODEV, GPRN_E_COMM, GPRN_E_NOMEM, GPRN_E_UNSUPPORTED = -1, -2, -3, -4, -5, -6
-M_K, M_KLINV, M_SIGMA = 0, 1, 2
+M_K, M_KLINV, M_SIGMA, M_BX, M_BL = 0, 1, 2, 3, 4
 T_NAMES = ('fill', 'build_B', 'diag', 'panel', 'update', 'lauum', 'vec', 'update_ahead')
 TILE = 128
 

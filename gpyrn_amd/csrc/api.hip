@@ -1663,11 +1663,20 @@ extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
     if (which == GPRN_M_K) src = c->K[gp];
     else if (which == GPRN_M_KLINV) src = c->KLinv[gp];
     else if (which == GPRN_M_SIGMA) src = c->Sig[gp];
+    else if (which == GPRN_M_BX || which == GPRN_M_BL) {
+        // the sweep's own workspaces of this latent GP: every local GP has its (B, X) pair, nodes first (build_tables)
+        const std::vector<int>& gps = gp < c->q ? c->loc_nodes : c->loc_weights;
+        for (size_t sl = 0; sl < gps.size() && c->tables_ready; ++sl)
+            if (gps[sl] == gp) {
+                const size_t slot = (gp < c->q ? 0 : c->loc_nodes.size()) + sl;
+                src = which == GPRN_M_BX ? c->wsX[slot] : c->wsB[slot];
+            }
+    }
     if (!src) return bad(c, "get_matrix: not available on this rank (or keep_sigma was off)");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy2D(out, (size_t)c->N * sizeof(double), src, (size_t)c->ld * sizeof(double),
                            (size_t)c->N * sizeof(double), c->N, hipMemcpyDeviceToHost));
-    if (which == GPRN_M_KLINV)      // strictly-upper tiles are scratch: report a clean lower factor
+    if (which == GPRN_M_KLINV || which == GPRN_M_BX || which == GPRN_M_BL)      // strictly-upper tiles are scratch: report a clean lower factor
         for (int m = 0; m < c->N; ++m)
             for (int n = m + 1; n < c->N; ++n) out[(size_t)m * c->N + n] = 0.0;
     return GPRN_OK;

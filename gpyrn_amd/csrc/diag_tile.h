@@ -32,6 +32,9 @@
 // pivot chain.  NaN for x < 0 (jnp.linalg.cholesky semantics).
 __device__ __forceinline__ double rsqrt_nr(double x)
 {
+#ifdef GPRN_EXACT_PIVOT           // (accuracy experiment: IEEE sqrt and division)
+    return __ddiv_rn(1.0, __dsqrt_rn(x));
+#endif
     double y = __builtin_amdgcn_rsq(x);
     const double hx = -0.5 * x;
     y = y * fma(hx * y, y, 1.5);
@@ -337,6 +340,12 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
             for (int s2 = 0; s2 < 4; ++s2) na[pp].v[s2] = -src.v[s2];
         }
         // column kb+1 first (published as the next panel), with it the diagonal sub-tile kb+2 for the pivot wave
+        // A DIAGONAL sub-tile (P == Q) holds the matrix' diagonal entries, ~1 in B = I + D^1/2 K D^1/2 where the update is
+        // ~d K: its four MFMA steps accumulate from zero (du) and are added once -- one rounding at the entry's magnitude
+        // per phase instead of four (the pivots' accuracy: tile_mma SYM, profiles/r05_var_accuracy.txt)
+        v4d du[3];
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) du[pp] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
 #pragma unroll
@@ -351,8 +360,17 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
                         if (!(P == kb || P < kb || P >= Q)) continue;
                         const int which = (Q == kb + 1) ? 0 : ((Q == kb + 2 && P == Q) ? 1 : 2);
                         if (which != pass) continue;
-                        acc[pp][Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[pp].v[s2], rb[Q].v[s2], acc[pp][Q], 0, 0, 0);
+                        if (P == Q) du[pp] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[pp].v[s2], rb[Q].v[s2], du[pp], 0, 0, 0);
+                        else acc[pp][Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[pp].v[s2], rb[Q].v[s2], acc[pp][Q], 0, 0, 0);
                     }
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {               // (a wave's diagonal sub-tile of this pass: P == kb + 2 in pass 1, beyond in pass 2)
+                const int P = ROWS[pp];
+                if (P > kb + 1 && P < NSB && ((P == kb + 2) ? 1 : 2) == pass) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[pp][P][t] += du[pp][t];
+                }
+            }
 #pragma unroll
             for (int pp = 0; pp < 3; ++pp) {
                 const int P = ROWS[pp];
@@ -452,9 +470,13 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
             v4d lt = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) lt = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.v[s], sb.v[s], lt, 0, 0, 0);
+            // (L' L'^T from zero, subtracted once: the sub-tile holds diagonal entries -- see the compute waves' du)
+            v4d uu = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) uu = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s], lt[s], uu, 0, 0, 0);
             tt = get16(L.DG + (n & 1) * 16 * PP);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(-lt[s], lt[s], tt, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) tt[t] -= uu[t];
         }
         DG_STAMP(kb, 1);
         lds_barrier();                                     // M

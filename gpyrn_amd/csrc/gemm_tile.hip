@@ -115,10 +115,16 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
         ft_row = (int)(t.c_off / ld) + sr * BM;
         ft_col = (int)(t.c_off % ld) + sc * BN;
     }
+    // ... and in the 8-wave 128 x 128 form (launches of thousands of tasks: T = 128) the same tasks take the instantiation
+    // whose diagonal 16 x 16 blocks accumulate from zero (tile_mma SYM: the accuracy of the pivots), all blocks computed
+    constexpr bool CAN_SYM128 = BM == 128 && BN == 128 && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT);
     if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
     else if (CAN_LOWER && lower && sr == sc)
         tile_mma<BM, BN, WM, WN, TRI, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
                                                        (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
+    else if (CAN_SYM128 && ((t.modes >> 4) & 1))
+        tile_mma<BM, BN, WM, WN, TRI, false, false, CAN_SYM128>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
+                                                                (sr * BM) >> 4, (sc * BN) >> 4);
     else
         tile_mma<BM, BN, WM, WN, TRI, false, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
                                                    (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
@@ -281,8 +287,8 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
     const double* A = Bm + a_off + (size_t)(16 * P + fr) * ld + 2 * fk;
     const double* B = Bm + a_off + (size_t)(16 * Q + fr) * ld + 2 * fk;
     gptr_t C = (gptr_t)(Bm + c_off) + (size_t)(16 * P + fk) * ld + 16 * Q + fr;
-    double a[32], b[32];
-    v4d acc;
+    double a[32], b[32], cin[4];
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const double2 av = *(const double2*)(A + 8 * j), bv = *(const double2*)(B + 8 * j);
@@ -290,14 +296,16 @@ void k_chain_u(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int64_t a_o
         b[2 * j] = bv.x; b[2 * j + 1] = bv.y;
     }
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) acc[tt] = C[(size_t)(4 * tt) * ld];
+    for (int tt = 0; tt < 4; ++tt) cin[tt] = C[(size_t)(4 * tt) * ld];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every load in flight before the first MFMA
     RW_STAMP(2);
     RW_STAMP(3);
+    // the product accumulates from ZERO and is subtracted once: the diagonal blocks hold B's diagonal entries (~1, the
+    // update ~d K), and 32 MFMA steps rounding at that magnitude cost the pivots their last digits (tile_mma, SYM)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[j], b[j], acc, 0, 0, 0);
+    for (int j = 0; j < 32; ++j) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[j], b[j], acc, 0, 0, 0);
 #pragma unroll
-    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = acc[tt];
+    for (int tt = 0; tt < 4; ++tt) C[(size_t)(4 * tt) * ld] = cin[tt] - acc[tt];
     RW_STAMP(4);
 #ifdef ROWS_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -127,7 +127,8 @@ __device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm
     tile_mma<128, 128, 2, 2, 1>(lds, Bm + t10, Xm, (gptr_t)(Bm + t10), ld, 0, 0, CM_SET, GPRN_TILE, 0, 0);
     sm_publish();
     // B_11 -= L_10 L_10^T;  R_10 = -L_10 X_00 (first touch of the inverse's row)
-    tile_mma<128, 128, 2, 2, 0>(lds, Bm + t10, Bm + t10, (gptr_t)(Bm + t11), ld, 0, 0, CM_SUB, GPRN_TILE, 0, 0);
+    // (SYM: the diagonal 16 x 16 blocks accumulate from zero -- the pivots' accuracy, tile_mma.h)
+    tile_mma<128, 128, 2, 2, 0, false, false, true>(lds, Bm + t10, Bm + t10, (gptr_t)(Bm + t11), ld, 0, 0, CM_SUB, GPRN_TILE, 0, 0);
     __syncthreads();
     tile_mma<128, 128, 2, 2, 0>(lds, Bm + t10, Xm, (gptr_t)(Xm + t10), ld, 0, 1, CM_SETNEG, GPRN_TILE, 0, 0);
     sm_publish();

@@ -49,7 +49,15 @@ __device__ __forceinline__ void lane_geometry(int tid, int mode, int ld, unsigne
 // k_build_B would have written there (same expression, same rounding).  ft_row / ft_col: the part's first row / column
 // inside the matrix.
 // DEEP_OK: the caller's register budget allows the second set of staging registers (the 64 x 64 form: 110 registers per lane)
-template <int BM, int BN, int WM, int WN, int TRI, bool LOWER = false, bool DEEP_OK = false>
+// SYM: the part lies on the diagonal of a symmetric update of a diagonal tile, B_jj -= L[j,.] L[j,.]^T (task bit 4).  Its
+// 16 x 16 blocks ON the diagonal hold the matrix' diagonal entries, which are ~1 in B = I + D^1/2 K D^1/2 where the update
+// is ~d K: with the tile in the accumulator from the start (acc = -C, acc += A.B) every one of the klen / 4 MFMA steps
+// rounds at the magnitude of C, and the errors do not average out -- 40 ulp on a pivot after 950 columns, which
+// var = (1 - sum_r X_rc^2) / d divides by d ~ 2e-4 (profiles/r05_var_accuracy.txt: the device's variances were 4-11 x
+// less accurate than LAPACK's on the same algebra).  Those blocks accumulate A.B from ZERO and the tile comes in at the
+// end, C - acc: one rounding at C's magnitude per update, as a BLAS syrk does it.  (The other blocks hold off-diagonal
+// entries, as small as their updates; they keep the form that needs no second pass over C.)
+template <int BM, int BN, int WM, int WN, int TRI, bool LOWER = false, bool DEEP_OK = false, bool SYM = LOWER>
 __device__ __forceinline__ void tile_mma(double* lds, const double* A, const double* B, gptr_t C, int ld,
                                          int a_mode, int b_mode, int c_mode, int klen, int mb16_0, int nb16_0,
                                          const double* ft_K = nullptr,
@@ -99,6 +107,7 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
     auto frag = [&](int byte_addr) { return *reinterpret_cast<const double*>(lds_b + byte_addr); };
 
     const bool neg = c_mode != CM_SET;                       // acc holds -(result)
+    auto on_diag = [&](int i, int j) { return SYM && nb16 + j == mb16 + i; };   // (wave-uniform)
     gptr_t Cw = C + (size_t)(row0 + fk) * ld + wc * TN + fr;
     auto crow = [&](int i) { return (size_t)(i * 16); };       // rows of block i past Cw
     auto arow_bytes = [&](int i) { return i * 128; };          // same, LDS bytes
@@ -166,17 +175,19 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
                     const double kv = (m < ft_n && n < ft_n) ? Kw[(crow(i) + 4 * r) * ld + j * 16] : 0.0;
                     double v = (n < ft_n) ? sm * sc[j] * kv : 0.0;
                     if (m == n) v += 1.0;
-                    acc[i][j][r] = -v;
+                    acc[i][j][r] = on_diag(i, j) ? 0.0 : -v;       // (SYM: formed again in the epilogue)
                 }
             }
     } else if (c_mode == CM_SUB) {               // one uniform branch around all the loads
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j) {
+                if (on_diag(i, j)) { acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0}; continue; }   // (SYM: read in the epilogue)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     acc[i][j][r] = -Cw[(crow(i) + 4 * r) * ld + j * 16];
+            }
     } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -290,9 +301,34 @@ __device__ __forceinline__ void tile_mma(double* lds, const double* A, const dou
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NI; ++j) {
+            if (SYM && c_mode == CM_SUB && on_diag(i, j)) {
+                // the block accumulated A.B from zero: the tile comes in now (first touch: formed from K as above)
+                double cin[4];
+                if (ft_K) {
+                    gcptr_t Kw = (gcptr_t)ft_K + (size_t)(row0 + fk) * ld + wc * TN + fr;
+                    const int n = ft_col + wc * TN + fr + 16 * j;
+                    const double scj = n < ft_n ? ft_s[n] : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = ft_row + row0 + fk + (int)crow(i) + 4 * r;
+                        const double sm = m < ft_n ? ft_s[m] : 0.0;
+                        const double kv = (m < ft_n && n < ft_n) ? Kw[(crow(i) + 4 * r) * ld + j * 16] : 0.0;
+                        double v = (n < ft_n) ? sm * scj * kv : 0.0;
+                        if (m == n) v += 1.0;
+                        cin[r] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cin[r] = Cw[(crow(i) + 4 * r) * ld + j * 16];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cw[(crow(i) + 4 * r) * ld + j * 16] = cin[r] - acc[i][j][r];
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 Cw[(crow(i) + 4 * r) * ld + j * 16] = neg ? -acc[i][j][r] : acc[i][j][r];
             }
+        }
 }

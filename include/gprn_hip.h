@@ -180,7 +180,11 @@ int gprn_grad_kernel(gprn_ctx* ctx, int gp, const double* m, double* grad_out);
 enum {
     GPRN_M_K = 0,        /* prior covariance K_gp (N,N) */
     GPRN_M_KLINV = 1,    /* chol(K_gp)^-1, lower */
-    GPRN_M_SIGMA = 2     /* variational covariance of the last sweep (N,N) */
+    GPRN_M_SIGMA = 2,    /* variational covariance of the last sweep (N,N) */
+    GPRN_M_BX = 3,       /* X = chol(B)^-1 (lower) of the last half-sweep that factored this latent GP, B = I + D^1/2 K D^1/2:
+                            what the posterior variances are column sums of; diagnostics */
+    GPRN_M_BL = 4        /* ... and chol(B) itself (lower); for a node k < q - 1 with q > 1 it has been overwritten by
+                            lower(B^-1) (quirk Q1) */
 };
 int gprn_keep_sigma(gprn_ctx* ctx, int on);   /* form Sigma explicitly during sweeps (ELBOaux shim) */
 int gprn_get_matrix(gprn_ctx* ctx, int which, int gp, double* out);

@@ -37,7 +37,7 @@ def data_args(data):
 # (/root/reference/gpyrn/meanfield.py:792, 865 produce the means; :688-697 the variances).  Relative to what: the state of
 # a latent GP is a vector of N values that pass through zero, so the bound is norm-wise PER LATENT GP -- the largest
 # deviation of a row of the (p+1, q, N) state against that row's largest entry.  Every check is recorded, and a session
-# that ran any writes the achieved figures to gpurun_out/r04_parity_achieved.txt (tests/conftest.py).
+# that ran any writes the achieved figures to gpurun_out/parity_achieved.txt (tests/conftest.py).
 STATE_TOL = 1e-8
 ACHIEVED = []
 

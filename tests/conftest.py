@@ -21,7 +21,7 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         os.makedirs(out_dir, exist_ok=True)
         gpu = any('gpu' in (getattr(item, 'keywords', {}) or {}) for item in getattr(session, 'items', []))
-        name = 'r04_parity_achieved.txt' if gpu else 'r04_parity_achieved_cpu.txt'
+        name = 'parity_achieved.txt' if gpu else 'parity_achieved_cpu.txt'
         with open(os.path.join(out_dir, name), 'w') as f:
             f.write('# max |x - x_ref| / max |x_ref| per latent GP (worst row), bound %.0e: posterior means | variances\n'
                     % _cases.STATE_TOL)
