@@ -511,14 +511,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
         const gprn_ctx::OuterRange& o0 = c->outers[set][0];
         const int outer = o0.k1 - o0.k0;
         // (the 64 x 64 tile kernel only: every launch of the first panel's update must use that shape)
-        static int persist128 = -1;                  // (experiment: persistent 128 x 128 K = 512 launches cannot form tiles on the way in)
-        if (persist128 < 0) {
-            const char* e = getenv("GPRN_PERSIST_WGS"); const char* e2 = getenv("GPRN_PERSIST_SHAPE");
-            persist128 = (e && atoi(e) > 0 && !(e2 && atoi(e2) == 1)) ? 1 : 0;
-        }
-        const char* emb = getenv("GPRN_PERSIST_MAXB");
-        const bool persist_here = persist128 && nbatch <= (emb ? atoi(emb) : 2);
-        ft_fused = c->ft_s_phase && pend == nbatch && c->T > outer && !persist_here &&
+        ft_fused = c->ft_s_phase && pend == nbatch && c->T > outer &&
                    shape_upd(o0.nfirst) == TS_64x64 && shape_upd(o0.nnext) == TS_64x64;
         if ((rc = vec_build_B(c, pend, s0, ft_fused ? 1 : 0, outer))) return rc;
     }

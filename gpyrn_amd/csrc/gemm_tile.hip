@@ -131,64 +131,6 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     signal_done(sig_slot, sig_value, then_wait, then_value, wait_timed_out);
 }
 
-// EXPERIMENT (round 5): the same contraction as a FIXED grid of workgroups, each walking the (task,
-// sub-tile, matrix) list with stride gridDim.x -- no queue, no atomics, no flags between them.  Launched with fewer
-// workgroups than the device has CUs, and with enough (unused) dynamic LDS that only one fits a CU, it leaves the other CUs
-// free of K = 512 work for the latency chain's kernels -- CU reservation by grid size instead of by queue masks (which cost
-// more than they gave: DESIGN_HISTORY.md).  Same XCD re-mapping as k_tile_gemm: entry lin = i * gridDim.x + blockIdx.x keeps
-// lin % 8 = the workgroup's XCD as long as gridDim.x is a multiple of 8.
-template <int BM, int BN, int NW, int TAG>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2)
-void k_tile_gemm_persist(const TileTask* __restrict__ tasks, double* const* __restrict__ ptrs, int ld, unsigned gx, unsigned nblk,
-                         int xcd_map, const double* ft_s, int ft_n, unsigned* start_flag, unsigned start_value)
-{
-    if (start_flag && blockIdx.x == 0 && threadIdx.x == 0)
-        __hip_atomic_store(start_flag, start_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    constexpr int WM = 2, WN = NW / 2;
-    constexpr int SM = GPRN_TILE / BM, SN = GPRN_TILE / BN;
-    __shared__ __attribute__((aligned(16))) double lds[2 * 16 * (BM + BN + 32)];
-    const unsigned sh = (unsigned)xcd_map, cmask = (1u << sh) - 1u;
-    const unsigned n128 = nblk & ~((8u << sh) - 1u);
-    for (unsigned lin = blockIdx.x; lin < nblk; lin += gridDim.x) {
-        const unsigned cx = lin >> 3;
-        const unsigned lb = (xcd_map && lin < n128) ? ((((cx >> sh) << 3) + (lin & 7u)) << sh) + (cx & cmask) : lin;
-        const unsigned bx = lb % gx, by = lb / gx;
-        const TileTask t = tasks[bx / (SM * SN)];
-        const int sub = bx % (SM * SN), sr = sub / SN, sc = sub % SN;
-        double* const* gp = ptrs + (size_t)by * GPRN_NBUF;
-        double* const p0 = gp[0]; double* const p1 = gp[1]; double* const p2 = gp[2]; double* const p3 = gp[3];
-        auto pick = [&](int b) { return b == 0 ? p0 : (b == 1 ? p1 : (b == 2 ? p2 : p3)); };
-        const int c_mode = t.modes & 3, a_mode = (t.modes >> 2) & 1, b_mode = (t.modes >> 3) & 1;
-        const double* A = pick(t.a_buf) + t.a_off + (a_mode ? (size_t)sr * BM : (size_t)sr * BM * ld);
-        const double* B = pick(t.b_buf) + t.b_off + (b_mode ? (size_t)sc * BN : (size_t)sc * BN * ld);
-        gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sr * BM * ld + sc * BN;
-        constexpr bool CAN_LOWER = BM == 64 && BN == 64;
-        const bool lower = CAN_LOWER && ((t.modes >> 4) & 1);
-        constexpr bool CAN_FT = BM == 64 && BN == 64;
-        const double* ft_K = nullptr;
-        const double* ft_sv = nullptr;
-        int ft_row = 0, ft_col = 0;
-        if (CAN_FT && ft_s && ((t.modes >> 5) & 1)) {
-            ft_K = pick(BUF_K) + t.c_off + (size_t)sr * BM * ld + sc * BN;
-            ft_sv = ft_s + (size_t)by * ld;
-            ft_row = (int)(t.c_off / ld) + sr * BM;
-            ft_col = (int)(t.c_off % ld) + sc * BN;
-        }
-        constexpr bool CAN_SYM128 = BM == 128 && BN == 128;
-        if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
-        else if (CAN_LOWER && lower && sr == sc)
-            tile_mma<BM, BN, WM, WN, 0, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                                         (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
-        else if (CAN_SYM128 && ((t.modes >> 4) & 1))
-            tile_mma<BM, BN, WM, WN, 0, false, false, CAN_SYM128>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                                                  (sr * BM) >> 4, (sc * BN) >> 4);
-        else
-            tile_mma<BM, BN, WM, WN, 0, false, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
-                                                     (sr * BM) >> 4, (sc * BN) >> 4, ft_K, ft_sv, ft_row, ft_col, ft_n);
-        __syncthreads();                               // the stage buffers are free for the next entry
-    }
-}
-
 // Both halves of a tile step's panel in ONE launch: tasks [0, n_l) are L_ik = B_ik X_kk^T (64 x 128 workgroups, B
 // triangular), the others X_kc = X_kk R_kc (128 x 64 workgroups, A triangular) -- two workgroups per task in either
 // form.  stream3 is the factorisation's second serial chain (synchronise, panel, in-panel update per tile step):
@@ -459,37 +401,6 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
         if (sig.slot && sig.then_wait)
             HIP_TRY(c, hipStreamWaitValue32(stream, (void*)sig.then_wait, sig.then_value, hipStreamWaitValueGte, 0xffffffffu));
         return GPRN_OK;
-    }
-    // EXPERIMENT: the K = 512 launches of a phase of one or two matrices as a fixed grid of persistent workgroups, one per CU
-    // on fewer CUs than the device has (k_tile_gemm_persist); GPRN_PERSIST_WGS = workgroups (0: off), GPRN_PERSIST_SHAPE =
-    // 0: 8-wave 128 x 128, 1: 4-wave 64 x 64, GPRN_PERSIST_MAXB = largest batch it applies to (2)
-    {
-        static int p_wgs = -1, p_shape = 0, p_maxb = 2, p_kb = 90;
-        if (p_wgs < 0) {
-            const char* e = getenv("GPRN_PERSIST_WGS"); p_wgs = e ? atoi(e) : 0;
-            e = getenv("GPRN_PERSIST_SHAPE"); p_shape = e ? atoi(e) : 0;
-            e = getenv("GPRN_PERSIST_MAXB"); p_maxb = e ? atoi(e) : 2;
-            e = getenv("GPRN_PERSIST_LDS_KB"); p_kb = e ? atoi(e) : 90;
-        }
-        const bool k512 = tag == TG_NEXT || tag == TG_AHEAD || tag == TG_BULK;
-        if (p_wgs > 0 && k512 && nbatch <= p_maxb && !sig.slot && !aw.flag) {
-            prof_begin(c, fam, stream);
-            const int per_task = p_shape == 0 ? 1 : 4;
-            const unsigned gx = (unsigned)ntasks * per_task, nblk = gx * (unsigned)nbatch;
-            const unsigned grid = std::min<unsigned>((unsigned)p_wgs, nblk);
-            const size_t static_lds = p_shape == 0 ? 2 * 16 * (128 + 128 + 32) * sizeof(double) : 2 * 16 * (64 + 64 + 32) * sizeof(double);
-            const size_t want = (size_t)p_kb * 1024;
-            const size_t dynp = want > static_lds ? std::min(want, lds_limit(c->device)) - static_lds : 0;
-            double* const* tabp = (double* const*)d_ptrs;
-#define GOP(BM, BN, NW, TAG) hipLaunchKernelGGL((k_tile_gemm_persist<BM, BN, NW, TAG>), dim3(grid), dim3(64 * NW), dynp, stream, d_tasks, tabp, ld, \
-                                                gx, nblk, GPRN_XCD_CHUNK_LOG2, c->ft_s_now, c->N, c->start_flag_now, c->start_value_now)
-            if (p_shape == 0) { if (tag == TG_NEXT) GOP(128, 128, 8, TG_NEXT); else if (tag == TG_AHEAD) GOP(128, 128, 8, TG_AHEAD); else GOP(128, 128, 8, TG_BULK); }
-            else { if (tag == TG_NEXT) GOP(64, 64, 4, TG_NEXT); else if (tag == TG_AHEAD) GOP(64, 64, 4, TG_AHEAD); else GOP(64, 64, 4, TG_BULK); }
-#undef GOP
-            prof_end(c);
-            HIP_TRY(c, hipGetLastError());
-            return GPRN_OK;
-        }
     }
     prof_begin(c, fam, stream);
     // Bulk launches on the look-ahead stream (the K = 512 trailing updates, the X^T X product) ask for 16 KiB of unused
