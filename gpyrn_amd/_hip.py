@@ -70,6 +70,8 @@ SIGNATURES = {
                             POINTER(c_int), _dp, _dp]),
     'gprn_elbocalc': (c_int, [c_void_p, c_int, _dp, _dp, _dp, _dp, c_int, _dp, c_int, POINTER(c_int), POINTER(c_int),
                       POINTER(c_int), _dp, _dp]),
+    'gprn_expected_loglike': (c_int, [c_void_p, _dp]),
+    'gprn_prior_terms': (c_int, [c_void_p, c_int, _dp, _dp, _dp]),
     'gprn_grad_matrices': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_grad_kernel': (c_int, [c_void_p, c_int, _dp, _dp]),
     'gprn_eval_kernel': (c_int, [c_void_p, POINTER(c_int32), c_int, _dp, c_int, c_double, _dp]),
@@ -293,6 +295,20 @@ class Context:
             self._h, flat.ctypes.data_as(POINTER(c_int32)), flat.shape[0], _ptr(par), par.size, float(nugget),
             z.shape[0], _ptr(z), _ptr(out)), 'sample_prior')
         return out, info
+
+    def expected_loglike(self):
+        """inference._expectedLogLike of the state and jitters last set (gprn_expected_loglike)."""
+        v = c_double(0.0)
+        self._check(self._lib.gprn_expected_loglike(self._h, byref(v)), 'expected_loglike')
+        return v.value
+
+    def prior_terms(self, gp, S, m):
+        """(log det K_gp, m^T K_gp^-1 m, tr(K_gp^-1 S)) from the resident factor of K_gp (gprn_prior_terms)."""
+        S = _f64(S, (self.N, self.N))
+        m = _f64(np.ravel(m), (self.N,))
+        out = np.zeros(3)
+        self._check(self._lib.gprn_prior_terms(self._h, int(gp), _ptr(S), _ptr(m), _ptr(out)), 'prior_terms')
+        return out
 
     def grad_matrices(self, gp):
         """(K^-1, K^-1 S K^-1) of latent GP `gp` after a sweep with keep_sigma: the N^3 part of the ELBO gradient."""

@@ -2143,6 +2143,124 @@ extern "C" int gprn_grad_kernel(gprn_ctx* c, int gp, const double* m, double* gr
     return grad_impl(c, gp, nullptr, nullptr, m, grad_out, closed);
 }
 
+// ------------------------------------------------------------------ the ELBO's terms on their own
+// inference._expectedLogLike (meanfield.py:895-990) of the state last set (gprn_set_muvar: the variances ARE the diagonals of
+// Sigma_f / Sigma_w that the reference extracts, :688-697, 956-987) under the jitters last set: the same kernel the sweep's
+// ELBO assembly uses (k_loglike_partial), its 32 partial sums added in k_elbo_final's order.
+extern "C" int gprn_expected_loglike(gprn_ctx* c, double* logl_out)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || !logl_out) return bad(c, "expected_loglike: bad argument");
+    if (!c->have_jit || !c->have_muvar) return bad(c, "expected_loglike: set_jitters and set_muvar first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    // (scal is not read by the launch we keep: a throw-away ELBO assembly over whatever the scalars hold)
+    double* part = c->d_elbo_part;
+    if (c->out_cap < 1) { dev_free(c->d_out); TRY(dev_alloc(c, &c->d_out, 4)); c->out_cap = 1; }
+    TRY(vec_elbo(c, c->d_out, c->d_scal_base, part));
+    double h[GPRN_ELBO_PART_DOUBLES];
+    HIP_TRY(c, hipMemcpyAsync(h, part, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    for (int b = 0; b < GPRN_ELBO_PART_DOUBLES / 3; ++b) { t1 += h[3 * b]; t2 += h[3 * b + 1]; t3 += h[3 * b + 2]; }
+    *logl_out = -0.5 * t1 - 0.5 * t2 - 0.5 * t3;
+    return GPRN_OK;
+}
+
+// out[i] = sum_{n <= i} A[i][n] W[i][n] over the lower triangle of two ld-pitched matrices (one wave per row)
+__global__ __launch_bounds__(256)
+void k_rowdot_lower(const double* __restrict__ A, const double* __restrict__ W, int N, int ld, double* __restrict__ out)
+{
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= N) return;
+    double acc = 0.0;
+    for (int n = lane; n <= i; n += 64) acc += A[(size_t)i * ld + n] * W[(size_t)i * ld + n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) out[i] = acc;
+}
+
+// What inference._expectedLogPrior (meanfield.py:992-1067) needs of latent GP `gp` for a covariance S and a mean m that the
+// CALLER supplies (the reference pairs node j with the cumulative Sigma_f0 + ... + Sigma_fj and weight (j, i) with the
+// raw-reshape row of mu_w: quirks Q1, Q2 -- the caller's business), from the factor of K_gp that gprn_factor_priors left on
+// the device:  out[0] = log det K = 2 sum log diag chol(K) (:1029, 1062),  out[1] = m^T K^-1 m = |L^-1 m|^2 (:1032, 1050),
+// out[2] = tr(K^-1 S) = < L^-1, L^-1 S > (:1041, 1051; the reference: cho_solve of the N x N matrix, 2 N^3 -- here one
+// triangular product on the tile kernel, N^3).  S: (N, N), m: (N).  Unsharded contexts.
+extern "C" int gprn_prior_terms(gprn_ctx* c, int gp, const double* S, const double* m, double* out3)
+{
+    DeviceLock lock_(c);
+    if (!c || !c->N || gp < 0 || gp >= c->G || !S || !m || !out3) return bad(c, "prior_terms: bad argument");
+    if (c->world != 1) return bad(c, "prior_terms: not available on a sharded context");
+    if (!c->factored) return bad(c, "prior_terms: needs factor_priors first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    TRY(build_tables(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    const int ld = c->ld, N = c->N, T = c->T;
+    // the latent GP's own row of the phase tables: BUF_B <- S (zero padding), BUF_X <- W = L_K^-1 S, BUF_KLINV = L_K^-1
+    const bool node = gp < c->q;
+    const std::vector<int>& gps = node ? c->loc_nodes : c->loc_weights;
+    int slot = -1;
+    for (size_t sl = 0; sl < gps.size(); ++sl) if (gps[sl] == gp) slot = (int)sl;
+    if (slot < 0) return bad(c, "prior_terms: latent GP not held here");
+    double** const tab = (node ? c->tab_node : c->tab_weight) + (size_t)slot * GPRN_NBUF;
+    const size_t ws = (node ? 0 : c->loc_nodes.size()) + (size_t)slot;
+    double* const dS = c->wsB[ws];
+    double* const dW = c->wsX[ws];
+    HIP_TRY(c, hipMemsetAsync(dS, 0, (size_t)ld * ld * sizeof(double), c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(dS, (size_t)ld * sizeof(double), S, (size_t)N * sizeof(double), (size_t)N * sizeof(double), N,
+                                hipMemcpyHostToDevice, c->stream));
+    std::vector<TileTask> tasks;
+    auto toff = [&](int ti, int tj) { return ((int64_t)ti * GPRN_TILE) * ld + (int64_t)tj * GPRN_TILE; };
+    for (int ti = 0; ti < T; ++ti)                     // W(ti, tj) = sum_{k <= ti} L^-1(ti, k) S(k, tj): the factor is lower triangular
+        for (int tj = 0; tj < T; ++tj)
+            tasks.push_back(TileTask{toff(ti, tj), toff(ti, 0), toff(0, tj), (ti + 1) * GPRN_TILE, BUF_X, BUF_KLINV, BUF_B,
+                                     tile_modes(CM_SET, 0, 1)});
+    TileTask* d_t = nullptr;
+    double* d_m = nullptr;
+    int rc = dev_alloc(c, &d_t, tasks.size());
+    if (!rc) rc = dev_alloc(c, &d_m, 3 * (size_t)ld + 4);
+    hipError_t e = hipSuccess;
+    double** const sptrs = c->d_ptrs;
+    const int sslot0 = c->slot0;
+    const EvalMap sev = c->ev;
+    if (!rc) e = hipMemcpyAsync(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice, c->stream);
+    if (!rc && e == hipSuccess) rc = launch_tiles(c, d_t, tasks.size(), tab, 1, ld, GPRN_T_UPDATE);
+    if (!rc && e == hipSuccess) {
+        hipLaunchKernelGGL(k_rowdot_lower, dim3((N + 3) / 4), dim3(256), 0, c->stream, (const double*)c->KLinv[gp], (const double*)dW,
+                           N, ld, d_m + ld);
+        e = hipGetLastError();
+    }
+    // tr(K^-1 S): the rows' sums in a fixed order; m^T K^-1 m: a = L^-1 m (one wave per row), then a . a
+    double h[3] = {0.0, 0.0, 0.0};
+    if (!rc && e == hipSuccess) e = hipMemcpyAsync(d_m, m, (size_t)N * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (!rc && e == hipSuccess) {
+        static const int zero = 0;
+        int* d_zero = nullptr;
+        rc = dev_alloc(c, &d_zero, 1);
+        if (!rc) e = hipMemcpyAsync(d_zero, &zero, sizeof(int), hipMemcpyHostToDevice, c->stream);
+        c->d_ptrs = tab; c->slot0 = 0; c->ev = EvalMap{nullptr, 0, 0, 0, 0};
+        if (!rc && e == hipSuccess) rc = vec_lower_matvec(c, BUF_KLINV, d_m, 0, 0, d_zero, 1, d_m + 2 * (size_t)ld);
+        // (one slot, "latent GP 0": the scalar lands at d_m[3 ld])
+        if (!rc && e == hipSuccess) rc = vec_dot_self(c, d_zero, 1, d_m + 2 * (size_t)ld, d_m + 3 * (size_t)ld);
+        if (!rc && e == hipSuccess) {
+            std::vector<double> rows(N);
+            e = hipMemcpyAsync(rows.data(), d_m + ld, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h[1], d_m + 3 * (size_t)ld, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&h[0], c->d_logdetK + gp, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            for (int i = 0; i < N; ++i) h[2] += rows[i];
+        }
+        c->d_ptrs = sptrs; c->slot0 = sslot0; c->ev = sev;
+        if (d_zero) hipFree(d_zero);
+    }
+    if (d_t) hipFree(d_t);
+    if (d_m) hipFree(d_m);
+    if (rc) return rc;
+    if (e != hipSuccess) { c->err = std::string("prior_terms: ") + hipGetErrorString(e); return GPRN_E_HIP; }
+    out3[0] = h[0]; out3[1] = h[1]; out3[2] = h[2];
+    return GPRN_OK;
+}
+
 // ------------------------------------------------------------------ diagnostics
 static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch)
 {

@@ -531,6 +531,93 @@ class inference:
         new_mu, new_var = ctx.get_muvar()
         return np.float64(e[0]), new_mu, new_var, sigmaF, sigmaW
 
+    # ------------------------------------------------- the four step methods ELBOaux is made of (meanfield.py:713, 895, 992, 1069)
+    # Private in the reference, but part of its class: a script that calls them finds them here with the reference's
+    # signatures and return shapes, computed on the device -- the sweep itself for _updateSigMu, the factorisation for
+    # _entropy, the resident factors plus one triangular product per latent GP for _expectedLogPrior, the ELBO assembly's own
+    # kernel for _expectedLogLike.  Each invalidates the object's cached set-up (the next ELBOcalc refactors).
+    def _updateSigMu(self, Kf, Kw, Lf, Lw, y, jitt2, muF, varF, muW, varW):
+        """Closed-form updates of the variational covariances and means (meanfield.py:713-893; eqs. 16-19 of Nguyen &
+        Bonilla 2013): ``(sigma_f (q, N, N), mu_f (q, N), sigma_w (q, p, N, N), mu_w (p, q, N))`` from the prior
+        matrices, ``y - mean``, the squared jitters and the current state split as ``_u_to_fhatW`` splits it.  One device
+        sweep with the explicit covariances kept (as ``ELBOaux``); ``Lf`` / ``Lw`` are recomputed there."""
+        q, p, N = self.q, self.p, self.N
+        mu = np.concatenate((np.reshape(muF, (1, q, N)), np.reshape(muW, (p, q, N))))
+        var = np.concatenate((np.reshape(varF, (1, q, N)), np.reshape(varW, (p, q, N))))
+        _, new_mu, _, sigma_f, sigma_w = self.ELBOaux(Kf, Kw, Lf, Lw, y, jitt2, mu, var)
+        return sigma_f, new_mu[0], sigma_w, new_mu[1:]
+
+    def _entropy(self, sigma_f, sigma_w):
+        """Entropy of the variational distribution (meanfield.py:1069-1093): ``sum log diag chol(Sigma)`` over the q + q p
+        covariances ``+ q (p + 1) N (1 + log 2 pi) / 2``.  The Choleskys run on the device (the covariances go in as the
+        latent GPs' matrices, the set-up's factorisation returns ``log det``); a covariance that is not positive definite
+        gives NaN, as jax's cholesky does."""
+        q, p, N = self.q, self.p, self.N
+        sigma_f = np.asarray(sigma_f, dtype=float).reshape(q, N, N)
+        sigma_w = np.asarray(sigma_w, dtype=float).reshape(q, p, N, N)
+        ctx = self._backend()
+        self._prior_key = None
+        for j in range(q):
+            ctx.upload_K(j, sigma_f[j])
+            for i in range(p):
+                ctx.upload_K(q + j * p + i, sigma_w[j, i])
+        info = ctx.factor_priors()
+        self.last_info = info
+        if info:
+            return np.float64(np.nan)
+        return np.float64(0.5 * np.sum(ctx.get_logdet_K()) + 0.5 * q * (p + 1) * N * (1.0 + np.log(2.0 * np.pi)))
+
+    def _expectedLogPrior(self, Kf, Kw, Lf, Lw, sigma_f, mu_f, sigma_w, mu_w):
+        """Expectation of the log prior under q(f, w) (meanfield.py:992-1067; eq. 15): per latent GP
+        ``-log det K / 2 - (m^T K^-1 m + tr(K^-1 S)) / 2``, node j with the CUMULATIVE ``S = Sigma_f0 + ... + Sigma_fj``
+        (:1025, 1039: quirk Q1), weight (j, i) with the raw reshape ``mu_w.reshape(q, p, N)[j, i]`` (:1021: quirk Q2),
+        ``- N q (p + 1) log(2 pi) / 2``.  The matrices are factored on the device (``Lf`` / ``Lw`` are recomputed there) and
+        every term comes from the resident factor (``gprn_prior_terms``: tr(K^-1 S) as one triangular product, N^3)."""
+        q, p, N = self.q, self.p, self.N
+        Kf = np.asarray(Kf, dtype=float).reshape(q, N, N)
+        Kw = np.asarray(Kw, dtype=float).reshape(q * p, N, N)
+        sigma_f = np.asarray(sigma_f, dtype=float).reshape(q, N, N)
+        sigma_w = np.asarray(sigma_w, dtype=float).reshape(q, p, N, N)
+        mf = np.asarray(mu_f, dtype=float).reshape(q, N)
+        mw = np.asarray(mu_w, dtype=float).reshape(q, p, N)              # quirk Q2
+        ctx = self._backend()
+        self._prior_key = None
+        for gp, K in enumerate(chain(Kf, Kw)):
+            ctx.upload_K(gp, K)
+        info = ctx.factor_priors()
+        self.last_info = info
+        if info:
+            return np.float64(np.nan)
+        total = 0.0
+        cumulative = np.zeros((N, N))
+        for j in range(q):
+            cumulative = cumulative + sigma_f[j]                          # quirk Q1
+            ld, quad, tr = ctx.prior_terms(j, cumulative, mf[j])
+            total += -0.5 * ld - 0.5 * (quad + tr)
+            for i in range(p):
+                ld, quad, tr = ctx.prior_terms(q + j * p + i, sigma_w[j, i], mw[j, i])
+                total += -0.5 * ld - 0.5 * (quad + tr)
+        return np.float64(total - 0.5 * N * q * (p + 1) * np.log(2.0 * np.pi))
+
+    def _expectedLogLike(self, y, jitt2, sigma_f, mu_f, sigma_w, mu_w):
+        """Expected log-likelihood (meanfield.py:895-990; eq. 14).  As in the reference the argument ``y`` is NOT what
+        enters: the residual is taken against the raw data ``self.y`` (:940, quirk Q3), and of the covariances only the
+        diagonals (:956-957).  Computed by the kernel of the device's own ELBO assembly from the state
+        ``(mu_f, mu_w)`` / ``(diag Sigma_f, diag Sigma_w)`` and the jitters."""
+        q, p, N = self.q, self.p, self.N
+        sigma_f = np.asarray(sigma_f, dtype=float).reshape(q, N, N)
+        sigma_w = np.asarray(sigma_w, dtype=float).reshape(q, p, N, N)
+        mu = np.concatenate((np.reshape(mu_f, (1, q, N)), np.reshape(mu_w, (p, q, N))))
+        var = np.empty((p + 1, q, N))
+        for j in range(q):
+            var[0, j] = np.diag(sigma_f[j])
+            for i in range(p):
+                var[1 + i, j] = np.diag(sigma_w[j, i])
+        ctx = self._backend()
+        ctx.set_jitters(np.sqrt(np.asarray(jitt2, dtype=float)))
+        ctx.set_muvar(mu, var)
+        return np.float64(ctx.expected_loglike())
+
     def nELBO(self, parameters, max_iter=None):
         """ Negative ELBO at `parameters` (warm-started, meanfield.py:1095-1111) """
         assert self._components_set, _NOT_SET
@@ -962,8 +1049,16 @@ class inference:
         reference accepts and drops them), so ``pool=sharding.EvalPool()`` spreads the walkers over the
         GPUs of a node; ``backend=`` replaces the HDF file, and without h5py emcee's in-memory backend is used.
         ``batch=True`` hands emcee a VECTORISED log-probability: the walkers of a half-step are evaluated side by side
-        on the GPU (``nELBO_batch``; problems of N <= 128), each from the same warm-start state instead of from its
-        predecessor's -- the chain is then not the reference's walker for walker, the posterior it samples is.
+        on the GPU (``nELBO_batch``), each from the SAME warm-start state -- the one the object holds when the half-step
+        begins -- instead of from its predecessor's converged state (meanfield.py:1102-1104).  What that changes: an
+        evaluation is 100 sweeps at most under the 1e-3 stop rule, which fires when progress is slow, not when the fixed
+        point is near, so its value depends on where its loop started.  Measured on 40 prior draws of a small problem
+        (``tests/test_parity_gpu.py::test_mcmc_with_the_walkers_side_by_side``): side by side against chained, median
+        4e-4 relative, nine in ten within 4e-3, worst 0.17 -- and the reference's own chaining differs from itself by the
+        same amounts when the same vectors are evaluated in the opposite order.  The batched log-probabilities are
+        therefore as good an estimate of the objective as the reference's; the chain is not the reference's walker for
+        walker (one accept / reject decision that falls inside that spread sends the ensembles apart for good: a moved
+        walker changes every later proposal), the posterior it samples is.
         """
         assert self._components_set, _NOT_SET
         from emcee import EnsembleSampler, backends

@@ -176,6 +176,17 @@ int gprn_grad_matrices(gprn_ctx* ctx, int gp, double* Kinv_out, double* P_out);
  * gprn_set_kernel accepted.  GPRN_E_UNSUPPORTED for a latent GP whose matrix was uploaded (gprn_upload_K). */
 int gprn_grad_kernel(gprn_ctx* ctx, int gp, const double* m, double* grad_out);
 
+/* ---- the terms of the ELBO on their own: what the reference's private step methods return (meanfield.py:895-990 and
+ * 992-1067; ELBOaux :651-710 calls them in turn, and scripts written against the reference may too).
+ * expected_loglike: inference._expectedLogLike of the state last set (gprn_set_muvar: var = the diagonals of Sigma_f, Sigma_w)
+ * under the jitters last set (gprn_set_jitters); the raw data enter as in the reference (quirk Q3).
+ * prior_terms: for latent GP `gp` and a covariance S (N, N) / mean m (N) of the caller's choosing -- the reference pairs node j
+ * with the cumulative Sigma_f0 + ... + Sigma_fj and weight (j, i) with the raw-reshape row of mu_w (quirks Q1, Q2) -- from the
+ * factor of K_gp that gprn_factor_priors left on the device: out3 = { log det K_gp, m^T K_gp^-1 m, tr(K_gp^-1 S) }
+ * (:1029-1041, 1050-1062).  Unsharded contexts. */
+int gprn_expected_loglike(gprn_ctx* ctx, double* logl_out);
+int gprn_prior_terms(gprn_ctx* ctx, int gp, const double* S, const double* m, double* out3);
+
 /* ---- read-back for tests and the ELBOaux compatibility shim ---- */
 enum {
     GPRN_M_K = 0,        /* prior covariance K_gp (N,N) */
