@@ -318,6 +318,8 @@ def golden_check(ctx, a, N, p, q, t, ys):
     them, uncommitted, before the timed region.  `elbo_last` further down is the state after hundreds of sweeps and says
     nothing by itself (at q >= 3 the reference's own iteration diverges: DESIGN.md 3); this does."""
     tag = {1: 'cfg1_N200', 2: 'cfg2_N2048', 3: 'cfg3_N4096', 4: 'cfg4_N4096_q4'}.get(a.config)
+    if a.config == 5:
+        tag = 'cfg5shape_N%d' % N                           # config 5's shape at a reduced N (rehearsals): the reference's own sweeps
     path = os.path.join(ROOT, 'tests', 'golden', '%s.npz' % tag) if tag and not a.shape else None
     if not path or not os.path.exists(path):
         return None
@@ -336,6 +338,71 @@ def golden_check(ctx, a, N, p, q, t, ys):
             'elbo_rel_err': float(np.max(np.abs(elbo - ref) / np.abs(ref))),
             'parts_rel_err': float(np.max(np.abs(parts - d['parts_sweeps']) / np.abs(d['parts_sweeps']))),
             'bound': 1e-8}
+
+
+# what DESIGN.md 6 expects of a BASELINE multi-GPU config in its stated topology, from the partition alone (exchange cost not
+# included): the per-rank share of latent GPs measured as an ad-hoc shape on one GPU against the whole config on one GPU
+EXPECTED_CEILING = {
+    4: {'n_gpus': 4, 'sweeps_per_s': 195.0, 'vs_one_gpu': 3.2,
+        'why': '4 nodes + 12 weights over 4 ranks = 1 + 3 latent GPs each: that shape alone runs at 195 sweeps/s against 61.5 for all 16 on one GPU'},
+    5: {'n_gpus': 8, 'sweeps_per_s': 7.0, 'vs_one_gpu': 5.0,
+        'why': '3 nodes leave five GPUs idle in the node phase and 12 weights split 2/2/2/2/1/1/1/1: the weight phase takes the time of two matrices where one GPU (1.40 sweeps/s) takes twelve'},
+}
+
+
+def config_in_topology(cfg, world, rank, n_override=None, steps=5, blocks=3, warmup=1):
+    """BASELINE config `cfg` sharded over the ranks of THIS run -- the topology BASELINE.json states for it when world is 4
+    (config 4) or 8 (config 5): its own communicator, set-up, the reference's golden first sweeps where a fixture holds them,
+    then timed blocks of forced sweeps (barrier + device sync on both sides, MAX over ranks).  Collective: every rank calls
+    it; rank 0 gets the block for `configs_at_n_gpus`, the others None."""
+    N, p, q, kind = synth.CONFIGS[cfg]
+    if n_override:
+        N = int(n_override)
+    comm = sharding.Comm()
+    t, ys, es = synth.rv_series(N, p)
+    spec = synth.component_spec(p, q, kind)
+    nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+    g = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair], comm=comm)
+    g.set_components(nodes, weights, means, jit)
+    t0 = time.time()
+    ctx = g._setup_device(nodes, weights, means, jit)
+    ctx.barrier_max(0.0)
+    t_setup = time.time() - t0
+    mu0, var0 = g._initMuVar(nodes, weights, jit)
+    ctx.set_muvar(mu0, var0)
+
+    class _A:                                              # what golden_check reads of the command line
+        config, shape = cfg, (None if (not n_override or cfg == 5) else 'x')
+    golden = golden_check(ctx, _A, N, p, q, t, ys)         # (a sweep of a sharded context: every rank takes part)
+    if warmup > 0:
+        ctx.sweep(warmup, commit=True)
+    block_s = []
+    for _ in range(max(1, blocks)):
+        ctx.barrier_max(0.0)
+        t0 = time.perf_counter()
+        elbo, parts, info = ctx.sweep(steps, commit=True)
+        block_s.append(ctx.barrier_max(time.perf_counter() - t0))
+    dt = float(np.median(block_s))
+    out = None
+    if rank == 0:
+        own = sharding.owners(p, q, world)
+        out = {'config': cfg, 'workload': 'BASELINE config %d: N=%d, p=%d outputs, q=%d nodes%s' % (
+                   cfg, N, p, q, '' if not n_override else ' (N reduced for a rehearsal)'),
+               'value': steps / dt, 'unit': 'sweeps/s', 'ms_per_step': 1e3 * dt / steps, 'steps': steps, 'blocks': len(block_s),
+               'sweeps_per_s': {'median': steps / dt, 'min': steps / max(block_s), 'max': steps / min(block_s)},
+               'scaling': 'strong', 'dtype': 'f64', 'data': 'synthetic',
+               'latent_gps': q * (p + 1), 'latent_gps_per_rank': [own.count(r) for r in range(world)],
+               'nodes_per_rank': [own[:q].count(r) for r in range(world)],
+               'comm_ranks': ctx.world, 'transport': os.environ.get('GPRN_COMM_TRANSPORT', 'rccl'),
+               'sweep_tflops': sweep_flops(N, p, q) * steps / dt / 1e12,
+               'sweep_frac_of_n_gpu_peak': sweep_flops(N, p, q) * steps / dt / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+               'setup_s': t_setup, 'golden_check': golden, 'elbo_last': float(elbo[-1]), 'info': int(info),
+               'schedule': {'flags': int(ctx.option('flags')), 'fallbacks': int(ctx.option('fallbacks'))},
+               'expected_ceiling': EXPECTED_CEILING.get(cfg) if not n_override else None}
+    ctx.barrier_max(0.0)
+    comm.cleanup()
+    g._ctx.close() if getattr(g, '_ctx', None) is not None else None
+    return out
 
 
 def self_launch(a):
@@ -410,6 +477,10 @@ def main():
     ap.add_argument('--latency-cpu-s', type=float, default=20.0, help='seconds of CPU baseline per shape')
     ap.add_argument('--latency-batch', type=int, default=0, help='evaluations per side-by-side call (default 256 at one tile, 32 above)')
     ap.add_argument('--no-side', action='store_true', help='skip the side-by-side leg of --latency')
+    ap.add_argument('--also-config', default=None,
+                    help='C or C:N -- after the headline, BASELINE config C (at N, for rehearsals) sharded over the same ranks, '
+                         'reported under configs_at_n_gpus; default: config 4 at --gpus 4, config 5 at --gpus 8 (their stated '
+                         'topologies), "none" to skip')
     a = ap.parse_args()
     if a.latency:
         return latency(a)
@@ -522,6 +593,16 @@ def main():
     prof = ctx.profile_read()
     ctx.profile_enable([])
 
+    # BASELINE's multi-GPU configs in their stated topologies (config 4: 4 GPUs, config 5: 8 GPUs) ride along with the
+    # config-3 strong-scaling headline of a run that has exactly that many ranks
+    extra = {}
+    also = a.also_config if a.also_config is not None else {4: '4', 8: '5'}.get(world, 'none')
+    if world > 1 and also != 'none' and not a.shape:
+        cfg_s, _, n_s = also.partition(':')
+        blk = config_in_topology(int(cfg_s), world, rank, n_override=int(n_s) if n_s else None)
+        if rank == 0:
+            extra['config %s on %d ranks' % (cfg_s, world)] = blk
+
     if rank == 0:
         nodes_l, weights_l = sharding.local_gps(p, q, world, 0)
         ms_upd, n_upd = prof['update']
@@ -602,6 +683,7 @@ def main():
                                     'achieved': fl_ahd / (ms_ahd * 1e-3) / 1e12} if n_ahd else None),
             },
         }
+        out['configs_at_n_gpus'] = extra or None
         out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
     if comm is not None:

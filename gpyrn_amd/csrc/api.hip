@@ -4,6 +4,7 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -184,6 +185,98 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
     return rc;
 }
 
+// ------------------------------------------------------------------ the collective watchdog
+// A collective has no time-out of its own: a rank that dies inside one (or never enters it) leaves the others waiting --
+// RCCL kernels spinning on the device, the host in the stream synchronisation behind them -- until somebody kills the job,
+// holding their GPUs meanwhile.  Every entry point that issues collectives on a context with a communicator therefore
+// runs under a watch: a detached thread (one per process) looks at the open watches every 200 ms, and when one has been
+// open longer than the context's budget (option "comm_budget_s", default 600 s; GPRN_COMM_BUDGET_S) it says which entry
+// point, which collective was enqueued last and which rank, and ends the process with a non-zero status (_exit: no
+// restart, no re-exec, no unwinding through a runtime that is blocked).  The launcher then sees a failed rank and stops
+// the others (bench.py's self-launcher, torchrun).
+struct WatchEntry {
+    std::atomic<long long> since_ms{0};        // 0: nothing open
+    std::atomic<const char*> what{nullptr};    // the entry point
+    std::atomic<const char*> last{nullptr};    // the collective enqueued last
+    std::atomic<int> budget_s{600}, rank{0}, world{1};
+};
+static std::mutex g_watch_mu;
+static std::vector<WatchEntry*> g_watch;
+static bool g_watch_thread = false;
+
+static long long now_ms()
+{
+    timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    return (long long)t.tv_sec * 1000 + t.tv_nsec / 1000000;
+}
+
+static void* watchdog_main(void*)
+{
+    for (;;) {
+        usleep(200000);
+        std::lock_guard<std::mutex> g(g_watch_mu);
+        const long long now = now_ms();
+        for (WatchEntry* w : g_watch) {
+            const long long since = w->since_ms.load();
+            if (!since || now - since <= 1000ll * w->budget_s.load()) continue;
+            const char* what = w->what.load();
+            const char* last = w->last.load();
+            fprintf(stderr, "[gprn] rank %d of %d: %s has been inside a collective section for more than %d s (last collective "
+                            "enqueued: %s); another rank has died or never arrived -- giving up the GPU (exit 86)\n",
+                    w->rank.load(), w->world.load(), what ? what : "?", w->budget_s.load(), last ? last : "none yet");
+            fflush(stderr);
+            _exit(86);
+        }
+    }
+    return nullptr;
+}
+
+static WatchEntry* watch_register(gprn_ctx* c)
+{
+    std::lock_guard<std::mutex> g(g_watch_mu);
+    WatchEntry* w = new WatchEntry();
+    const char* e = getenv("GPRN_COMM_BUDGET_S");
+    w->budget_s = c->comm_budget_s > 0 ? c->comm_budget_s : (e && atoi(e) > 0 ? atoi(e) : 600);
+    w->rank = c->rank; w->world = c->world;
+    g_watch.push_back(w);
+    if (!g_watch_thread) {
+        pthread_t th;
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&th, &at, watchdog_main, nullptr) == 0) g_watch_thread = true;
+        pthread_attr_destroy(&at);
+    }
+    return w;
+}
+
+static void watch_unregister(gprn_ctx* c)
+{
+    if (!c->watch) return;
+    std::lock_guard<std::mutex> g(g_watch_mu);
+    WatchEntry* w = (WatchEntry*)c->watch;
+    g_watch.erase(std::remove(g_watch.begin(), g_watch.end(), w), g_watch.end());
+    delete w;
+    c->watch = nullptr;
+}
+
+// held by an entry point for as long as its collectives may be outstanding (nested scopes: the outermost one counts)
+struct WatchScope {
+    WatchEntry* w; bool outer;
+    WatchScope(gprn_ctx* c, const char* what) : w(c ? (WatchEntry*)c->watch : nullptr), outer(false)
+    {
+        if (!w || w->since_ms.load()) return;
+        outer = true;
+        w->what = what; w->last = nullptr;
+        w->since_ms = now_ms();
+    }
+    ~WatchScope() { if (w && outer) w->since_ms = 0; }
+};
+static inline void watch_note(gprn_ctx* c, const char* collective)
+{
+    if (c->watch) ((WatchEntry*)c->watch)->last = collective;
+}
+
 // Per-context switches (tests, experiments).  Returns the previous value through *old when given.
 //   "flags"          1/0: device-side flags or HIP events for the factorisation's cross-stream dependencies
 //   "wait_budget_ms" wall-clock budget of one in-kernel wait
@@ -196,6 +289,7 @@ static int with_event_fallback(gprn_ctx* c, const char* what, F&& body, bool col
 //                    phase, 8 log det B in k_finalize, 16 a sweep's end beside the next sweep); 0 = everything in sequence
 //                    as in rounds 1-2; -1: the default (31).  Results are bit-identical for every value
 //   "batch_mem_mb"   device memory (MiB) one chunk of gprn_elbocalc_batch's evaluations may take; longer lists run chunk by chunk
+//   "comm_budget_s"  seconds an entry point may stay inside its collective section before the watchdog ends the process
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
@@ -210,6 +304,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "bulk_pad_kb")) field = &c->pad_kb_opt;
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "batch_mem_mb")) field = &c->batch_mem_mb;
+    else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
@@ -223,7 +318,9 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
         }
         if (field == &c->wait_budget_ms && value < 1) return bad(c, "set_option: wait_budget_ms >= 1");
         if (field == &c->batch_mem_mb && value < 1) return bad(c, "set_option: batch_mem_mb >= 1");
+        if (field == &c->comm_budget_s && value < 1) return bad(c, "set_option: comm_budget_s >= 1");
         *field = value;
+        if (field == &c->comm_budget_s && c->watch) ((WatchEntry*)c->watch)->budget_s = value;
     }
     return GPRN_OK;
 }
@@ -643,7 +740,8 @@ static int shm_barrier(gprn_ctx* c, ShmComm* sc)
         sched_yield();
         if ((spin & 1023) == 1023) {
             timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
-            if (t1.tv_sec - t0.tv_sec > 120) { c->err = "shm transport: barrier timed out (a rank died?)"; return GPRN_E_COMM; }
+            const int budget = c->watch ? ((WatchEntry*)c->watch)->budget_s.load() : 120;
+            if (t1.tv_sec - t0.tv_sec > budget + 5) { c->err = "shm transport: barrier timed out (a rank died?)"; return GPRN_E_COMM; }
         }
     }
     return GPRN_OK;
@@ -717,6 +815,7 @@ static int shm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max)
 // ---- the three collectives of the path, on whichever transport the context has ----
 static int comm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
 {
+    watch_note(c, "row broadcast");
     if (c->shm) return shm_broadcast(c, buf, n, root);
     NCCL_TRY(c, g_rccl.Broadcast(buf, buf, n, ncclDouble, root, (ncclComm_t)c->comm, c->stream));
     return GPRN_OK;
@@ -724,6 +823,7 @@ static int comm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
 
 static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max)
 {
+    watch_note(c, is_max ? "max all-reduce (agreement / barrier)" : "sum all-reduce (per-GP scalars)");
     if (c->shm) return shm_allreduce(c, buf, n, is_max);
     NCCL_TRY(c, g_rccl.AllReduce(buf, buf, n, ncclDouble, is_max ? ncclMax : ncclSum, (ncclComm_t)c->comm, c->stream));
     return GPRN_OK;
@@ -751,6 +851,7 @@ extern "C" int gprn_comm_unique_id(char* id128)
 
 static void comm_teardown(gprn_ctx* c)
 {
+    watch_unregister(c);
     if (c->comm && g_rccl_handle) g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
     shm_close_comm(c);
@@ -767,13 +868,18 @@ extern "C" int gprn_comm_init(gprn_ctx* c, int world, int rank, const char* id12
     // a one-rank communicator is legal RCCL and lets a single GPU exercise every collective call
     if (world == 1 && !getenv("GPRN_FORCE_RCCL")) return GPRN_OK;
     if (!id128) return bad(c, "comm_init: id required");
-    if (!memcmp(id128, "gprnshm", 8)) return shm_open_comm(c, world, rank, id128);
+    if (!memcmp(id128, "gprnshm", 8)) {
+        const int rc = shm_open_comm(c, world, rank, id128);
+        if (!rc) c->watch = watch_register(c);
+        return rc;
+    }
     TRY(rccl_load(&c->err));
     ncclUniqueId id;
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm;
     NCCL_TRY(c, g_rccl.CommInitRank(&comm, world, id, rank));
     c->comm = comm;
+    c->watch = watch_register(c);
     return GPRN_OK;
 }
 
@@ -792,6 +898,7 @@ extern "C" int gprn_set_owners(gprn_ctx* c, const int* owner)
 extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 {
     DeviceLock lock_(c);
+    WatchScope watch_(c, "gprn_comm_barrier_max");
     if (!c || !value) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (comm_active(c)) {
@@ -813,6 +920,7 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
 extern "C" int gprn_comm_allreduce_sum(gprn_ctx* c, double* buf, int n)
 {
     DeviceLock lock_(c);
+    WatchScope watch_(c, "gprn_comm_allreduce_sum");
     if (!c || !buf || n < 0) return bad(c, "comm_allreduce_sum: bad argument");
     if (!comm_active(c) || n == 0) return GPRN_OK;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -947,6 +1055,7 @@ static int factor_priors_impl(gprn_ctx* c);
 extern "C" int gprn_factor_priors(gprn_ctx* c)
 {
     DeviceLock lock_(c);
+    WatchScope watch_(c, "gprn_factor_priors");
     if (!c || !c->N) return bad(c, "factor_priors: call set_data first");
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->owner.empty()) return bad(c, "factor_priors: call set_owners first");
@@ -1265,6 +1374,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
 extern "C" int gprn_sweep(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, double* parts_out)
 {
     DeviceLock lock_(c);
+    WatchScope watch_(c, "gprn_sweep");
     if (!c) return GPRN_E_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     int pre = GPRN_OK;
@@ -1545,34 +1655,39 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
                              int* converged, double* mu_out, double* var_out)
 {
     DeviceLock lock_(c);
-    if (!c || !c->N || max_iter < 0 || !history || cap < 1 || !n_history || !iterations || !converged || (!mu != !var) ||
+    if (!c) return GPRN_E_ARG;
+    WatchScope watch_(c, "gprn_elbocalc");
+    // On a sharded context every LOCAL finding -- arguments, call order, a setter that fails -- goes into `pre`, and the
+    // ranks agree on it before the first collective of the call (the set-up's own): a rank that returned here on its own
+    // would leave the others in gprn_factor_priors' all-reduce.
+    int pre = GPRN_OK;
+    if (!c->N || max_iter < 0 || !history || cap < 1 || !n_history || !iterations || !converged || (!mu != !var) ||
         (!mu_out != !var_out))
-        return bad(c, "elbocalc: bad argument");
-    HIP_TRY(c, hipSetDevice(c->device));
-    if (do_setup) {
-        if (c->owner.empty()) return bad(c, "elbocalc: call set_owners first");
-        for (int g = 0; g < c->G; ++g)
-            if (!c->kspec[g].set) return bad(c, "elbocalc: a latent GP has no kernel");
+        pre = bad(c, "elbocalc: bad argument");
+    if (!pre && hipSetDevice(c->device) != hipSuccess) { c->err = "hipSetDevice"; pre = GPRN_E_HIP; }
+    if (!pre && do_setup) {
+        if (c->owner.empty()) pre = bad(c, "elbocalc: call set_owners first");
+        for (int g = 0; g < c->G && !pre; ++g)
+            if (!c->kspec[g].set) pre = bad(c, "elbocalc: a latent GP has no kernel");
     }
     std::vector<double> hist;
     int iter = 0, conv = 0, info = 0;
-    if (small_applies(c)) {
+    if (!pre && small_applies(c)) {
         const ElboIo io{do_setup, y_resid, jitters, mu, var, mu_out, var_out};
         TRY(elbocalc_small(c, io, max_iter, hist, &iter, &conv, &info));
     } else {
         int rc;
-        if (y_resid && (rc = gprn_set_y_resid(c, y_resid))) return rc;
-        if (jitters && (rc = gprn_set_jitters(c, jitters))) return rc;
-        if (mu && (rc = gprn_set_muvar(c, mu, var))) return rc;
+        if (!pre && y_resid) pre = gprn_set_y_resid(c, y_resid);
+        if (!pre && jitters) pre = gprn_set_jitters(c, jitters);
+        if (!pre && mu) pre = gprn_set_muvar(c, mu, var);
+        if (!pre && (!c->have_yres || !c->have_jit || !c->have_muvar || (!do_setup && !c->factored)))
+            pre = bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
+        if ((pre = agree_to_start(c, pre, "elbocalc"))) return pre;
         if (do_setup) {
             rc = gprn_factor_priors(c);
             if (rc < 0) return rc;
             info = rc;
         }
-        int pre = GPRN_OK;
-        if (!c->factored || !c->have_yres || !c->have_jit || !c->have_muvar)
-            pre = bad(c, "elbocalc: needs the set-up, y_resid, jitters and the state (given or set before)");
-        if ((pre = agree_to_start(c, pre, "elbocalc"))) return pre;
         double e = 0.0;
         // Quirk Q7: the first ELBOaux call's update is discarded and its ELBO kept as elboArray[0] (:627-628); the loop's
         // first trip then repeats that very call (same state in, :636) -- elboArray[1] == elboArray[0] by construction.
@@ -1739,6 +1854,7 @@ __global__ void k_add_to_diagonal(double* __restrict__ A, int ld, const double* 
 extern "C" int gprn_predict(gprn_ctx* c, int ns, const double* tstar, double* mean_out, double* var_out)
 {
     DeviceLock lock_(c);
+    WatchScope watch_(c, "gprn_predict");
     if (!c || !c->N) return bad(c, "predict: bad argument");
     if (c->owner.empty()) return bad(c, "predict: call set_owners first");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -134,6 +134,8 @@ struct gprn_ctx {
     void* comm = nullptr;            // ncclComm_t
     void* shm = nullptr;             // ShmComm: rehearsal transport of one-GPU boxes (api.hip)
     double* d_agree = nullptr;       // one word: did any rank's call time out (with_event_fallback, api.hip)
+    void* watch = nullptr;           // WatchEntry (api.hip): this context's slot of the collective watchdog, while it has a communicator
+    int comm_budget_s = -1;          // gprn_set_option "comm_budget_s"; -1: GPRN_COMM_BUDGET_S or 600
 
     // ---- per latent GP, persistent across sweeps (only for GPs this rank needs)
     std::vector<KernelSpec> kspec;   // G

@@ -233,6 +233,9 @@ int gprn_elbocalc(gprn_ctx* ctx, int do_setup, const double* y_resid, const doub
                   const double* var, int max_iter, double* history, int cap, int* n_history, int* iterations,
                   int* converged, double* mu_out, double* var_out);
 
+/* (On a sharded context every local finding of gprn_elbocalc -- arguments, call order, a failing setter -- is agreed between
+ * the ranks before its first collective: either every rank goes on or every rank returns.) */
+
 /* n_eval INDEPENDENT evaluations of the same problem at n_eval parameter vectors -- what scipy's simplex or emcee's
  * walkers ask inference.nELBO for one after the other (meanfield.py:1095-1111, 1222-1260) -- side by side on the device:
  * every launch covers all of them, each evaluation with its own covariance matrices, factors, state, loop and stop rule.
@@ -241,8 +244,13 @@ int gprn_elbocalc(gprn_ctx* ctx, int do_setup, const double* y_resid, const doub
  *   y_resid [n_eval][p N], jitters [n_eval][p], mu / var [n_eval][d]: per evaluation, as for gprn_elbocalc.
  * Out per evaluation: the last ELBO of its loop, its trip count, whether the stop rule fired, its info (> 0: a pivot
  * failed, the ELBO is NaN), and (or both NULL) the state it ended in, [n_eval][d].
- * One-tile problems (N <= 128) on one rank with device kernels only: GPRN_E_UNSUPPORTED otherwise (the caller evaluates
- * one by one).  The context's own state and factors are not touched. */
+ * One rank, device kernels only (every latent GP's kernel given by gprn_set_kernel, even in t_i - t_j): GPRN_E_UNSUPPORTED
+ * otherwise (the caller evaluates one by one).  One-tile problems (N <= 128) run a half-sweep of ALL evaluations as one
+ * launch (csrc/smalln.hip); larger ones go through the launch schedule of the large problems with its batch dimension =
+ * evaluations x latent GPs of the phase, an evaluation that has stopped leaving the next sweep's launches (csrc/midn.hip).
+ * Lists longer than the memory budget (option "batch_mem_mb") run chunk by chunk.  The context's own state and factors
+ * are not touched.  An evaluation whose factorisation fails returns info > 0 and a NaN ELBO at once (the reference's loop
+ * would carry the NaN to max_iter: iterations reports max_iter). */
 int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, int n_kernel_params,
                         const double* y_resid, const double* jitters, const double* mu, const double* var,
                         int max_iter, double* elbo, int* iterations, int* converged, int* info,
@@ -261,8 +269,12 @@ int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, 
  * panel, 4 node term beside the weight phase, 8 log det B in the finalising kernel, 16 a sweep's end beside the
  * next sweep's node phase; results are bit-identical for every value); "small_path" (1, the default: problems of
  * one tile -- N <= 128 -- run each half-sweep as ONE launch, one workgroup per latent GP, csrc/smalln.hip; 2: problems
- * of two tiles too; 0: the launch schedule at every size; same results to rounding).  value == -1 only reads; *old (may be NULL) receives the previous
- * value. */
+ * of two tiles too; 0: the launch schedule at every size; same results to rounding); "batch_mem_mb" (device memory, MiB, that
+ * one chunk of gprn_elbocalc_batch's evaluations may take: longer lists run chunk by chunk; default: half of what is free, 48 GiB
+ * at most); "comm_budget_s" (sharded contexts: seconds an entry point may stay inside its collective section -- a rank that
+ * died leaves the others there -- before the library's watchdog names the entry point, the collective and the rank on
+ * stderr and ends the process with status 86; default 600, or GPRN_COMM_BUDGET_S).  value == -1 only reads; *old (may be
+ * NULL) receives the previous value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 
 /* ---- diagnostic entry points: one kernel each, for tests/test_kernels_gpu.py ----

@@ -52,6 +52,16 @@ def main(tag, out, uid_tag):
         comm.cleanup()
         return
     ctx.set_muvar(d['mu_init'], d['var_init'])
+    if os.environ.get('GPRN_TEST_LONG_SWEEPS'):
+        # the watchdog test: sweep until killed.  A marker file says that this rank is past its first call (the harness kills
+        # one rank after both markers exist: the other is then inside a sweep's collectives, or about to enter them)
+        ctx.sweep(1, commit=True)
+        open(out + '.started', 'w').close()
+        for _ in range(int(os.environ['GPRN_TEST_LONG_SWEEPS'])):
+            ctx.sweep(5, commit=False)
+        np.savez(out, rank=comm.rank, world=comm.world, message='ran to the end')
+        comm.cleanup()
+        return
     hook_rank = int(os.environ.get('GPRN_TEST_WITHHOLD_RANK', -1))
     if hook_rank == comm.rank:
         # this rank only: a producer flag that never goes up, so that its in-kernel wait gives up after 20 ms

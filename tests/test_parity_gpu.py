@@ -835,6 +835,49 @@ def test_a_rank_that_fails_its_checks_stops_every_rank(tmp_path):
     assert 'another rank did not pass its checks' in msgs[0]
 
 
+def test_a_rank_that_dies_inside_a_sweep_does_not_hold_the_others(tmp_path):
+    """a collective has no time-out -- a rank that dies inside one left the others holding their GPUs
+    until the launcher's 1500 s limit.  Every collective entry point now runs under the library's watchdog (csrc/api.hip):
+    two ranks sweep in a loop (shm transport, one GPU), rank 1 is killed from outside once both are under way, and rank 0
+    must end ITSELF -- non-zero status, a line that names the entry point, the collective and the rank -- within its budget
+    (5 s here; 600 s by default), without restarting anything."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    budget = 5
+    procs, outs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(20000 + os.getpid() % 20000), GPRN_COMM_TRANSPORT='shm',
+                   GPRN_TEST_LONG_SWEEPS='100000', GPRN_COMM_BUDGET_S=str(budget))
+        out = str(tmp_path / f'rank{r}.npz')
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, '-m', 'tests._shard_worker', 'mid_N300_p3q2', out,
+                                       f'{os.getpid()}_watchdog'], cwd=root, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    try:
+        t0 = time.time()
+        while not all(os.path.exists(o + '.started') for o in outs):
+            assert time.time() - t0 < 240, 'the ranks never got under way'
+            assert all(pr.poll() is None for pr in procs), 'a rank ended before the test began'
+            time.sleep(0.05)
+        time.sleep(0.5)                                        # both are inside their loops of sweeps now
+        procs[1].send_signal(signal.SIGKILL)
+        t_kill = time.time()
+        log0, _ = procs[0].communicate(timeout=budget + 60)
+        waited = time.time() - t_kill
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    log0 = log0.decode(errors='replace')
+    assert procs[0].returncode == 86, log0
+    assert 'inside a collective section' in log0 and 'rank 0 of 2' in log0 and 'gprn_sweep' in log0, log0
+    assert waited < budget + 10, 'rank 0 held on for %.0f s after rank 1 had died' % waited
+
+
 @pytest.mark.parametrize('tag,world,user', [('step_p3q2', 2, False), ('step_p2q3', 3, False), ('mid_N300_p3q2', 2, True)])
 def test_sharded_prediction(tag, world, user, tmp_path):
     """inference._Prediction on a sharded object (meanfield.py:1289-1381; _gp.py:107-138 per latent GP): the owners
