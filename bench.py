@@ -83,7 +83,7 @@ def pmc_traffic():
     """HBM bytes per bulk-update launch from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
     coalesced reads on gfx950).  Produced by profiles/summarize_pmc.py; None if absent."""
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_bulk_update.json')) as f:
                 return json.load(f)['hbm_bytes_per_launch']
@@ -96,7 +96,7 @@ def pmc_mfma():
     """MFMA-pipe utilisation of the bulk-update launches from the committed rocprofv3 PMC pass
     (SQ_VALU_MFMA_BUSY_CYCLES against 1024 SIMDs x launch time x the clock GRBM_GUI_ACTIVE gives; kernels
     serialised by counter collection; profiles/summarize_r02.py)."""
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd + '_pmc_mfma_util.json')) as f:
                 d = json.load(f)
@@ -110,7 +110,7 @@ def pmc_mfma():
 
 def k512_union():
     """Union-time figures of the K = 512 launches from the committed kernel trace (profiles/summarize_r02.py union)."""
-    for rnd in ('r04', 'r03'):
+    for rnd in ('r05', 'r04', 'r03'):
         try:
             with open(os.path.join(ROOT, 'profiles', rnd + '_k512_union.json')) as f:
                 d = json.load(f)
@@ -266,7 +266,7 @@ def latency(a):
         side = None
         if N <= g.batch_max_N and not a.no_side:
             with contextlib.redirect_stdout(io.StringIO()):
-                nb = a.latency_batch if a.latency_batch > 0 else (256 if N <= 128 else 32)
+                nb = a.latency_batch if a.latency_batch > 0 else (256 if N <= 256 else 32)
                 xb = [x0 * (1.0 + 0.01 * rng.standard_normal(x0.size)) for _ in range(nb)]
                 g.nELBO_batch(xb)                                # buffers (sized by the list)
                 best = None
@@ -475,7 +475,7 @@ def main():
     ap.add_argument('--latency-reps', type=int, default=0, help='evaluations per shape (default 200, 40 at N = 2048)')
     ap.add_argument('--latency-only', default='', help='comma-separated N of the shapes to run (default: all four)')
     ap.add_argument('--latency-cpu-s', type=float, default=20.0, help='seconds of CPU baseline per shape')
-    ap.add_argument('--latency-batch', type=int, default=0, help='evaluations per side-by-side call (default 256 at one tile, 32 above)')
+    ap.add_argument('--latency-batch', type=int, default=0, help='evaluations per side-by-side call (default 256 up to two tiles, 32 above)')
     ap.add_argument('--no-side', action='store_true', help='skip the side-by-side leg of --latency')
     ap.add_argument('--also-config', default=None,
                     help='C or C:N -- after the headline, BASELINE config C (at N, for rehearsals) sharded over the same ranks, '
