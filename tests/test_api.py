@@ -267,7 +267,7 @@ def test_inference_has_the_reference_methods_with_their_signatures():
         'mcmc': ['priors', 'p0', 'vars', 'niter'],
         'predict': ['tstar', 'nn'],
         '_KMatrix': ['kernel', 'time'],
-        '_initMuVar': ['nodes', 'weights', 'jitters'],
+        '_initMuVar': ['nodes', 'weights', 'jitter'],
         '_u_to_fhatW': ['u'],
         'sample': ['time'],
     }
