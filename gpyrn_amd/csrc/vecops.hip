@@ -342,16 +342,18 @@ void k_reduce_finalize(const int* __restrict__ slot_gp, int N, int ld, int T, in
         if (n < N) {
             mu[row * N + n] = (z[o] - b) / s[o];
             var[row * N + n] = (1.0 - a) / d[o];
-            tt[n] = a;
-            if (Lm) tt[ld + n] = log(Lm[(size_t)n * ld + n]);
+            // (the terms go to the last workgroup of this launch, possibly on another XCD: agent-scope stores -- written
+            // through -- and loads, no fence.  A __threadfence() here is an L2 write-back per workgroup, on an L2 full of
+            // the factorisation's freshly written tiles: 84 us for the 192 matrices of a batch's weight phase)
+            __hip_atomic_store(tt + n, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (Lm) __hip_atomic_store(tt + ld + n, log(Lm[(size_t)n * ld + n]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread's stores acknowledged, then the workgroup's ticket
     __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(tickets + slot, 1u) + 1 == gridDim.x ? 1u : 0u;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(tickets + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gridDim.x ? 1u : 0u;
     __syncthreads();
     if (!last) return;                              // (uniform)
-    __threadfence();
     double tr = 0.0, ld_acc = 0.0;
     for (int m = threadIdx.x; m < N; m += 256) {
         tr += __hip_atomic_load(tt + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
