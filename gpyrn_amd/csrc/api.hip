@@ -276,6 +276,13 @@ static inline void watch_note(gprn_ctx* c, const char* collective)
 {
     if (c->watch) ((WatchEntry*)c->watch)->last = collective;
 }
+// the host has just seen the device finish everything enqueued so far (a stream synchronisation returned): the open
+// watch, if any, starts counting again -- the budget bounds the time WITHOUT such progress, not the length of a call
+static inline void watch_progress(gprn_ctx* c)
+{
+    WatchEntry* w = (WatchEntry*)c->watch;
+    if (w && w->since_ms.load()) w->since_ms = now_ms();
+}
 
 // Per-context switches (tests, experiments).  Returns the previous value through *old when given.
 //   "flags"          1/0: device-side flags or HIP events for the factorisation's cross-stream dependencies
@@ -733,6 +740,7 @@ static int shm_barrier(gprn_ctx* c, ShmComm* sc)
     if (sc->hdr->count.fetch_add(1) + 1 == sc->world) {
         sc->hdr->count.store(0);
         sc->hdr->sense.store(sc->local_sense);
+        watch_progress(c);
         return GPRN_OK;
     }
     timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
@@ -744,6 +752,7 @@ static int shm_barrier(gprn_ctx* c, ShmComm* sc)
             if (t1.tv_sec - t0.tv_sec > budget + 5) { c->err = "shm transport: barrier timed out (a rank died?)"; return GPRN_E_COMM; }
         }
     }
+    watch_progress(c);
     return GPRN_OK;
 }
 
@@ -1442,6 +1451,12 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
             std::swap(c->d_mu, c->d_mu_alt);
             std::swap(c->d_var, c->d_var_alt);
             continue;
+        }
+        if (comm_active(c) && it > 0 && (it & 63) == 0) {
+            // a long call on a sharded context: let the host see the device's progress now and then, so that the collective
+            // watchdog's budget bounds a STALL (a rank that died) and not the legitimate length of the call
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            watch_progress(c);
         }
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));

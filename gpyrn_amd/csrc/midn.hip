@@ -102,7 +102,8 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
 {
     MidBatch* m = (MidBatch*)c->mid_batch;
     const size_t per = mid_bytes_per_eval(c);
-    const int fit = (int)std::max<size_t>(1, std::min<size_t>(batch_budget_bytes(c) / per, 1 << 16));
+    // (a launch's grid y is the number of slots of a phase: cap x G stays far below its 65 535 limit)
+    const int fit = (int)std::max<size_t>(1, std::min<size_t>(batch_budget_bytes(c) / per, (size_t)32768 / c->G));
     want = std::min(want, fit);
     const bool same = m && m->N == c->N && m->p == c->p && m->q == c->q && m->ld == c->ld;
     if (same && m->cap >= want && m->cap <= fit) { *cap_out = m->cap; return GPRN_OK; }

@@ -688,7 +688,7 @@ int small_batch_chunk(gprn_ctx* c)
     const size_t nn = (size_t)c->ld * c->ld, d = (size_t)(c->p + 1) * c->q * c->N;
     const size_t per = ((4 * (size_t)c->G + c->q) * nn + 7 * (size_t)c->G * c->ld + 6 * d + 4 * (size_t)c->p * c->N + 256) * sizeof(double) +
                        (size_t)c->G * fill_program_bytes() * 2;
-    return (int)std::max<size_t>(16, std::min<size_t>(batch_budget_bytes(c) / per, 1 << 16));
+    return (int)std::max<size_t>(16, std::min<size_t>(batch_budget_bytes(c) / per, 32768));   // (grid y = evaluations)
 }
 
 static int small_batch_ensure(gprn_ctx* c, int n_eval)
