@@ -186,6 +186,8 @@ LATENCY_SHAPES = [
     # name, N, p, q, components
     ('notebook', 45, 1, 1, 'notebook'),       # one_dataset.ipynb: Periodic(1, 13, 1) node, SE(1, 50) weight, jitter 0.1
     ('config 1', 200, 1, 1, 'SE'),            # BASELINE config 1
+    ('solar-sized', 497, 4, 1, 'QP'),         # the size of the reference's one real dataset (datasets/Solar_observations.txt:
+                                              # 497 epochs; RV + three activity indicators as outputs, one node), synthetic values
     ('mid', 512, 3, 2, 'QP'),                 # the shape of tests/golden/mid_N512_p3q2
     ('config 2', 2048, 1, 1, 'QP'),           # BASELINE config 2
 ]
@@ -471,9 +473,9 @@ def main():
                     help='N,p,q of an ad-hoc problem (experiments; not a BASELINE config)')
     ap.add_argument('--blocks', type=int, default=20, help='timed blocks of --steps sweeps each')
     ap.add_argument('--latency', action='store_true',
-                    help='the small-N regime instead: nELBO evaluations/s at N = 45, 200, 512, 2048 (one JSON line each)')
+                    help='the small-N regime instead: nELBO evaluations/s at N = 45, 200, 497, 512, 2048 (one JSON line each)')
     ap.add_argument('--latency-reps', type=int, default=0, help='evaluations per shape (default 200, 40 at N = 2048)')
-    ap.add_argument('--latency-only', default='', help='comma-separated N of the shapes to run (default: all four)')
+    ap.add_argument('--latency-only', default='', help='comma-separated N of the shapes to run (default: all five)')
     ap.add_argument('--latency-cpu-s', type=float, default=20.0, help='seconds of CPU baseline per shape')
     ap.add_argument('--latency-batch', type=int, default=0, help='evaluations per side-by-side call (default 256 up to two tiles, 32 above)')
     ap.add_argument('--no-side', action='store_true', help='skip the side-by-side leg of --latency')
