@@ -384,7 +384,7 @@ def test_every_slot_of_a_batch_above_one_tile_reproduces_the_reference(tag, B):
 
 @pytest.mark.parametrize('n,p,q,kind,B,budget_mb', [(200, 1, 1, 'SE', 6, 0), (300, 3, 2, 'QP', 9, 0), (512, 3, 2, 'QP', 32, 0),
                                                     (260, 2, 3, 'QP', 5, 0), (300, 2, 2, 'QP', 11, 80), (1024, 1, 1, 'QP', 4, 0)])
-def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb):
+def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb, capsys):
     """inference.nELBO_batch above one tile: B PERTURBED parameter vectors side by side against the same evaluations one by
     one from the same starting state, cold (each from its own _initMuVar state) and warm (all from one converged state) --
     values to 1e-9 and, through them, trip counts; evaluations that stop at different trips leave the launches one by one
@@ -408,7 +408,9 @@ def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb):
     rng = np.random.RandomState(11)
     sets = [x0 * (1.0 + 0.05 * rng.standard_normal(x0.size)) + 0.01 * rng.standard_normal(x0.size) * (x0 == 0)
             for _ in range(B)]
+    capsys.readouterr()
     got = np.array(g.nELBO_batch(sets, max_iter=max_iter))
+    assert 'evaluations side by side' in capsys.readouterr().out, 'the list was evaluated one by one: no batched form?'
     assert g.last_info == 0 and np.all(np.isfinite(got))
     gs = fresh()
     want, trips = [], []
@@ -435,6 +437,48 @@ def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb):
         assert len(set(trips)) > 1, 'every evaluation stopped at the same trip: the compaction was not exercised'
     _assert_default_schedule(g._backend())
     _assert_default_schedule(gs._backend())
+
+
+@pytest.mark.parametrize('n', [77, 497])
+def test_nelbo_batch_with_composite_kernels_ragged_sizes_and_a_capped_loop(n, capsys):
+    """The side-by-side forms (one tile / above) on what the other batch tests leave out: kernel EXPRESSIONS (a Sum and a
+    Multiplication tree: the fill's postfix-program path, each evaluation with its own parameters), a Matern weight (a
+    built-in without host-computed reciprocals), sizes that end inside a 16-column block and a tile (77; 497, the
+    reference's solar table), non-zero Linear / Constant means, and a max_iter that cuts some loops short while others stop
+    by the rule -- against the same evaluations one by one from the same state."""
+    p, q = 2, 1
+    t, ys, es = synth.rv_series(n, p)
+
+    def fresh():
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        node = covfunc.QuasiPeriodic(1.1, 40.0, 25.0, 0.8) + covfunc.SquaredExponential(0.4, 5.0)
+        weights = [covfunc.SquaredExponential(1.0, 70.0) * covfunc.Periodic(1.0, 33.0, 1.2), covfunc.Matern32(0.9, 45.0)]
+        g.set_components([node], weights, [meanfunc.Linear(0.001, 0.2), meanfunc.Constant(-0.1)], [0.4, 0.6])
+        return g
+
+    g = fresh()
+    kernels = list(g.nodes) + list(g.weights)
+    if any(k._device_program() is None for k in kernels):
+        pytest.skip('a composite of this test has no device program')
+    # (Sum / Multiplication keep the reference's quirk: set_parameters updates the composite's own vector, which is what the
+    # device program reads -- covfunc.py:56-62)
+    x0 = np.array(g.get_parameters(), dtype=float)
+    rng = np.random.RandomState(21)
+    B = 9
+    sets = [x0 * (1.0 + 0.04 * rng.standard_normal(x0.size)) for _ in range(B)]
+    for max_iter in (5, None):
+        g = fresh()
+        capsys.readouterr()
+        got = np.array(g.nELBO_batch(sets, max_iter=max_iter))
+        assert 'evaluations side by side' in capsys.readouterr().out, 'the list was evaluated one by one: no batched form?'
+        assert g.last_info == 0 and np.all(np.isfinite(got))
+        gs = fresh()
+        want = []
+        for x in sets:
+            gs.set_parameters(x)
+            want.append(-gs.ELBOcalc(max_iter=max_iter)[0])
+        np.testing.assert_allclose(got, want, rtol=1e-9)
+    _assert_default_schedule(g._backend())
 
 
 @pytest.mark.parametrize('n,p,q', [(60, 2, 2), (45, 1, 1)])
