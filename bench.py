@@ -283,6 +283,42 @@ def latency(a):
                     'schedule': {'flags': int(ctx.option('flags')), 'fallbacks': int(ctx.option('fallbacks'))},
                     'note': 'inference.nELBO_batch: every evaluation with its own matrices, state, loop and stop rule, all in the '
                             'same launches; what an optimiser population or emcee walkers ask for (best of 3 calls)'}
+        # ... and what a user of the reference sees of it: inference.mcmc (meanfield.py:1154-1286) for a few ensemble steps, the
+        # walkers one by one as the reference evaluates them (:1214-1260) and side by side (batch=True), under the small
+        # deterministic emcee stand-in of the tests (emcee is installed nowhere here) with flat priors around the start
+        walk = None
+        if a.latency_mcmc and N <= 512:
+            fake = os.path.join(ROOT, 'tests', 'fake_emcee')
+            if os.path.isdir(fake):
+                import scipy.stats as st
+                sys.path.insert(0, fake)
+                names = [k for k, fz in zip(g.parameters_dict.keys(), g.frozen_mask) if not fz]
+                pri = {k: st.uniform(min(0.8 * v, 1.2 * v) - 1e-3, abs(0.4 * v) + 2e-3) for k, v in zip(names, x0)}
+                walk = {'walkers': 2 * len(names), 'steps': a.latency_mcmc}
+                for label, flag in (('one_by_one', False), ('side_by_side', True)):
+                    gm = gpyrn.inference(q, t, *[x for pair in zip(ys, es) for x in pair])
+                    gm.set_components(*synth.build_components(covfunc, meanfunc, spec))
+                    np.random.seed(5)
+                    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                        gm.nELBO(x0)
+                        if flag:
+                            gm.nELBO_batch([x0 * (1 + 1e-3 * k) for k in range(len(names))])     # buffers
+                        cwd = os.getcwd()
+                        import tempfile
+                        with tempfile.TemporaryDirectory() as tmp:
+                            os.chdir(tmp)                        # (a real emcee would write gprn.h5 here)
+                            try:
+                                t0 = time.perf_counter()
+                                sampler = gm.mcmc(pri, niter=a.latency_mcmc, batch=flag)
+                                dtm = time.perf_counter() - t0
+                            finally:
+                                os.chdir(cwd)
+                    evals = walk['walkers'] * (2 + a.latency_mcmc)   # initial walkers (twice: mcmc's and the sampler's) + one per step
+                    walk[label] = {'s_total': dtm, 'ms_per_ensemble_step': 1e3 * dtm / (2 + a.latency_mcmc), 'evaluations': evals,
+                                   'all_finite': bool(np.all(np.isfinite(sampler.get_log_prob())))}
+                walk['speedup'] = walk['one_by_one']['s_total'] / walk['side_by_side']['s_total']
+                walk['note'] = 'inference.mcmc under tests/fake_emcee (Goodman-Weare stretch move on NumPy\'s generator), flat priors +-20 % around the start'
+                sys.path.remove(fake)
         cpu = None
         if not a.no_cpu:
             # the CPU walk starts at x0 too.  Twice: with ONE BLAS thread (at these sizes the threads of a
@@ -311,6 +347,7 @@ def latency(a):
             'reference_note': ('one_dataset.ipynb cell 20 prints 2.79 ms per nELBO for this problem shape on its author\'s '
                                'machine (jax on CPU)' if kind == 'notebook' else None),
             'side_by_side': side,
+            'mcmc': walk,
             'cpu_baseline': cpu}), flush=True)
 
 
@@ -479,6 +516,8 @@ def main():
     ap.add_argument('--latency-cpu-s', type=float, default=20.0, help='seconds of CPU baseline per shape')
     ap.add_argument('--latency-batch', type=int, default=0, help='evaluations per side-by-side call (default 256 up to two tiles, 32 above)')
     ap.add_argument('--no-side', action='store_true', help='skip the side-by-side leg of --latency')
+    ap.add_argument('--latency-mcmc', type=int, default=3,
+                    help='ensemble steps of the inference.mcmc leg of --latency (both ways, N <= 512; 0: skip)')
     ap.add_argument('--also-config', default=None,
                     help='C or C:N -- after the headline, BASELINE config C (at N, for rehearsals) sharded over the same ranks, '
                          'reported under configs_at_n_gpus; default: config 4 at --gpus 4, config 5 at --gpus 8 (their stated '
