@@ -370,7 +370,8 @@ static void free_problem(gprn_ctx* c)
     c->nslot = 0; c->out_cap = 0;
     c->factored = c->have_yres = c->have_jit = c->have_muvar = false;
     c->tables_ready = false;
-    c->small_tabs_ready = c->small_sweep_ready = false;
+    c->small_tabs_ready = c->small_sweep_ready = c->setup1_ready = false;
+    dev_free(c->tab_kinv1);
 }
 
 // ------------------------------------------------------------------ context
@@ -1044,6 +1045,7 @@ static int build_tables(gprn_ctx* c)
     c->tables_ready = true;
     c->small_tabs_ready = false;
     c->small_sweep_ready = false;
+    c->setup1_ready = false;
     return GPRN_OK;
 }
 
@@ -1123,6 +1125,7 @@ static int factor_priors_small(gprn_ctx* c, bool sync = true)
             }
         }
         TRY(upload_table(c, c->tab_setup, rows));
+        c->setup1_ready = false;                       // (the launch-path set-up's rows are gone)
         HIP_TRY(c, hipMemcpy(c->d_slotgp_setup, gps.data(), nj * sizeof(int), hipMemcpyHostToDevice));
         dev_free(c->d_kinv_out);
         TRY(dev_alloc(c, &c->d_kinv_out, (size_t)c->nslot));
@@ -1142,13 +1145,79 @@ static int factor_priors_small(gprn_ctx* c, bool sync = true)
     return first_info;
 }
 
+// The set-up of an UNSHARDED problem through the launch schedule: every latent GP is local, so the tables of the call never
+// change (uploaded once per problem: setup1_ready), all K_j^-1 of quirk Q1 are ONE X^T X launch over the nodes j >= 1, and the
+// host waits once, for the pivot verdicts.  (The general form below synchronises a dozen times per call -- table uploads,
+// one X^T X per node with its own table, the host's filter of log det K for the all-reduce: 0.25 of the 0.4-0.57 ms a set-up
+// took at N = 200 ... 512, where an evaluation of nELBO is 1.3-2.4 ms.)
+static int factor_priors_single(gprn_ctx* c)
+{
+    TRY(build_tables(c));
+    TRY(ensure_tasks(c));
+    c->small_tabs_ready = false;
+    c->small_sweep_ready = false;
+    c->info_gp = -1;
+    const size_t nn = (size_t)c->ld * c->ld;
+    std::vector<int> gps(c->loc_nodes);
+    gps.insert(gps.end(), c->loc_weights.begin(), c->loc_weights.end());
+    const int nb = (int)gps.size(), n_inv = c->q - 1;
+    for (int j = 1; j < c->q; ++j)
+        if (!c->Kinv[j]) { TRY(dev_alloc(c, &c->Kinv[j], nn)); c->setup1_ready = false; }
+    if (!c->setup1_ready) {
+        std::vector<double*> rows((size_t)c->nslot * GPRN_NBUF, nullptr);
+        for (int s = 0; s < nb; ++s) {
+            rows[s * GPRN_NBUF + BUF_B] = c->wsB[s];
+            rows[s * GPRN_NBUF + BUF_X] = c->KLinv[gps[s]];
+            rows[s * GPRN_NBUF + BUF_K] = c->K[gps[s]];
+            rows[s * GPRN_NBUF + BUF_KLINV] = c->KLinv[gps[s]];
+        }
+        TRY(upload_table(c, c->tab_setup, rows));
+        HIP_TRY(c, hipMemcpy(c->d_slotgp_setup, gps.data(), nb * sizeof(int), hipMemcpyHostToDevice));
+        if (n_inv > 0) {                                   // lower(K_j^-1) = lower(X^T X), X = chol(K_j)^-1: nodes 1 .. q - 1
+            dev_free(c->tab_kinv1);
+            TRY(dev_alloc(c, &c->tab_kinv1, (size_t)n_inv * GPRN_NBUF));
+            std::vector<double*> kr((size_t)n_inv * GPRN_NBUF, nullptr);
+            for (int j = 1; j < c->q; ++j) {
+                kr[(size_t)(j - 1) * GPRN_NBUF + BUF_B] = c->Kinv[j];
+                kr[(size_t)(j - 1) * GPRN_NBUF + BUF_X] = c->KLinv[j];
+            }
+            HIP_TRY(c, hipMemcpy(c->tab_kinv1, kr.data(), kr.size() * sizeof(double*), hipMemcpyHostToDevice));
+        }
+        c->setup1_ready = true;
+    }
+    for (int s = 0; s < nb; ++s) {
+        const int g = gps[s];
+        if (!c->kspec[g].uploaded) TRY(launch_fill(c, c->kspec[g], c->K[g]));
+        HIP_TRY(c, hipMemcpyAsync(c->wsB[s], c->K[g], nn * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
+    c->d_ptrs = c->tab_setup;
+    c->slot0 = 0;
+    c->d_info_cur = c->d_info;
+    TRY(factor_invert(c, nb));
+    TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
+    if (n_inv > 0) {
+        c->d_ptrs = c->tab_kinv1;
+        TRY(lauum_lower(c, n_inv));
+        c->d_ptrs = c->tab_setup;
+    }
+    int first_info = 0;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (the one wait of the call; the null stream's copy below does not
+    TRY(check_info(c, c->d_info, gps, &first_info));      // wait for the library's non-blocking streams by itself)
+    TRY(factor_check_waits(c));
+    c->factored = true;
+    return first_info;
+}
+
 static int factor_priors_impl(gprn_ctx* c)
 {
     if (small_applies(c) && c->world == 1) return factor_priors_small(c);
+    if (!comm_active(c) && c->world == 1) return factor_priors_single(c);
     TRY(build_tables(c));
     TRY(ensure_tasks(c));
     c->small_tabs_ready = false;               // (tab_setup gets this path's rows; Kinv[j] may be allocated below)
     c->small_sweep_ready = false;
+    c->setup1_ready = false;
     c->info_gp = -1;
     const size_t nn = (size_t)c->ld * c->ld;
     HIP_TRY(c, hipMemsetAsync(c->d_logdetK, 0, c->G * sizeof(double), c->stream));
@@ -1197,7 +1266,8 @@ static int factor_priors_impl(gprn_ctx* c)
         TRY(factor_invert(c, nb));
         // log det K: non-owned helper entries are dropped below, before the all-reduce
         TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
-        TRY(check_info(c, c->d_info, gps, &first_info));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the verdicts are read through the null stream, which does not wait
+        TRY(check_info(c, c->d_info, gps, &first_info));  // for the library's non-blocking streams by itself)
         // K_j^-1 = X^T X for the nodes that need it (one at a time: output goes to Kinv[j])
         for (int s = 0; s < nb; ++s) {
             const int g = gps[s];
@@ -1708,13 +1778,24 @@ extern "C" int gprn_elbocalc(gprn_ctx* c, int do_setup, const double* y_resid, c
         // first trip then repeats that very call (same state in, :636) -- elboArray[1] == elboArray[0] by construction.
         // The sweep is deterministic (no atomics in any reduction), so it runs ONCE, committed, and its ELBO is entered
         // twice; only max_iter = 0 needs the uncommitted form.
+        // The stop rule cannot fire before trip 4 (:640), so trips 1 .. min(4, max_iter) go out as ONE call of sweep_impl: one
+        // host synchronisation instead of four, and each sweep's ELBO assembly runs beside the next sweep's node phase
+        // (overlap bit 16: same bits).  A warm-started evaluation -- nELBO's case -- usually stops right there.
         const int first_commit = max_iter >= 1 ? 1 : 0;
-        rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, first_commit, &e, nullptr, retry); }, true);
+        const int nfirst = std::max(1, std::min(max_iter, 4));
+        double efirst[4] = {0.0, 0.0, 0.0, 0.0};
+        rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, nfirst, first_commit, efirst, nullptr, retry); }, true);
         if (rc < 0) return rc;
         if (!info) info = rc;
+        e = efirst[0];
         hist.push_back(e);
-        if (first_commit) { hist.push_back(e); iter = 1; }
-        while (iter < max_iter) {
+        if (first_commit) {
+            for (int k = 0; k < nfirst; ++k) hist.push_back(efirst[k]);
+            iter = nfirst;
+            const size_t n = hist.size();
+            if (iter > 3 && elbo_stop_rule(hist[n - 3], hist[n - 2], hist[n - 1])) conv = 1;
+        }
+        while (!conv && iter < max_iter) {
             rc = with_event_fallback(c, "sweep", [&](bool retry) { return sweep_impl(c, 1, 1, &e, nullptr, retry); }, true);
             if (rc < 0) return rc;
             if (!info) info = rc;

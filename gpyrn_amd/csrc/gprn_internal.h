@@ -247,6 +247,8 @@ struct gprn_ctx {
     size_t pin_in_cap = 0, pin_out_cap = 0;
     bool small_tabs_ready = false;   // the set-up's tables for this problem are on the device (factor_priors_small)
     bool small_sweep_ready = false;  // ... and what a sweep of the small path reads beside the phase tables (ensure_small_sweep_tabs)
+    bool setup1_ready = false;       // tab_setup / d_slotgp_setup / tab_kinv1 hold the unsharded launch-path set-up's rows (factor_priors_single)
+    double** tab_kinv1 = nullptr;    // [q - 1][GPRN_NBUF]: BUF_B = K_j^-1, BUF_X = chol(K_j)^-1, nodes j >= 1 (one X^T X launch)
     // ---- many evaluations side by side above one tile (midn.hip): a worker context holds the matrices and states of a
     // chunk of evaluations; its kernels find an evaluation's arrays through `ev`
     EvalMap ev = {nullptr, 0, 0, 0, 0};

@@ -605,6 +605,33 @@ def test_small_path_reports_a_failed_pivot():
     assert g.last_info == 41 and not np.isfinite(E)
 
 
+@pytest.mark.parametrize('n', [200, 300])
+def test_launch_path_reports_a_failed_pivot_of_the_set_up(n):
+    """The same semantics above one tile (the launch schedule's set-up, unsharded: factor_priors_single): a prior matrix
+    that is not positive definite gives info > 0 -- the order of the failing minor -- and NaN downstream, no exception; and
+    the object recovers with a proper kernel afterwards."""
+    t, ys, es = synth.rv_series(n, 1)
+
+    class Indefinite(covfunc.covFunction):
+        _param_names = ('theta',)
+        _tag = 'bad'
+
+        def __call__(self, r):
+            k = self.pars[0] ** 2 * np.exp(-0.5 * r ** 2 / 30.0 ** 2)
+            if k.ndim == 2 and k.shape[0] == k.shape[1]:
+                k = k.copy()
+                k[150, 150] = -1.0
+            return k
+
+    g = gpyrn.inference(1, t, ys[0], es[0])
+    g.set_components(Indefinite(1.0), covfunc.SquaredExponential(1.0, 60.0), meanfunc.Constant(0.0), 0.5)
+    E, mu, var, it = g.ELBOcalc(max_iter=5)
+    assert g.last_info == 151 and not np.isfinite(E)
+    g.set_components(covfunc.SquaredExponential(1.0, 30.0), covfunc.SquaredExponential(1.0, 60.0), meanfunc.Constant(0.0), 0.5)
+    E2 = g.ELBOcalc()[0]
+    assert g.last_info == 0 and np.isfinite(E2)
+
+
 def test_elboaux_shim_returns_sigma():
     meta, d, g = _model('step_p3q2')
     j2 = np.array(meta['jitters'])**2
