@@ -39,7 +39,7 @@ template <bool ARGS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
-                  unsigned* wait_timed_out)
+                  unsigned* wait_timed_out, int nph)
 {
     __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
@@ -49,7 +49,9 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
     const size_t off = ((size_t)kblk * GPRN_TILE) * ld + (size_t)kblk * GPRN_TILE;
     double* const Bm = ARGS ? pa.p[slot][0] : ptrs[(size_t)slot * GPRN_NBUF + BUF_B];
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
-    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE);
+    // (nph: the 16-column phases of this tile that hold data -- the last tile of a matrix whose size is not a multiple of 128
+    // ends in identity padding, whose factor diag_tile writes without running the phases)
+    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE, nph);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
 }
@@ -114,12 +116,16 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     if (nbatch * c->T <= GPRN_LAT_MAX)
         dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
     pa.stamps = step_stamp_ptr(c, kblk, 0);
+    // rows of data in this tile: all 128 but in the last tile of a ragged matrix (ld is the context's: the diagnostic entry
+    // points factor whole tiles)
+    const int rows_here = ld == c->ld ? std::min(GPRN_TILE, c->N - kblk * GPRN_TILE) : GPRN_TILE;
+    const int nph = std::max(1, (rows_here + 15) / 16);
     if (tab_rows(c, d_ptrs, nbatch, &pa))
         hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
-                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out, nph);
     else
         hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
-                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out);
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out, nph);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
