@@ -283,6 +283,7 @@ static int mid_prior_term(gprn_ctx* w, MidBatch* m, bool weights, int nA)
 // One sweep (meanfield.py:651-710) of the evaluations in the active tables; out4 of each lands at d_out + 4 * evaluation.
 static int mid_sweep(gprn_ctx* w, MidBatch* m, int nA)
 {
+    w->chain_started = nullptr;                          // (nothing left over from a sweep that broke off)
     HIP_TRY(w, hipMemsetAsync(w->d_info + (size_t)w->nslot, 0, 2 * (size_t)w->nslot * sizeof(int), w->stream));
     MB_TRY(mid_phase(w, m, false, nA));
     if (m->q > 1) {
