@@ -298,6 +298,7 @@ static inline void watch_progress(gprn_ctx* c)
 //   "batch_mem_mb"   device memory (MiB) one chunk of gprn_elbocalc_batch's evaluations may take; longer lists run chunk by chunk
 //   "comm_budget_s"  seconds an entry point may stay inside its collective section before the watchdog ends the process
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
+//   "batch_chunk"    read-only: evaluations per chunk in the last gprn_elbocalc_batch call
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
 {
     DeviceLock lock_(c);
@@ -313,6 +314,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "batch_mem_mb")) field = &c->batch_mem_mb;
     else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
+    else if (!strcmp(name, "batch_chunk")) { if (old) *old = c->last_batch_chunk; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
     const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt;
@@ -1844,6 +1846,7 @@ extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel
     const bool small = c->T == 1 && small_applies(c);
     const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;
     const int chunk = small ? small_batch_chunk(c) : n_eval;       // (midn.hip sizes its own chunks: it knows what a matrix costs)
+    if (small) c->last_batch_chunk = std::min(chunk, n_eval);
     for (int e0 = 0; e0 < n_eval; e0 += chunk) {
         const int ne = std::min(chunk, n_eval - e0);
         const double* kp = kernel_params + (size_t)e0 * n_kernel_params;

@@ -254,6 +254,7 @@ struct gprn_ctx {
     EvalMap ev = {nullptr, 0, 0, 0, 0};
     void* mid_batch = nullptr;       // MidBatch (midn.hip): the worker context and its slabs, owned by the PARENT context
     int batch_mem_mb = -1;           // gprn_set_option "batch_mem_mb": device memory one chunk of evaluations may take; -1: a share of what is free
+    int last_batch_chunk = 0;        // read-only option "batch_chunk": evaluations per chunk in the last gprn_elbocalc_batch call
 };
 
 struct DeviceLock {                                // no-op for a null context (the entry point rejects it next)

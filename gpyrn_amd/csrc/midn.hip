@@ -119,6 +119,7 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
     }
     gprn_ctx* w = m->w;
     const int cap = want;
+    *cap_out = cap;                                       // (what was tried, for a caller that halves after GPRN_E_NOMEM)
     const size_t nn = (size_t)ld * ld, d = (size_t)(p + 1) * q * N, pn = (size_t)p * N, nscal = 3 * (size_t)G + (size_t)q * q;
     const size_t nslot = (size_t)cap * G;
     {
@@ -470,8 +471,12 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
         kp_total += c->kspec[g].n_params;
     }
     if (kp_total != n_kpar) { c->err = "elbocalc_batch: kernel_params has the wrong length per evaluation"; return GPRN_E_ARG; }
-    int cap = 0;
-    MB_TRY(mid_ensure(c, n_eval, &cap));
+    // (the budget is an estimate: when the device has less in one piece than it reports free, smaller chunks)
+    int cap = 0, want = n_eval, rc_mem;
+    while ((rc_mem = mid_ensure(c, want, &cap)) == GPRN_E_NOMEM && cap > 1) want = cap / 2;
+    if (rc_mem) return rc_mem;
+    c->err.clear();
+    c->last_batch_chunk = std::min(cap, n_eval);
     MidBatch* m = (MidBatch*)c->mid_batch;
     gprn_ctx* w = m->w;
     // the worker follows the parent's switches

@@ -271,7 +271,8 @@ int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, 
  * one tile -- N <= 128 -- run each half-sweep as ONE launch, one workgroup per latent GP, csrc/smalln.hip; 2: problems
  * of two tiles too; 0: the launch schedule at every size; same results to rounding); "batch_mem_mb" (device memory, MiB, that
  * one chunk of gprn_elbocalc_batch's evaluations may take: longer lists run chunk by chunk; default: half of what is free, 48 GiB
- * at most); "comm_budget_s" (sharded contexts: seconds an entry point may stay inside its collective section -- a rank that
+ * at most; when the device cannot give that much in one piece the chunk is halved until it can); "batch_chunk" (read-only:
+ * evaluations per chunk in the last gprn_elbocalc_batch call); "comm_budget_s" (sharded contexts: seconds an entry point may stay inside its collective section -- a rank that
  * died leaves the others there -- before the library's watchdog names the entry point, the collective and the rank on
  * stderr and ends the process with status 86; default 600, or GPRN_COMM_BUDGET_S).  value == -1 only reads; *old (may be
  * NULL) receives the previous value. */

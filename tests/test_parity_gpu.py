@@ -439,6 +439,45 @@ def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb, ca
     _assert_default_schedule(gs._backend())
 
 
+def test_a_batch_the_device_cannot_hold_in_one_piece_runs_in_smaller_chunks(capsys):
+    """The memory budget of a chunk is an estimate (option "batch_mem_mb", or half of what hipMemGetInfo reports free).  When
+    the device cannot give that much -- here: a budget of 600 GB on a 288 GB device, 96 evaluations of BASELINE config 3
+    (N = 4096, 8 latent GPs: 4.4 GB each) -- the slabs' allocation fails part-way; the call must halve the chunk until it
+    fits, not fail: values against the same evaluations one by one, and the chunk the call ended up with."""
+    N, p, q, kind = synth.CONFIGS[3]
+    t, ys, es = synth.rv_series(N, p)
+    spec = synth.component_spec(p, q, kind)
+
+    def fresh():
+        nodes, weights, means, jit = synth.build_components(covfunc, meanfunc, spec)
+        g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+        g.set_components(nodes, weights, means, jit)
+        return g
+
+    g = fresh()
+    ctx = g._backend()
+    ctx.option('batch_mem_mb', 600_000)
+    g.batch_max_N = N                                          # (nELBO_batch's own size limit is below this problem)
+    B = 96
+    x0 = np.array(g.get_parameters(), dtype=float)
+    rng = np.random.RandomState(5)
+    sets = [x0 * (1.0 + 0.02 * rng.standard_normal(x0.size)) for _ in range(B)]
+    capsys.readouterr()
+    got = np.array(g.nELBO_batch(sets, max_iter=2))
+    assert 'evaluations side by side' in capsys.readouterr().out
+    assert g.last_info == 0 and np.all(np.isfinite(got))
+    chunk = ctx.option('batch_chunk')
+    assert 1 <= chunk < B, 'the whole list in one chunk: %d evaluations of 4.4 GB on one device?' % chunk
+    gs = fresh()
+    for b in (0, chunk - 1, chunk, B - 1):                     # (either side of a chunk boundary)
+        gs.set_parameters(sets[b])
+        e = gs.ELBOcalc(max_iter=2)[0]
+        np.testing.assert_allclose(got[b], -e, rtol=1e-9)
+    ctx.option('batch_mem_mb', 64)                             # (the slabs go back before the next test allocates)
+    g.nELBO_batch(sets[:2], max_iter=0)
+    _assert_default_schedule(ctx)
+
+
 @pytest.mark.parametrize('n', [77, 497])
 def test_nelbo_batch_with_composite_kernels_ragged_sizes_and_a_capped_loop(n, capsys):
     """The side-by-side forms (one tile / above) on what the other batch tests leave out: kernel EXPRESSIONS (a Sum and a
