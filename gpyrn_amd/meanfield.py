@@ -758,6 +758,7 @@ class inference:
     #: largest N for which nELBO_batch / mcmc(batch=True) evaluate side by side on one GPU (beyond it a single evaluation
     #: already fills the device, and a chunk of evaluations would be a few matrices)
     batch_max_N = 2048
+    _batch_last_done = -1            # position (in the last side-by-side list) of the evaluation whose state was kept
 
     def nELBO_batch(self, parameter_sets, max_iter=None, pool=None, batch=True):
         """
@@ -766,7 +767,9 @@ class inference:
         this same problem on its own GPU) the vectors are split over the ranks and
         every rank returns the full list.  Not in the reference, which evaluates
         optimiser populations and emcee walkers one by one (meanfield.py:1222-1260).
-        The parameters of ``self`` end up at the last vector this rank evaluated.
+        The parameters of ``self`` end up at the last vector this rank evaluated.  With a pool AND the side-by-side form
+        below, each rank evaluates its share side by side and the state every rank keeps is the same (that of the last
+        evaluation of the whole list that converged): the values do not depend on the number of ranks.
 
         Without a pool, a problem whose kernels all have device programs evaluates the whole list SIDE BY SIDE on the GPU
         (``gprn_elbocalc_batch``): every evaluation with its own covariance matrices, state, loop and stop rule, all of
@@ -782,8 +785,49 @@ class inference:
             out = self._nELBO_batch_device(sets, max_iter)
             if out is not None:
                 return out
+        if pool is not None and batch and sets and hasattr(pool, 'map_lists') and self._batchable():
+            return self._nELBO_batch_pool(sets, max_iter, pool)
         f = lambda x: float(self.nELBO(x, max_iter=max_iter))
         return list(map(f, sets)) if pool is None else pool.map(f, sets)
+
+    def _batchable(self):
+        """Whether ``_nELBO_batch_device`` applies to this object at its current components -- a property of the problem,
+        the same on every rank of a pool (so that all of them take the same branch, collectives included)."""
+        if self._comm is not None or self.N > self.batch_max_N:
+            return False
+        nodes, weights, _, _ = self._get_components()
+        return all(self._kernel_spec(k)[0] == 'device' for k in chain(nodes, weights))
+
+    def _nELBO_batch_pool(self, sets, max_iter, pool):
+        """``nELBO_batch`` over the GPUs of a node: rank r evaluates ``sets[r::world]`` SIDE BY SIDE on its own GPU, all
+        of them from the state the object holds on entry -- the same on every rank, because the state it holds on exit
+        is again the same on every rank: that of the last evaluation OF THE WHOLE LIST whose loop converged
+        (``nELBO_batch``'s rule), handed round by its owner.  The values therefore do not depend on the number of
+        ranks (to the rounding of a batch's size-dependent launch shapes)."""
+        n = len(sets)
+        mine = list(range(pool.rank, n, pool.world))
+        last = {'key': -1}
+
+        def share(xs):
+            out = self._nELBO_batch_device(xs, max_iter)
+            if out is None:                                    # (vectors that change a kernel expression's shape)
+                out = [float(self.nELBO(x, max_iter=max_iter)) for x in xs]
+                last['key'] = mine[-1]
+            elif self._batch_last_done >= 0:
+                last['key'] = mine[self._batch_last_done]
+            return out
+
+        mu0, var0 = self._mu, self._var
+        vals = pool.map_lists(share, sets)
+        shape = (self.p + 1, self.q, self.N)
+        offer = [self._mu, self._var] if last['key'] >= 0 else [np.zeros(shape), np.zeros(shape)]
+        got = pool.take_from_highest(last['key'], offer)
+        if got is not None:
+            self._mu, self._var = got
+        else:
+            self._mu, self._var = mu0, var0
+        self.set_parameters(sets[-1])
+        return vals
 
     def _nELBO_batch_device(self, sets, max_iter):
         """``nELBO_batch`` through ``gprn_elbocalc_batch``, or None where that does not apply (larger problems, sharded
@@ -859,6 +903,7 @@ class inference:
         elbo, iters, conv, info, mu_f, var_f = res
         self.last_info = int(info[np.flatnonzero(info)[0]]) if np.any(info) else 0
         done = np.flatnonzero(conv)
+        self._batch_last_done = int(done[-1]) if done.size else -1
         if done.size:                                      # the warm start of whatever comes next (meanfield.py:644-646)
             self._mu, self._var = mu_f[done[-1]], var_f[done[-1]]
         took = 1e3 * (time_module.time() - start)
@@ -1088,12 +1133,16 @@ class inference:
             out = np.full((X.shape[0], 2), -np.inf)
             ok = np.flatnonzero(~np.isneginf(lp))
             if ok.size:
-                elbo = -np.array(self.nELBO_batch([X[i] for i in ok], max_iter=100))
+                elbo = -np.array(self.nELBO_batch([X[i] for i in ok], max_iter=100, pool=batch_pool))
                 out[ok, 0] = lp[ok] + elbo
                 out[ok, 1] = elbo
             return out
 
         batch = bool(kwargs.pop('batch', False))
+        # (a vectorised log-probability never reaches emcee's pool: with both, each rank of the pool evaluates its share
+        # of a half-step's walkers side by side -- nELBO_batch(pool=...))
+        pool_rank = getattr(kwargs.get('pool'), 'rank', 0)
+        batch_pool = kwargs.pop('pool', None) if batch else None
 
         ndim = len(names)
         nwalkers = 2 * ndim
@@ -1122,7 +1171,6 @@ class inference:
         # the reference's HDF5 file (meanfield.py:1262-1263) -- written by ONE process: with an SPMD pool
         # (sharding.EvalPool) every rank runs this same method, and N writers resetting one file end in an
         # h5py lock error or a corrupt file; the other ranks keep emcee's in-memory backend
-        pool_rank = getattr(kwargs.get('pool'), 'rank', 0)
         if 'backend' not in kwargs and pool_rank == 0:
             try:
                 be = backends.HDFBackend('gprn.h5')

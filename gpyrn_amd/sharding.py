@@ -196,5 +196,36 @@ class EvalPool:
             return [float(buf[i, 0]) for i in range(n)]
         return [tuple(float(x) for x in buf[i]) for i in range(n)]
 
+    def map_lists(self, func, items):
+        """``map`` for a ``func`` that takes this rank's whole share as ONE list and returns one float per item
+        (``inference.nELBO_batch``: the share is evaluated side by side on this rank's GPU).  Every rank returns the
+        full list, in order."""
+        items = list(items)
+        n = len(items)
+        mine = list(range(self.rank, n, self.world))
+        vals = [float(v) for v in func([items[i] for i in mine])] if mine else []
+        if len(vals) != len(mine):
+            raise ValueError('map_lists: %d results for %d items' % (len(vals), len(mine)))
+        if self.world == 1:
+            return vals
+        import numpy as np
+        buf = np.zeros(n)
+        buf[mine] = vals
+        return [float(v) for v in self._ctx.allreduce_sum(buf)]
+
+    def take_from_highest(self, key, arrays):
+        """Every rank offers ``arrays`` (same shapes on every rank) under a priority ``key`` (distinct over the ranks
+        that offer; < 0: nothing to offer, the arrays' CONTENT is then ignored).  All ranks return the arrays of the
+        rank with the highest key, or None when no rank offers: two collectives, whatever the outcome."""
+        import numpy as np
+        top = self._ctx.barrier_max(float(key)) if self.world > 1 else float(key)
+        out = []
+        for a in arrays:
+            a = np.asarray(a, dtype=float)
+            buf = a.ravel() if (key >= 0 and float(key) == top) else np.zeros(a.size)
+            got = self._ctx.allreduce_sum(buf) if self.world > 1 else np.array(buf)
+            out.append(got.reshape(a.shape))
+        return out if top >= 0 else None
+
     def close(self):
         self.comm.cleanup()

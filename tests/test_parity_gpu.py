@@ -1031,11 +1031,22 @@ def test_schedule_and_kernel_variants_agree(env, tag, tmp_path):
 def test_eval_pool_splits_independent_evaluations(tmp_path):
     """sharding.EvalPool: three ranks, each with the whole problem on the (shared)
     GPU, split five nELBO evaluations; every rank gets all five values, bit-identical to
-    evaluating them one by one."""
+    evaluating them one by one.  nELBO_batch(pool=...) and mcmc(batch=True, pool=...): each rank's share side by
+    side, the warm-start state handed round so that every rank holds the same one -- values, state and chain as on
+    one GPU without a pool."""
     for res in _run_ranks('tests._pool_worker', 'step_p3q2', 3, tmp_path):
         assert int(res['world']) == 3
         assert np.array_equal(res['pooled'], res['serial'])
-        np.testing.assert_allclose(res['batch'], res['serial'], rtol=1e-2)   # warm starts differ
+        np.testing.assert_allclose(res['one_by_one'], res['serial'], rtol=1e-2)   # (chained: warm starts differ)
+        # each rank's share side by side, the state handed round: independent of the number of ranks
+        np.testing.assert_allclose(res['batch'], res['serial'], rtol=1e-9)
+        np.testing.assert_allclose(res['batch'], res['alone'], rtol=1e-12)
+        np.testing.assert_allclose(res['batch_warm'], res['alone_warm'], rtol=1e-12)
+        np.testing.assert_allclose(res['mu_pool'], res['mu_alone'], rtol=1e-12, atol=1e-300)
+        # mcmc(batch=True, pool=...): the same chain as on one GPU
+        np.testing.assert_allclose(res['chain_pool'], res['chain_alone'], rtol=1e-12)
+        np.testing.assert_allclose(res['lp_pool'], res['lp_alone'], rtol=1e-9)
+        assert np.all(np.isfinite(res['lp_pool'])) and res['chain_pool'].shape[0] == 2
         odd = res['odd']
         assert odd.shape == (7, 2) and np.array_equal(odd[:, 0], np.arange(7.0))
         assert np.isneginf(odd[1, 1]) and np.isnan(odd[2, 1]) and odd[6, 1] == 3.0

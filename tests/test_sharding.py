@@ -176,8 +176,10 @@ def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
         def comm_init(self, world, rank, uid):
             pass
 
+        max = None
+
         def barrier_max(self, v=0.0):
-            return float(v)
+            return float(v) if FakeCtx.max is None else FakeCtx.max
 
         def allreduce_sum(self, buf):
             self.sent = np.array(buf, dtype=float)
@@ -205,6 +207,36 @@ def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
         assert np.isneginf(out[1][1]) and np.isnan(out[2][1]) and out[4][1] == 2.0
     one = sharding.EvalPool(NoRendezvous(world=1, rank=0, local_rank=0))
     assert one.map(lambda x: x * 2.0, [1.0, 2.0]) == [2.0, 4.0]
+    # map_lists: a rank's whole share goes to func as ONE list (nELBO_batch: side by side on that rank's GPU)
+    FakeCtx.total = None
+    shares = [[], []]
+    for r, pool in enumerate(pools):
+        pool.map_lists(lambda xs, r=r: (shares[r].extend(xs), [10.0 * x for x in xs])[1], range(5))
+    assert shares == [[0, 2, 4], [1, 3]]
+    FakeCtx.total = pools[0]._ctx.sent + pools[1]._ctx.sent
+    for pool in pools:
+        assert pool.map_lists(lambda xs: [10.0 * x for x in xs], range(5)) == [0.0, 10.0, 20.0, 30.0, 40.0]
+    assert one.map_lists(lambda xs: [x + 1.0 for x in xs], [1.0, 2.0]) == [2.0, 3.0]
+    with pytest.raises(ValueError):
+        one.map_lists(lambda xs: [0.0], [1.0, 2.0])
+    # (a rank without a share does not call func at all)
+    FakeCtx.total = np.zeros(1)
+    assert pools[1].map_lists(lambda xs: [7.0], [3.0]) == [0.0]
+    # take_from_highest: the arrays of the rank with the largest key; every rank contributes zeros otherwise
+    a0, a1 = np.full((2, 3), 1.5), np.full((2, 3), 2.5)
+    FakeCtx.total = None
+    FakeCtx.max = 4.0
+    pools[0].take_from_highest(2, [a0]); sent0 = pools[0]._ctx.sent
+    pools[1].take_from_highest(4, [a1]); sent1 = pools[1]._ctx.sent
+    assert not sent0.any() and np.array_equal(sent1, a1.ravel())
+    FakeCtx.total = sent0 + sent1
+    for pool, key, arr in ((pools[0], 2, a0), (pools[1], 4, a1)):
+        got = pool.take_from_highest(key, [arr])
+        assert got[0].shape == (2, 3) and np.array_equal(got[0], a1)
+    FakeCtx.max = -1.0
+    assert pools[0].take_from_highest(-1, [a0]) is None
+    FakeCtx.max = None
+    assert np.array_equal(one.take_from_highest(0, [a0])[0], a0) and one.take_from_highest(-1, [a0]) is None
 
 
 # ---------------------------------------------------------------- bench.py --gpus N without a launcher
