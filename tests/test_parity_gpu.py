@@ -79,6 +79,38 @@ def test_user_kernel_takes_host_path():
     np.testing.assert_allclose(e_user, e_builtin, rtol=1e-10)
 
 
+@pytest.mark.parametrize('tag', ['mid_N300_p3q2', 'cfg1_N200'])
+def test_user_kernels_above_one_tile_mix_with_device_kernels(tag):
+    """User-defined covFunction subclasses (host-evaluated, gprn_upload_K) on the LAUNCH path (N > 128), mixed with device
+    programs in one problem: the second node (the one whose K_j^-1 quirk Q1 needs when q = 2) and every other weight are
+    user kernels that evaluate the fixture's own formula on the host.  The whole ELBOcalc -- the unsharded set-up
+    (factor_priors_single: one factorisation over uploaded and filled matrices alike), trip count, value, state -- must
+    reproduce the all-device run, which reproduces the reference."""
+    if not _cases.available(tag):
+        pytest.skip('fixture not generated')
+
+    class Hosted(covfunc.covFunction):
+        def __init__(self, inner):
+            super().__init__(*inner.pars)
+            self.inner = inner
+
+        def __call__(self, r):
+            return self.inner(r)
+
+    meta, d, g = _model(tag)
+    e_dev, mu_dev, var_dev, it_dev = g.ELBOcalc()
+    nodes = [Hosted(k) if j == len(g.nodes) - 1 else k for j, k in enumerate(g.nodes)]
+    weights = [Hosted(k) if i % 2 == 0 else k for i, k in enumerate(g.weights)]
+    assert nodes[-1]._device_program() is None
+    g2 = _model(tag)[2]
+    g2.set_components(nodes, weights, g2.means, g2.jitters)
+    e_usr, mu_usr, var_usr, it_usr = g2.ELBOcalc()
+    assert it_usr == it_dev and g2.last_info == 0
+    np.testing.assert_allclose(e_usr, e_dev, rtol=1e-10)
+    _cases.assert_state('user kernels ' + tag, mu_usr, mu_dev, var_usr, var_dev)
+    _assert_default_schedule(g2._backend())
+
+
 # ------------------------------------------------------------------- one sweep
 def _assert_default_schedule(ctx):
     """No call of this context was re-run on HIP events after an in-kernel wait timed out, and it is still on the
