@@ -239,6 +239,90 @@ def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
     assert np.array_equal(one.take_from_highest(0, [a0])[0], a0) and one.take_from_highest(-1, [a0]) is None
 
 
+def test_pooled_side_by_side_evaluations_keep_one_state_on_every_rank():
+    """inference._nELBO_batch_pool without a GPU: three 'ranks' (threads, each with its own inference object and an
+    EvalPool over an in-memory all-reduce) split seven vectors; the device call is replaced by a recorder that returns
+    sum(x) and 'converges' on chosen vectors.  Every rank must return the full list in order, and every rank must end
+    with the state of the LAST vector of the WHOLE list that converged -- whoever evaluated it -- or keep its state
+    when none did."""
+    import threading
+    import gpyrn_amd as gpyrn
+    world = 3
+
+    class Wire:
+        def __init__(self):
+            self.bar = threading.Barrier(world)
+            self.slots = [None] * world
+
+        def reduce(self, rank, buf, op):
+            self.slots[rank] = np.array(buf, dtype=float)
+            self.bar.wait()
+            out = op(np.stack(self.slots), axis=0)
+            self.bar.wait()
+            return out
+
+    class Ctx:
+        def __init__(self, wire, rank):
+            self.wire, self.rank = wire, rank
+
+        def barrier_max(self, v=0.0):
+            return float(self.wire.reduce(self.rank, [v], np.max)[0])
+
+        def allreduce_sum(self, buf):
+            return self.wire.reduce(self.rank, np.ravel(buf), np.sum)
+
+    def pool_for(wire, rank):
+        pool = sharding.EvalPool.__new__(sharding.EvalPool)
+        pool.world, pool.rank, pool._ctx = world, rank, Ctx(wire, rank)
+        return pool
+
+    t = np.linspace(0.0, 10.0, 12)
+    sets = [np.array([1.0 + 0.1 * k, 2.0, 0.5, 3.0, 0.0, 0.1]) for k in range(7)]
+
+    def run(converging):
+        wire, out = Wire(), [None] * world
+
+        def rank_main(r):
+            g = gpyrn.inference(1, t, np.sin(t), 0.1 * np.ones(t.size))
+            g.set_components(covfunc.SquaredExponential(1.0, 2.0), covfunc.SquaredExponential(0.5, 3.0),
+                             meanfunc.Constant(0.0), 0.1)
+            g._mu = np.full((2, 1, t.size), -1.0)
+            g._var = np.full((2, 1, t.size), -2.0)
+            seen = []
+
+            def fake_device(xs, max_iter):                     # what _nELBO_batch_device does to the object
+                seen.extend(float(x[0]) for x in xs)
+                done = [i for i, x in enumerate(xs) if round((x[0] - 1.0) * 10) in converging]
+                g._batch_last_done = done[-1] if done else -1
+                if done:
+                    g._mu = np.full((2, 1, t.size), xs[done[-1]][0])
+                    g._var = np.full((2, 1, t.size), 10.0 * xs[done[-1]][0])
+                return [float(np.sum(x)) for x in xs]
+
+            g._nELBO_batch_device = fake_device
+            g._batchable = lambda: True
+            vals = g.nELBO_batch(sets, pool=pool_for(wire, r))
+            out[r] = (vals, g._mu.copy(), g._var.copy(), seen, np.array(g.get_parameters()))
+
+        threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(60)
+        assert all(o is not None for o in out), 'a rank did not finish'
+        return out
+
+    out = run({0, 2, 4})                                       # the last converged one, vector 4, is rank 1's
+    for r, (vals, mu, var, seen, pars) in enumerate(out):
+        np.testing.assert_allclose(vals, [float(np.sum(x)) for x in sets], rtol=1e-15)
+        assert seen == [sets[i][0] for i in range(r, 7, world)]
+        assert np.all(mu == sets[4][0]) and np.all(var == 10.0 * sets[4][0])
+        np.testing.assert_array_equal(pars, sets[-1])
+    out = run(set())                                           # nothing converged: every rank keeps the state it had
+    for vals, mu, var, seen, pars in out:
+        assert np.all(mu == -1.0) and np.all(var == -2.0)
+
+
 # ---------------------------------------------------------------- bench.py --gpus N without a launcher
 def _bench(args, extra_env):
     import subprocess
