@@ -470,6 +470,13 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     // at N = 4096 and 8192; at N = 16384, where a "rest" launch runs for 11 ms, -0.7 %: up to 64 tile steps
     const bool sr = c->stream4 && c->T <= 64;
     hipStream_t sn = sr ? c->stream4 : s2;
+    // The chain's two products per tile step, L_{k+1,k} and the update of B_{k+1,k+1}, have kernels of their own that cut
+    // a 128 x 128 tile into 16 x 16 pieces (k_chain_l / k_chain_u: 3-5 us for one matrix, where the tile kernel needs 12).
+    // With MANY matrices in lock-step -- a batch of evaluations (midn.hip): 192 weight matrices of 32 evaluations -- those
+    // are throughput work, and kernels built for latency do it at 6-10 TF: 77 + 62 us of a 215 us tile step at N = 512.
+    // (as tile tasks 49 + 31-72 us; N = 512, 32 evaluations 3 960 -> 4 090 /s, N = 497 5 930 -> 6 070; the diagonal blocks of
+    // the next step, 4-5 x slower beside the step's updates than alone, are what such a step waits for now)
+    const bool wide_chain = nbatch >= GPRN_WIDE_CHAIN;
 
     // stream3 at the start of step k: raise F_INNER of the step before, then wait for diag(k)
     auto side_sync = [&](int k) -> int {
@@ -635,6 +642,16 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             const bool spin = use_flags && k > 0 && nbatch <= 2;
             if (use_flags && k > 0 && !spin && (rc = flag_sync(s0, nullptr, slot(k - 1, F_INNER) + 1))) return rc;
             if (k > 0 && !use_flags) HIP_TRY(c, await(s0, k - 1, F_INNER));
+            if (wide_chain) {
+                // the same two products as tasks of the tile kernel: the step's first panel task and first update task
+                // (ensure_tasks), a few hundred 64-row workgroups at its K = 128 rate
+                if ((rc = tiles(s.panel0, 1, s0, TS_64x128_BTRI, GPRN_T_PANEL, nosig, noaw, TG_PANEL))) return rc;
+                if (use_flags) { c->start_flag_now = slot(k, F_MINIL) + 1; c->start_value_now = epoch; }
+                else HIP_TRY(c, raise(s0, k, F_MINIL));
+                rc = tiles(s.upd0, 1, s0, TS_64x64, GPRN_T_PANEL, nosig, noaw, TG_INNER);
+                c->start_flag_now = nullptr;
+                if (rc) return rc;
+            } else {
             if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, s0, nosig,
                                        spin ? in_kernel_wait(k - 1, F_INNER) : noaw))) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
@@ -642,6 +659,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // instead of at the end of its own -- 1.7 us less between the two at every tile step)
             if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 1, GPRN_T_PANEL, s0, nosig, noaw,
                                        use_flags ? slot(k, F_MINIL) + 1 : (unsigned*)nullptr, epoch))) return rc;
+            }
             // The outer update of the previous panel is ENQUEUED here, behind the chain's three launches of this panel's
             // first step: its dozen stream operations and launches take the host 60-100 us, during which the chain stream
             // ran dry at every panel boundary (profiles/r02_chain_timeline_cfg3.txt)

@@ -18,6 +18,9 @@
 #define GPRN_OUTER_SMALL 16    // ... when batch x tiles <= 32 (latency-bound: measured +11 % at N=2048, batch 1)
 #define GPRN_LAT_MAX 32        // batch x tiles up to which a factorisation runs on the latency set of task lists
 #define GPRN_FEW_TASKS 4000    // tasks x batch above which a tile launch uses 128 x 128 workgroups (100 ... 8000 swept)
+#ifndef GPRN_WIDE_CHAIN
+#define GPRN_WIDE_CHAIN 48     // matrices in lock-step from which the chain's two products per tile step run on the tile kernel
+#endif
 #define GPRN_XCD_CHUNK_LOG2 4  // consecutive task-list entries that meet in one XCD's L2 (k_tile_gemm): 16
 
 // Pointers fetched from a device pointer table are generic to the compiler, which then emits
