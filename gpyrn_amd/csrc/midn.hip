@@ -31,6 +31,7 @@
 #include <vector>
 
 #define MB_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+#define MID_LEAD 4     // sweeps enqueued before the host looks at their results (the stop rule cannot fire before trip 4)
 
 struct MidBatch {
     gprn_ctx* w = nullptr;            // the worker context
@@ -147,7 +148,7 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
     MB_TRY(mb_alloc(c, &w->d_logdetK, (size_t)cap * G));
     MB_TRY(mb_alloc(c, &w->d_scal_base, (size_t)cap * nscal));
     MB_TRY(mb_alloc(c, &w->d_elbo_part, (size_t)cap * GPRN_ELBO_PART_DOUBLES));
-    MB_TRY(mb_alloc(c, &w->d_out, (size_t)cap * 4));
+    MB_TRY(mb_alloc(c, &w->d_out, (size_t)MID_LEAD * cap * 4));      // (one block of results per sweep enqueued ahead)
     MB_TRY(mb_alloc(c, &w->d_d, nslot * ld)); MB_TRY(mb_alloc(c, &w->d_s, nslot * ld)); MB_TRY(mb_alloc(c, &w->d_pred, nslot * ld));
     MB_TRY(mb_alloc(c, &w->d_z, nslot * ld)); MB_TRY(mb_alloc(c, &w->d_u, nslot * ld)); MB_TRY(mb_alloc(c, &w->d_cs, nslot * ld));
     MB_TRY(mb_alloc(c, &w->d_ct, nslot * ld));
@@ -189,7 +190,7 @@ static int mid_ensure(gprn_ctx* c, int want, int* cap_out)
     MB_TRY(mb_alloc(c, &m->d_int_block, m->n_int));
     m->pin_tab_bytes = m->n_ptr * sizeof(double*) + m->n_int * sizeof(int);
     m->pin_in_bytes = (size_t)cap * G * fill_program_bytes() + (2 * (size_t)cap * pn + 2 * (size_t)cap * d) * sizeof(double);
-    m->pin_out_bytes = (size_t)cap * 4 * sizeof(double) + 3 * nslot * sizeof(int) + 2 * (size_t)cap * d * sizeof(double) + 64;
+    m->pin_out_bytes = (size_t)MID_LEAD * cap * 4 * sizeof(double) + 3 * nslot * sizeof(int) + 2 * (size_t)cap * d * sizeof(double) + 64;
     HIP_TRY(c, hipHostMalloc((void**)&m->pin_tab, m->pin_tab_bytes, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&m->pin_in, m->pin_in_bytes, hipHostMallocDefault));
     HIP_TRY(c, hipHostMalloc((void**)&m->pin_out, m->pin_out_bytes, hipHostMallocDefault));
@@ -269,7 +270,7 @@ static int mid_phase(gprn_ctx* w, MidBatch* m, bool weights, int nA)
 }
 
 // m^T K^-1 m = |L_K^-1 m|^2 per latent GP of the phase, m the state row as it lies in memory (quirk Q2)
-static int mid_prior_term(gprn_ctx* w, MidBatch* m, bool weights, int nA)
+static int mid_prior_term(gprn_ctx* w, MidBatch* m, bool weights, int nA, hipStream_t st)
 {
     const int per = weights ? m->q * m->p : m->q, ns = per * nA;
     const int* slotgp = m->d_int_block + (weights ? m->i_gp_weight : m->i_gp_node);
@@ -277,46 +278,46 @@ static int mid_prior_term(gprn_ctx* w, MidBatch* m, bool weights, int nA)
     w->ev.slot_eval = m->d_int_block + (weights ? m->i_ev_weight : m->i_ev_node);
     w->slot0 = weights ? nA * m->q : 0;
     double* a = w->d_u + (size_t)w->slot0 * w->ld;
-    MB_TRY(vec_lower_matvec(w, BUF_KLINV, w->d_mu, w->N, 1, slotgp, ns, a));
-    return vec_dot_self(w, slotgp, ns, a, w->d_muKmu);
+    MB_TRY(vec_lower_matvec(w, BUF_KLINV, w->d_mu, w->N, 1, slotgp, ns, a, st));
+    return vec_dot_self(w, slotgp, ns, a, w->d_muKmu, st);
 }
 
-// One sweep (meanfield.py:651-710) of the evaluations in the active tables; out4 of each lands at d_out + 4 * evaluation.
-static int mid_sweep(gprn_ctx* w, MidBatch* m, int nA)
+// One sweep (meanfield.py:651-710) of the evaluations in the active tables; out4 of each lands at out4 + 4 * evaluation.
+// The pivot verdicts of its phases are only raised (rows 1, 2 of d_info: the caller clears them).
+static int mid_sweep(gprn_ctx* w, MidBatch* m, int nA, double* out4)
 {
     w->chain_started = nullptr;                          // (nothing left over from a sweep that broke off)
-    HIP_TRY(w, hipMemsetAsync(w->d_info + (size_t)w->nslot, 0, 2 * (size_t)w->nslot * sizeof(int), w->stream));
     MB_TRY(mid_phase(w, m, false, nA));
-    if (m->q > 1) {
-        // quirk Q1 (:1039-1041): lower(B_k^-1) = lower(X^T X) of every node but the last into its B buffer (L is not needed
-        // any more: log det B is taken), then <K_j^-1, Sigma_k> for j > k.  Nothing in the weight phase reads it: it runs
-        // beside that phase on the bulk stream, handed to its factorisation (behind the first diagonal block, as run_phase
-        // does it for one evaluation), and is joined before the ELBO assembly.
-        HIP_TRY(w, hipEventRecord(w->ev_nodes, w->stream));
-        w->chain_started = [w, m, nA]() -> int {
-            double** const cur = w->d_ptrs;
-            const int cur_slot0 = w->slot0;
-            const int* const cur_ev = w->ev.slot_eval;
-            HIP_TRY(w, hipStreamWaitEvent(w->stream2, w->ev_nodes, 0));
+    // What reads the node phase's results and nothing of the weight phase's runs BESIDE that phase on the bulk stream, handed to
+    // its factorisation (behind the first diagonal block, as run_phase does it for one evaluation) and joined before the
+    // ELBO assembly: the nodes' prior term m^T K^-1 m, and quirk Q1 (:1039-1041) -- lower(B_k^-1) = lower(X^T X) of every
+    // node but the last into its B buffer (L is not needed any more: log det B is taken), then <K_j^-1, Sigma_k> for j > k.
+    HIP_TRY(w, hipEventRecord(w->ev_nodes, w->stream));
+    w->chain_started = [w, m, nA]() -> int {
+        double** const cur = w->d_ptrs;
+        const int cur_slot0 = w->slot0;
+        const int* const cur_ev = w->ev.slot_eval;
+        HIP_TRY(w, hipStreamWaitEvent(w->stream2, w->ev_nodes, 0));
+        int rc = mid_prior_term(w, m, false, nA, w->stream2);
+        if (!rc && m->q > 1) {
             w->d_ptrs = m->d_ptr_block + m->o_node;
-            int rc = lauum_lower(w, (m->q - 1) * nA, w->stream2);
+            rc = lauum_lower(w, (m->q - 1) * nA, w->stream2);
             if (!rc) rc = vec_q1_evals(w, m->d_int_block + m->i_ev_node, m->Kinv, nA, m->q1_scratch, w->stream2);
-            w->d_ptrs = cur; w->slot0 = cur_slot0; w->ev.slot_eval = cur_ev;
-            if (rc) return rc;
-            HIP_TRY(w, hipEventRecord(w->ev_q1, w->stream2));
-            return GPRN_OK;
-        };
-    }
+        }
+        w->d_ptrs = cur; w->slot0 = cur_slot0; w->ev.slot_eval = cur_ev;
+        if (rc) return rc;
+        HIP_TRY(w, hipEventRecord(w->ev_q1, w->stream2));
+        return GPRN_OK;
+    };
     MB_TRY(mid_phase(w, m, true, nA));
     if (w->chain_started) {                              // (no factorisation took it along)
         std::function<int()> f;
         f.swap(w->chain_started);
         MB_TRY(f());
     }
-    if (m->q > 1) HIP_TRY(w, hipStreamWaitEvent(w->stream, w->ev_q1, 0));
-    MB_TRY(mid_prior_term(w, m, false, nA));
-    MB_TRY(mid_prior_term(w, m, true, nA));
-    return vec_elbo_evals(w, m->d_int_block + m->i_evals, nA, w->d_out, w->d_scal_base, w->d_elbo_part);
+    HIP_TRY(w, hipStreamWaitEvent(w->stream, w->ev_q1, 0));
+    MB_TRY(mid_prior_term(w, m, true, nA, w->stream));
+    return vec_elbo_evals(w, m->d_int_block + m->i_evals, nA, out4, w->d_scal_base, w->d_elbo_part);
 }
 
 struct MidIo {
@@ -390,50 +391,63 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     for (int b = 0; b < B; ++b) { act[b] = b; io.elbo[b] = 0.0; io.iters[b] = 0; io.conv[b] = 0; io.info[b] = 0; }
     std::vector<double> last3((size_t)3 * B, 0.0);
     double* const out_h = (double*)m->pin_out;
-    int* const info_h = (int*)(out_h + (size_t)m->cap * 4);
+    int* const info_h = (int*)(out_h + (size_t)MID_LEAD * m->cap * 4);
     bool tables_stale = true, first = true;
     while (!act.empty()) {
         const int nA = (int)act.size();
         if (tables_stale) { MB_TRY(mid_upload_active(c, m, act)); tables_stale = false; }
-        MB_TRY(mid_sweep(w, m, nA));
-        HIP_TRY(c, hipMemcpyAsync(out_h, w->d_out, (size_t)m->cap * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        // The stop rule cannot fire before trip 4 (:640), so the first trips -- min(4, max_iter) of them -- are enqueued
+        // without looking at their results in between: one host round trip instead of four (80 us each: the read-back,
+        // the rule, the next sweep's first launches), and the device goes from one sweep into the next.  A warm-started
+        // evaluation -- nELBO's case -- usually stops right there.  Later trips go one by one: each may be an
+        // evaluation's last, and its state must stay what that trip left.
+        const int lead = first ? std::max(1, std::min(MID_LEAD, io.max_iter)) : 1;
+        HIP_TRY(w, hipMemsetAsync(w->d_info + (size_t)w->nslot, 0, 2 * (size_t)w->nslot * sizeof(int), st));
+        for (int sw = 0; sw < lead; ++sw) MB_TRY(mid_sweep(w, m, nA, w->d_out + (size_t)sw * m->cap * 4));
+        HIP_TRY(c, hipMemcpyAsync(out_h, w->d_out, (size_t)lead * m->cap * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(c, hipMemcpyAsync(info_h, w->d_info, 3 * (size_t)w->nslot * sizeof(int), hipMemcpyDeviceToHost, st));
         us_enqueue += lap();
         HIP_TRY(c, hipStreamSynchronize(st));
         us_wait += lap();
-        n_sweeps += 1;
+        n_sweeps += lead;
         MB_TRY(factor_check_waits(w));
         std::vector<int> next;
         next.reserve(nA);
         for (int a = 0; a < nA; ++a) {
             const int b = act[a];
-            const double e = out_h[(size_t)b * 4];
-            // pivot verdicts: the set-up's (slot = b G + g) with the first sweep, the phases' (node-major slots) always
+            // pivot verdicts (raised, never lowered, by every sweep of the group): the set-up's (slot = b G + g) with the
+            // first group, the phases' (node-major slots) always
             int bad = 0;
             if (first) for (int g = 0; g < G && !bad; ++g) bad = std::max(0, info_h[(size_t)b * G + g]);
             for (int j = 0; j < q && !bad; ++j) bad = std::max(0, info_h[(size_t)w->nslot + (size_t)j * nA + a]);
             for (int kk = 0; kk < q * p && !bad; ++kk) bad = std::max(0, info_h[2 * (size_t)w->nslot + (size_t)kk * nA + a]);
             double* l3 = &last3[(size_t)3 * b];
-            if (bad || e != e) {
-                // a matrix that is not positive definite (jnp.linalg.cholesky: NaN from there on, no exception -- :71-89), or a
-                // state that has left the finite numbers: NaN stays NaN, so the loop would run to max_iter and return it
-                io.info[b] = bad;
-                io.elbo[b] = NAN;
-                io.iters[b] = io.max_iter;
-                continue;
+            bool go_on = true;
+            for (int sw = 0; sw < lead && go_on; ++sw) {
+                const double e = out_h[((size_t)sw * m->cap + b) * 4];
+                if (bad || e != e) {
+                    // a matrix that is not positive definite (jnp.linalg.cholesky: NaN from there on, no exception -- :71-89), or
+                    // a state that has left the finite numbers: NaN stays NaN, so the loop would run to max_iter and return it
+                    io.info[b] = bad;
+                    io.elbo[b] = NAN;
+                    io.iters[b] = io.max_iter;
+                    go_on = false;
+                    break;
+                }
+                io.elbo[b] = e;
+                if (io.iters[b] == 0) {                     // the sweep that stands for ELBOaux call 0 and trip 1
+                    l3[1] = e; l3[2] = e;
+                    if (io.max_iter == 0) { go_on = false; break; }   // only the discarded sweep: done, state as given
+                    io.iters[b] = 1;
+                } else {
+                    l3[0] = l3[1]; l3[1] = l3[2]; l3[2] = e;
+                    io.iters[b] += 1;
+                }
+                // (inside a group neither can happen before its last sweep: lead <= min(4, max_iter))
+                if (io.iters[b] > 3 && elbo_stop_rule(l3[0], l3[1], l3[2])) { io.conv[b] = 1; go_on = false; }
+                else if (io.iters[b] >= io.max_iter) go_on = false;
             }
-            io.elbo[b] = e;
-            if (io.iters[b] == 0) {                     // the sweep that stands for ELBOaux call 0 and trip 1
-                l3[1] = e; l3[2] = e;
-                if (io.max_iter == 0) continue;          // only the discarded sweep: done, state as given
-                io.iters[b] = 1;
-            } else {
-                l3[0] = l3[1]; l3[1] = l3[2]; l3[2] = e;
-                io.iters[b] += 1;
-            }
-            if (io.iters[b] > 3 && elbo_stop_rule(l3[0], l3[1], l3[2])) { io.conv[b] = 1; continue; }
-            if (io.iters[b] >= io.max_iter) continue;
-            next.push_back(b);
+            if (go_on) next.push_back(b);
         }
         if (next.size() != act.size()) tables_stale = true;
         act.swap(next);
