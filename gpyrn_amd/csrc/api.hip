@@ -1845,16 +1845,27 @@ extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel
     TRY(build_tables(c));
     const bool small = c->T == 1 && small_applies(c);
     const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;
-    const int chunk = small ? small_batch_chunk(c) : n_eval;       // (midn.hip sizes its own chunks: it knows what a matrix costs)
+    int chunk = small ? small_batch_chunk(c) : n_eval;             // (midn.hip sizes its own chunks: it knows what a matrix costs)
     if (small) c->last_batch_chunk = std::min(chunk, n_eval);
-    for (int e0 = 0; e0 < n_eval; e0 += chunk) {
+    for (int e0 = 0; e0 < n_eval;) {
         const int ne = std::min(chunk, n_eval - e0);
         const double* kp = kernel_params + (size_t)e0 * n_kernel_params;
         double* mo = mu_out ? mu_out + (size_t)e0 * d : nullptr;
         double* vo = var_out ? var_out + (size_t)e0 * d : nullptr;
         auto run = small ? small_batch_elbocalc : mid_batch_elbocalc;
-        TRY(run(c, ne, kp, n_kernel_params, y_resid + (size_t)e0 * pn, jitters + (size_t)e0 * c->p, mu + (size_t)e0 * d,
-                var + (size_t)e0 * d, max_iter, elbo + e0, iterations + e0, converged + e0, info + e0, mo, vo));
+        const int rc = run(c, ne, kp, n_kernel_params, y_resid + (size_t)e0 * pn, jitters + (size_t)e0 * c->p, mu + (size_t)e0 * d,
+                           var + (size_t)e0 * d, max_iter, elbo + e0, iterations + e0, converged + e0, info + e0, mo, vo);
+        if (rc == GPRN_E_NOMEM && small && ne > 1) {
+            // the budget is an estimate: the device has less in one piece than it reports free -- the same chunk in halves
+            // (nothing of it has run: the buffers are allocated before anything is enqueued)
+            small_batch_free(c);
+            chunk = std::max(1, ne / 2);
+            c->last_batch_chunk = chunk;
+            c->err.clear();
+            continue;
+        }
+        if (rc) return rc;
+        e0 += ne;
     }
     return GPRN_OK;
 }
