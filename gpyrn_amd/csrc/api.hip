@@ -297,6 +297,9 @@ static inline void watch_progress(gprn_ctx* c)
 //                    as in rounds 1-2; -1: the default (31).  Results are bit-identical for every value
 //   "batch_mem_mb"   device memory (MiB) one chunk of gprn_elbocalc_batch's evaluations may take; longer lists run chunk by chunk
 //   "comm_budget_s"  seconds an entry point may stay inside its collective section before the watchdog ends the process
+//   "accurate_factor" panel steps of a factorisation by substitution instead of products with explicit inverses (diag_tile.h
+//                    ACC): 0 never, 1 always (the launch path's sweeps too), -2 back to the default = every factorisation of a
+//                    PRIOR matrix (the set-up, prediction, prior draws)
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 //   "batch_chunk"    read-only: evaluations per chunk in the last gprn_elbocalc_batch call
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
@@ -313,12 +316,13 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "small_pad_kb")) field = &c->pad_small_kb_opt;
     else if (!strcmp(name, "batch_mem_mb")) field = &c->batch_mem_mb;
     else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
+    else if (!strcmp(name, "accurate_factor")) field = &c->acc_opt;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else if (!strcmp(name, "batch_chunk")) { if (old) *old = c->last_batch_chunk; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
     const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt;
-    if (is_pad && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
+    if ((is_pad || field == &c->acc_opt) && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
     if (value >= 0) {
         if (field == &c->use_flags && value) {
             int can = 0;
@@ -1196,7 +1200,7 @@ static int factor_priors_single(gprn_ctx* c)
     c->d_ptrs = c->tab_setup;
     c->slot0 = 0;
     c->d_info_cur = c->d_info;
-    TRY(factor_invert(c, nb));
+    TRY(factor_invert(c, nb, true));
     TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
     if (n_inv > 0) {
         c->d_ptrs = c->tab_kinv1;
@@ -1265,7 +1269,7 @@ static int factor_priors_impl(gprn_ctx* c)
         HIP_TRY(c, hipMemsetAsync(c->d_info, 0, 3 * (size_t)c->nslot * sizeof(int), c->stream));
         c->d_ptrs = c->tab_setup;
         c->d_info_cur = c->d_info;
-        TRY(factor_invert(c, nb));
+        TRY(factor_invert(c, nb, true));
         // log det K: non-owned helper entries are dropped below, before the all-reduce
         TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
         HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the verdicts are read through the null stream, which does not wait
@@ -2080,7 +2084,7 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
         c->d_ptrs = c->tab_pred;
         c->slot0 = 0;
         c->d_info_cur = c->d_info;
-        PTRY(factor_invert(c, nloc));
+        PTRY(factor_invert(c, nloc, true));
         PTRY(vec_lower_matvec(c, BUF_X, c->d_mu, N, 1, c->d_slotgp_all, nloc, c->d_u));   // u = X mu
         PTRY(vec_colops(c, nloc));                                                          // ct = X^T u
         for (int bt = 0; bt < ns_pad / GPRN_TILE; ++bt)
@@ -2209,7 +2213,7 @@ static int sample_prior_impl(gprn_ctx* c, const KernelSpec& ks, double nugget, i
                                              (size_t)N * sizeof(double), n_samples, hipMemcpyHostToDevice);
         if (e == hipSuccess) rc = launch_fill(c, ks, c->d_test[0], nugget);
         c->d_ptrs = d_p; c->d_info_cur = d_i;
-        if (e == hipSuccess && !rc) rc = factor_invert(c, 1);
+        if (e == hipSuccess && !rc) rc = factor_invert(c, 1, true);
         for (int s = 0; s < n_samples && e == hipSuccess && !rc; ++s)     // L z: row i of lower(B) . z
             rc = vec_lower_matvec(c, BUF_B, d_z + (size_t)s * ld, 0, 0, nullptr, 1, d_o + (size_t)s * ld);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

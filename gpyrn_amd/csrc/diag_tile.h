@@ -84,6 +84,9 @@ __device__ long long b16_stamps[4][8];
 #define B16_STAMP(R, i, dep) do {} while (0)
 #endif
 // c: the block in C layout (what lies above the diagonal is ignored); L -> St (lower), X -> xd and Xg
+// ACC (the set-up's factorisation of a PRIOR matrix, cond(K) ~ 1e8): W by substitution against the 4 x 4 block instead of
+// the product with its explicit inverse -- see subst16_row below
+template <bool ACC = false>
 __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pitch PP */,
                                             double* __restrict__ xd, gptr_t Xg, int ld,
                                             int* info, int slot, int pivot0,
@@ -135,6 +138,18 @@ __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pi
         // row fk of X = L^-1 in every lane (X L = I from the diagonal backwards; zero beyond the diagonal), and
         // with it W[r = fr][m = fk] = sum_n Sp[r][n] X[m][n]
         double xr[4], w = 0.0;
+        if constexpr (ACC) {
+            // row r of W solves  w L^T = Sp[r][.]  (every lane has the whole row and the uniform L); lane (r, m) keeps w[m]
+            double ws[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                double u = sp[n];
+#pragma unroll
+                for (int k = 0; k < n; ++k) u = fma(-ws[k], L[n][k], u);
+                ws[n] = u * inv[n];
+            }
+            w = fk == 0 ? ws[0] : (fk == 1 ? ws[1] : (fk == 2 ? ws[2] : ws[3]));
+        } else {
 #pragma unroll
         for (int n = 3; n >= 0; --n) {
             double u = 0.0;
@@ -142,6 +157,7 @@ __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pi
             for (int k = n + 1; k < 4; ++k) u = fma(xr[k], L[k][n], u);
             xr[n] = (fk == n) ? inv[n] : -u * inv[n];
             w = fma(sp[n], xr[n], w);
+        }
         }
         B16_STAMP(R, 5, w);
         // ---- 4. rank-4 update of what is still to come
@@ -169,6 +185,7 @@ __device__ __forceinline__ void base16_regs(v4d c, double* __restrict__ St /* pi
 }
 
 // the block from LDS (St, lower part)
+template <bool ACC = false>
 __device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
                                        double* __restrict__ xd, gptr_t Xg, int ld,
                                        int* info, int slot, int pivot0,
@@ -178,7 +195,7 @@ __device__ __forceinline__ void base16(double* __restrict__ St /* pitch PP */,
     v4d c;
 #pragma unroll
     for (int t = 0; t < 4; ++t) c[t] = St[(fk + 4 * t) * PP + fr];
-    base16_regs(c, St, xd, Xg, ld, info, slot, pivot0, line);
+    base16_regs<ACC>(c, St, xd, Xg, ld, info, slot, pivot0, line);
 }
 
 // 16x16 tile in MFMA C/D layout <-> LDS image [row][col], pitch PP
@@ -223,16 +240,55 @@ __device__ long long diag_stamps[4][NSB + 1][6];
 // small-batch pad.  (Round 1-2 form: 67 KB with the published column double-buffered -- it is read before barrier M and
 // rewritten after it, one buffer does -- and a scratch tile the pivot wave no longer needs.)
 #define DIAG_LDS_DOUBLES (128 * PP + 128 * PP + 2 * 16 * PP + 2 * 16 * PP + 64)
+// ... and of the ACC form (the pivot wave's own copy of its look-ahead panel block): the set-up's launches only
+#define DIAG_LDS_DOUBLES_ACC (DIAG_LDS_DOUBLES + 16 * PP)
 
 struct DiagLds {
-    double *PA, *PB, *DG, *XD, *LINE;
+    double *PA, *PB, *DG, *XD, *LINE, *LP;
     __device__ explicit DiagLds(double* lds)
         : PA(lds),                       // published column panel (before its scaling)        128 x PP
           PB(PA + 128 * PP),             // current column after scaling by X_kb^T              128 x PP
           DG(PB + 128 * PP),             // diagonal sub-tiles for / from the pivot wave (by parity)
           XD(DG + 2 * 16 * PP),          // X_kb by parity
-          LINE(XD + 2 * 16 * PP) {}
+          LINE(XD + 2 * 16 * PP),
+          LP(LINE + 64) {}               // ACC only (DIAG_LDS_DOUBLES_ACC): S(kb+1,kb) L_kb^-T of the pivot wave    16 x PP
 };
+
+// ---- ACC: the panel step by SUBSTITUTION.
+// The panel step of the blocked factorisation, L_ik = B_ik L_kk^-T, runs everywhere else as a PRODUCT with the explicit
+// inverse X_kk (the inverse is what the sweep has to build anyway, and a product is one MFMA pass where a substitution is
+// 16 dependent steps).  Its backward error is eps cond(L_kk) |B_ik| where a triangular solve has eps |L_ik| |L_kk^T|: on the
+// well-conditioned B = I + D^1/2 K D^1/2 of a sweep (cond 1e3-1e4) that is harmless; on a PRIOR matrix (cond(K) ~ 1e8, a
+// pure Periodic kernel: rank-deficient but for the reference's 1e-6 nugget) with a mean far outside the range of K it put
+// m^T K^-1 m at 4e-16 cond(K) = 2.8e-8 where LAPACK gets 1.4e-10 (profiles/r05_prior_term_accuracy.txt; the only input of
+// the round-5 tests that missed north_star's 1e-8).  The set-up's factorisation of K (meanfield.py:71-89, 621-622; its
+// cho_solve quadratic forms :1032, :1050) therefore solves, at all three block levels -- 4 (base16_regs), 16 (here) and 128
+// (trsm_rows16, gemm_tile.hip's k_tile_panel<true>) -- as LAPACK's potrf does: row r of the panel solves x L^T = s.
+// One lane per row; L (lower, [row][PP]) and the reciprocal pivots (the diagonal of X_kb) are uniform LDS reads; two
+// accumulators halve the dependent chain.  S and out may be the same row.
+__device__ __forceinline__ void subst16_row(const double* S, const double* __restrict__ Lb, const double* __restrict__ rinv,
+                                            int rinv_stride, double* out)
+{
+    double x[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const double2 v = *(const double2*)(S + 2 * j);
+        x[2 * j] = v.x; x[2 * j + 1] = v.y;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double a0 = x[c], a1 = 0.0;
+#pragma unroll
+        for (int m = 0; m + 1 < c; m += 2) {
+            a0 = fma(-x[m], Lb[c * PP + m], a0);
+            a1 = fma(-x[m + 1], Lb[c * PP + m + 1], a1);
+        }
+        if (c & 1) a0 = fma(-x[c - 1], Lb[c * PP + c - 1], a0);
+        x[c] = (a0 + a1) * rinv[c * rinv_stride];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *(double2*)(out + 2 * j) = double2{x[2 * j], x[2 * j + 1]};
+}
 
 // LDS-only workgroup barrier: global stores stay in flight across it
 __device__ __forceinline__ void lds_barrier()
@@ -262,7 +318,7 @@ __device__ __forceinline__ Op16 op16_t(const double* __restrict__ T)
 // one phase of a compute wave; KB and the wave's rows are compile-time constants, so every acc[][] index is one too
 // (as a loop over kb the body stayed rolled once -- the unroll pragma is a hint -- and the accumulators went to
 // scratch memory: 150 us per block instead of 23)
-template <int W, int kb>
+template <int W, int kb, bool ACC>
 __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld)
 {
     constexpr int ROWS[3] = {W == 0 ? 0 : (W == 1 ? 1 : 2), W == 0 ? 7 : (W == 1 ? 6 : 5), W == 0 ? -1 : (W == 1 ? 3 : 4)};
@@ -272,7 +328,20 @@ __device__ __forceinline__ void diag_phase(v4d (&acc)[3][NSB], const DiagLds& L,
     double* pa_next = L.PA;                            // (read before barrier M, rewritten after it)
     DG_STAMP(kb, 0);
     // ---- panel(kb): S(P,kb) <- S(P,kb) X_kb^T; the diagonal sub-tile comes back as L_kb
-    {
+    if constexpr (ACC) {
+        // ... by substitution against L_kb (the pivot wave left it in DG): lane l takes row l & 15 of the wave's (l >> 4)-th
+        // sub-tile row, published column -> scaled column; the sub-tiles come back into the accumulators from there
+        const int sp = lane >> 4;
+        const int P = sp == 0 ? ROWS[0] : (sp == 1 ? ROWS[1] : (sp == 2 ? ROWS[2] : -1));
+        if (P >= 0 && P != kb)
+            subst16_row(pa + (16 * P + fr) * PP, L.DG + (kb & 1) * 16 * PP, xd, PP + 1, L.PB + (16 * P + fr) * PP);
+        wave_lds_sync();
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            if (ROWS[pp] < 0) continue;
+            acc[pp][kb] = get16(ROWS[pp] == kb ? L.DG + (kb & 1) * 16 * PP : L.PB + (16 * ROWS[pp]) * PP);
+        }
+    } else {
         const Op16 xb = op16(xd);
         Op16 a[3];
 #pragma unroll
@@ -393,7 +462,7 @@ struct DiagFromTile {
 
 // nph: sub-tile columns (phases) that hold data -- beyond them the tile is its identity padding, whose factor and inverse
 // are the identity again (diag_identity_tail writes it); every wave of the workgroup gets the same value
-template <int W, class LOAD>
+template <int W, class LOAD, bool ACC>
 __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int nph)
 {
     // this wave's sub-tile rows (-1 = none): equal update counts
@@ -428,17 +497,17 @@ __device__ __forceinline__ void diag_compute(const DiagLds& L, gptr_t Bt, gptr_t
     DG_STAMP(NSB, 3);
 
     // (uniform branches around straight-line phases: every index into acc stays a compile-time constant)
-    diag_phase<W, 0>(acc, L, Bt, Xt, ld);
-    if (nph > 1) diag_phase<W, 1>(acc, L, Bt, Xt, ld);
-    if (nph > 2) diag_phase<W, 2>(acc, L, Bt, Xt, ld);
-    if (nph > 3) diag_phase<W, 3>(acc, L, Bt, Xt, ld);
-    if (nph > 4) diag_phase<W, 4>(acc, L, Bt, Xt, ld);
-    if (nph > 5) diag_phase<W, 5>(acc, L, Bt, Xt, ld);
-    if (nph > 6) diag_phase<W, 6>(acc, L, Bt, Xt, ld);
-    if (nph > 7) diag_phase<W, 7>(acc, L, Bt, Xt, ld);
+    diag_phase<W, 0, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 1) diag_phase<W, 1, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 2) diag_phase<W, 2, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 3) diag_phase<W, 3, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 4) diag_phase<W, 4, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 5) diag_phase<W, 5, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 6) diag_phase<W, 6, ACC>(acc, L, Bt, Xt, ld);
+    if (nph > 7) diag_phase<W, 7, ACC>(acc, L, Bt, Xt, ld);
 }
 
-template <class LOAD>
+template <class LOAD, bool ACC>
 __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t Xt, int ld, const LOAD& load, int* __restrict__ info, int slot,
                                            int pivot0, int nph)
 {
@@ -449,7 +518,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
 #pragma unroll
         for (int t = 0; t < 4; ++t) c0[t] = load(fk + 4 * t, fr);
         DG_STAMP(NSB, 1);
-        base16_regs(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
+        base16_regs<ACC>(c0, L.DG, L.XD, Xt, ld, info, slot, pivot0, L.LINE);
     }
     DG_STAMP(NSB, 2);
     lds_barrier();
@@ -466,14 +535,26 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
             // ---- one step ahead: bring S(kb+1,kb+1) up to date through step kb.  L'^T = X_kb S(kb+1,kb)^T comes
             // out of the MFMA as lane (fr = r, fk) holding L'[r][fk + 4t] -- an operand layout of L' (K index
             // fk + 4t for the t-th product), the same for both sides of L' L'^T: no trip through LDS
+            v4d uu = (v4d){0.0, 0.0, 0.0, 0.0};
+            if constexpr (ACC) {
+                // L' by substitution (subst16_row: the compute wave that owns row n does the same on the same input), a copy
+                // of this wave's own; from there as an operand layout of L' for both sides of L' L'^T
+                if ((threadIdx.x & 63) < 16)
+                    subst16_row(pa + (16 * n + (threadIdx.x & 15)) * PP, L.DG + (kb & 1) * 16 * PP, xd, PP + 1,
+                                L.LP + (threadIdx.x & 15) * PP);
+                wave_lds_sync();
+                const Op16 lp = op16(L.LP);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) uu = __builtin_amdgcn_mfma_f64_16x16x4f64(lp.v[s], lp.v[s], uu, 0, 0, 0);
+            } else {
             const Op16 xa = op16(xd), sb = op16(pa + (16 * n) * PP);
             v4d lt = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) lt = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.v[s], sb.v[s], lt, 0, 0, 0);
             // (L' L'^T from zero, subtracted once: the sub-tile holds diagonal entries -- see the compute waves' du)
-            v4d uu = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; ++s) uu = __builtin_amdgcn_mfma_f64_16x16x4f64(lt[s], lt[s], uu, 0, 0, 0);
+            }
             tt = get16(L.DG + (n & 1) * 16 * PP);
 #pragma unroll
             for (int t = 0; t < 4; ++t) tt[t] -= uu[t];
@@ -482,7 +563,7 @@ __device__ __forceinline__ void diag_pivot(const DiagLds& L, gptr_t Bt, gptr_t X
         lds_barrier();                                     // M
         DG_STAMP(kb, 2);
         if (kb < NSB - 1)                                  // ... then factor it, straight from the registers
-            base16_regs(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
+            base16_regs<ACC>(tt, L.DG + (n & 1) * 16 * PP, L.XD + (n & 1) * 16 * PP, Xt + (size_t)(16 * n) * ld + 16 * n, ld,
                         info, slot, pivot0 + 16 * n, L.LINE);
         DG_STAMP(kb, 3);
         lds_barrier();                                     // E
@@ -516,23 +597,85 @@ __device__ __forceinline__ void diag_identity_tail(gptr_t Bt, gptr_t Xt, int ld,
     }
 }
 
-template <class LOAD>
+// ACC: panel steps by substitution (subst16_row; `lds` then has DIAG_LDS_DOUBLES_ACC doubles)
+template <class LOAD, bool ACC = false>
 __device__ __forceinline__ void diag_tile_from(double* __restrict__ lds, const LOAD& load, gptr_t Bt, gptr_t Xt, int ld,
                                                int* __restrict__ info, int slot, int pivot0, int nph = NSB)
 {
     const DiagLds L(lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     nph = __builtin_amdgcn_readfirstlane(nph < 1 ? 1 : (nph > NSB ? NSB : nph));
-    if (wave == 0) diag_compute<0>(L, Bt, Xt, ld, load, nph);
-    else if (wave == 1) diag_compute<1>(L, Bt, Xt, ld, load, nph);
-    else if (wave == 2) diag_compute<2>(L, Bt, Xt, ld, load, nph);
-    else diag_pivot(L, Bt, Xt, ld, load, info, slot, pivot0, nph);
+    if (wave == 0) diag_compute<0, LOAD, ACC>(L, Bt, Xt, ld, load, nph);
+    else if (wave == 1) diag_compute<1, LOAD, ACC>(L, Bt, Xt, ld, load, nph);
+    else if (wave == 2) diag_compute<2, LOAD, ACC>(L, Bt, Xt, ld, load, nph);
+    else diag_pivot<LOAD, ACC>(L, Bt, Xt, ld, load, info, slot, pivot0, nph);
     if (nph < NSB) diag_identity_tail(Bt, Xt, ld, nph);
 }
 
 // ... of the tile at Bt itself
+template <bool ACC = false>
 __device__ __forceinline__ void diag_tile(double* __restrict__ lds, gptr_t Bt, gptr_t Xt, int ld,
                                           int* __restrict__ info, int slot, int pivot0, int nph = NSB)
 {
-    diag_tile_from(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0, nph);
+    diag_tile_from<DiagFromTile, ACC>(lds, DiagFromTile{Bt, ld}, Bt, Xt, ld, info, slot, pivot0, nph);
 }
+
+// ---- ACC at the tile level: 16 rows of a panel tile, x L_kk^T = b in place, by ONE wave.
+// Blocked by 16 like the tile itself: block column cb of the rows is solved by substitution against the diagonal block
+// L_kk[cb,cb] (subst16_row, one lane per row), then taken out of the block columns right of it on the matrix cores,
+// b[., cb'] -= x_cb L_kk[cb',cb]^T (the operand blocks of L_kk straight from memory, lane (n, fk) four consecutive k of row
+// n) -- LAPACK's blocked trsm with its 16 x 16 solves by substitution.  Every caller (the chain's tile, the side stream's
+// panel launch, the two-tile small path) runs this function on whole 16-row blocks, so the result does not depend on who
+// computed it.  rows: 16 rows x 128 columns, leading dimension ld; Lkk: the factored diagonal tile (lower part read);
+// Xkk: its inverse (diagonal read: the reciprocal pivots); scr: TRSM_SCRATCH doubles of LDS of this wave's own.
+#define TRSM_SCRATCH (2 * 16 * PP + 16)
+__device__ __forceinline__ void trsm_rows16(double* __restrict__ scr, gptr_t rows, gcptr_t Lkk, gcptr_t Xkk, int ld)
+{
+    const int l = threadIdx.x & 63, fr = l & 15, fk = l >> 4;
+    double* const SA = scr;                  // the block column being solved, [row][PP]
+    double* const SL = scr + 16 * PP;        // L_kk[cb,cb], [row][PP]
+    double* const SR = scr + 2 * 16 * PP;    // its reciprocal pivots
+    v4d acc[NSB];
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[cb][t] = rows[(size_t)(fk + 4 * t) * ld + 16 * cb + fr];
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb) {
+        // operands of this step, requested up front: the diagonal block (lane (row, part): four consecutive entries), the
+        // reciprocal pivots, and the blocks below it
+        gcptr_t Ld = Lkk + (size_t)(16 * cb) * ld + 16 * cb;
+        const v2d d0 = *(const GPRN_GLOBAL v2d*)(Ld + (size_t)fr * ld + 4 * fk);
+        const v2d d1 = *(const GPRN_GLOBAL v2d*)(Ld + (size_t)fr * ld + 4 * fk + 2);
+        const double rv = l < 16 ? Xkk[(size_t)(16 * cb + l) * ld + 16 * cb + l] : 0.0;
+        Op16 lb[NSB];
+#pragma unroll
+        for (int c2 = cb + 1; c2 < NSB; ++c2) {
+            gcptr_t Lo = Lkk + (size_t)(16 * c2 + fr) * ld + 16 * cb + 4 * fk;
+            const v2d lo = *(const GPRN_GLOBAL v2d*)Lo, hi = *(const GPRN_GLOBAL v2d*)(Lo + 2);
+            lb[c2] = Op16{{lo.x, lo.y, hi.x, hi.y}};
+        }
+        put16(SA, acc[cb]);
+        *(v2d*)(SL + fr * PP + 4 * fk) = d0;
+        *(v2d*)(SL + fr * PP + 4 * fk + 2) = d1;
+        if (l < 16) SR[l] = rv;
+        wave_lds_sync();
+        if (l < 16) subst16_row(SA + l * PP, SL, SR, 1, SA + l * PP);
+        wave_lds_sync();
+        // the solved block: to memory (lane (row, part): 32 bytes of its row) and, as the A operand, to the updates
+        {
+            const v2d x0 = *(const v2d*)(SA + fr * PP + 4 * fk), x1 = *(const v2d*)(SA + fr * PP + 4 * fk + 2);
+            *(GPRN_GLOBAL v2d*)(rows + (size_t)fr * ld + 16 * cb + 4 * fk) = x0;
+            *(GPRN_GLOBAL v2d*)(rows + (size_t)fr * ld + 16 * cb + 4 * fk + 2) = x1;
+#pragma unroll
+            for (int c2 = cb + 1; c2 < NSB; ++c2) {
+                acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0.x, lb[c2].v[0], acc[c2], 0, 0, 0);
+                acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x0.y, lb[c2].v[1], acc[c2], 0, 0, 0);
+                acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1.x, lb[c2].v[2], acc[c2], 0, 0, 0);
+                acc[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1.y, lb[c2].v[3], acc[c2], 0, 0, 0);
+            }
+        }
+        wave_lds_sync();                     // (SA, SL are rewritten by the next step)
+    }
+}
+

@@ -35,13 +35,13 @@
 // PTRS: the two pointers per matrix come as kernel arguments (launch_diag), else from the table
 // (one wave per SIMD: the register-resident tile needs ~290 VGPRs per lane; without the second bound the compiler sizes
 // the allocation for the three workgroups per CU the LDS would allow and spills)
-template <bool ARGS>
+template <bool ARGS, bool ACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk, int* __restrict__ info,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* wait_flag, unsigned wait_value,
                   unsigned* wait_timed_out, int nph)
 {
-    __shared__ __attribute__((aligned(16))) double lds[DIAG_LDS_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds[ACC ? DIAG_LDS_DOUBLES_ACC : DIAG_LDS_DOUBLES];
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[0] = __builtin_amdgcn_s_memrealtime();
     await_flag(wait_flag, wait_value, wait_timed_out);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[1] = __builtin_amdgcn_s_memrealtime();
@@ -51,7 +51,7 @@ void k_diag_block(double* const* __restrict__ ptrs, PtrArgs pa, int ld, int kblk
     double* const Xm = ARGS ? pa.p[slot][1] : ptrs[(size_t)slot * GPRN_NBUF + BUF_X];
     // (nph: the 16-column phases of this tile that hold data -- the last tile of a matrix whose size is not a multiple of 128
     // ends in identity padding, whose factor diag_tile writes without running the phases)
-    diag_tile(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE, nph);
+    diag_tile<ACC>(lds, (gptr_t)(Bm + off), (gptr_t)(Xm + off), ld, info, slot, kblk * GPRN_TILE, nph);
     if (pa.stamps && blockIdx.x == 0 && threadIdx.x == 0) pa.stamps[2] = __builtin_amdgcn_s_memrealtime();
     signal_done(sig_slot, sig_value, nullptr, 0, nullptr);
 }
@@ -114,18 +114,17 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     // as the neighbours would have cost (config 3 with the pad in the node phase: 109.8 vs 110.1), hence the limit.
     size_t dyn = 0;
     if (nbatch * c->T <= GPRN_LAT_MAX)
-        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES * sizeof(double));
+        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES_ACC * sizeof(double));
     pa.stamps = step_stamp_ptr(c, kblk, 0);
     // rows of data in this tile: all 128 but in the last tile of a ragged matrix (ld is the context's: the diagnostic entry
     // points factor whole tiles)
     const int rows_here = ld == c->ld ? std::min(GPRN_TILE, c->N - kblk * GPRN_TILE) : GPRN_TILE;
     const int nph = std::max(1, (rows_here + 15) / 16);
-    if (tab_rows(c, d_ptrs, nbatch, &pa))
-        hipLaunchKernelGGL(k_diag_block<true>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
-                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out, nph);
-    else
-        hipLaunchKernelGGL(k_diag_block<false>, dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk,
-                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out, nph);
+#define GO_D(ARGS, ACC) hipLaunchKernelGGL((k_diag_block<ARGS, ACC>), dim3(nbatch), dim3(256), dyn, stream, (double* const*)d_ptrs, pa, ld, kblk, \
+                           d_info, sig.slot, sig.value, aw.flag, aw.value, aw.timed_out, nph)
+    if (tab_rows(c, d_ptrs, nbatch, &pa)) { if (c->acc_now) GO_D(true, true); else GO_D(true, false); }
+    else { if (c->acc_now) GO_D(false, true); else GO_D(false, false); }
+#undef GO_D
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -652,8 +651,12 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
                 c->start_flag_now = nullptr;
                 if (rc) return rc;
             } else {
-            if ((rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, s0, nosig,
-                                       spin ? in_kernel_wait(k - 1, F_INNER) : noaw))) return rc;
+            // (a prior matrix: the tile by substitution, the panel kernel's ACC form on the step's first task)
+            if (c->acc_now) rc = launch_panel(c, c->d_tasks + s.panel0, 1, 0, c->d_ptrs, nbatch, c->ld, s0, nosig,
+                                              spin ? in_kernel_wait(k - 1, F_INNER) : noaw);
+            else rc = launch_tile_rows(c, k, c->d_ptrs, nbatch, c->ld, 0, GPRN_T_PANEL, s0, nosig,
+                                       spin ? in_kernel_wait(k - 1, F_INNER) : noaw);
+            if (rc) return rc;
             if (!use_flags) HIP_TRY(c, raise(s0, k, F_MINIL));
             // (flag schedule: L_{k+1,k}'s flag goes up at the START of the update launch behind it on the chain stream
             // instead of at the end of its own -- 1.7 us less between the two at every tile step)
@@ -808,10 +811,12 @@ int factor_check_waits(gprn_ctx* c)
 }
 
 
-int factor_invert(gprn_ctx* c, int nbatch)
+int factor_invert(gprn_ctx* c, int nbatch, bool prior)
 {
     int rc = ensure_tasks(c);
     if (rc) return rc;
+    struct AccScope { gprn_ctx* c; ~AccScope() { c->acc_now = false; } } acc_scope{c};
+    c->acc_now = c->acc_opt < 0 ? prior : c->acc_opt != 0;
     static int step_stamps_env = -1;               // GPRN_STEP_STAMPS=1/2 (probes): in-kernel clock stamps of the chain / of stream3 too
     if (step_stamps_env < 0) { const char* e = getenv("GPRN_STEP_STAMPS"); step_stamps_env = e ? atoi(e) : 0; }
     c->side_stamps = nullptr;

@@ -34,6 +34,7 @@
 #include <type_traits>
 
 #include "tile_mma.h"
+#include "diag_tile.h"
 
 // Output tile of one workgroup: BM x BN in {64,128}^2, computed by NW = 4 waves (2 x 2) or 8 waves (2 x 4).
 // A 128x128 task is cut into (128/BM) x (128/BN) workgroups (sub-tile index = blockIdx.x % that).
@@ -135,7 +136,10 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
 // triangular), the others X_kc = X_kk R_kc (128 x 64 workgroups, A triangular) -- two workgroups per task in either
 // form.  stream3 is the factorisation's second serial chain (synchronise, panel, in-panel update per tile step):
 // one launch less per step on it.
-__global__ __launch_bounds__(256, 2)
+// ACC (factor_invert's `prior`: the set-up's factorisation of a prior matrix): the L part by substitution against L_kk
+// (trsm_rows16, diag_tile.h: each of the workgroup's four waves 16 of its 64 rows) instead of the product with X_kk.
+template <bool ACC>
+__global__ __launch_bounds__(256, ACC ? 1 : 2)
 void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __restrict__ ptrs, int ld,
                   unsigned* sig_slot, unsigned sig_value, const unsigned* then_wait, unsigned then_value,
                   unsigned* wait_timed_out, const unsigned* wait_flag, unsigned wait_value,
@@ -159,6 +163,11 @@ void k_tile_panel(const TileTask* __restrict__ tasks, int n_l, double* const* __
         const double* A = pick(t.a_buf) + t.a_off + (a_mode ? (size_t)sub * 64 : (size_t)sub * 64 * ld);
         const double* B = pick(t.b_buf) + t.b_off;
         gptr_t C = (gptr_t)(pick(t.c_buf) + t.c_off) + (size_t)sub * 64 * ld;
+        if constexpr (ACC) {
+            // (the task: C = A = tile (i,k) of the B buffer, B = X_kk; L_kk is the same tile of the B buffer)
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            trsm_rows16(lds + wave * TRSM_SCRATCH, C + (size_t)(16 * wave) * ld, (gcptr_t)(pick(t.a_buf) + t.b_off), (gcptr_t)B, ld);
+        } else
         tile_mma<64, 128, 2, 2, 1>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen, (sub * 64) >> 4, 0);
     } else {                                                    // columns split
         const double* A = pick(t.a_buf) + t.a_off;
@@ -174,9 +183,11 @@ int launch_panel(gprn_ctx* c, const TileTask* d_tasks, size_t n_l, size_t n_x, d
 {
     if (n_l + n_x == 0 || nbatch == 0) return launch_tiles(c, d_tasks, 0, d_ptrs, nbatch, ld, GPRN_T_PANEL, stream, TS_128x64, sig);
     prof_begin(c, GPRN_T_PANEL, stream);
-    hipLaunchKernelGGL(k_tile_panel, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l,
-                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value,
-                       aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value, raise_at_start, raise_value, raise_at_start2);
+#define GO_P(ACC) hipLaunchKernelGGL(k_tile_panel<ACC>, dim3((unsigned)(2 * (n_l + n_x)), (unsigned)nbatch), dim3(256), 0, stream, d_tasks, (int)n_l, \
+                       (double* const*)d_ptrs, ld, sig.slot, sig.value, sig.then_wait, sig.then_value, \
+                       aw.timed_out ? aw.timed_out : sig.timed_out, aw.flag, aw.value, raise_at_start, raise_value, raise_at_start2)
+    if (c->acc_now) GO_P(true); else GO_P(false);
+#undef GO_P
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -402,6 +413,9 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
             HIP_TRY(c, hipStreamWaitValue32(stream, (void*)sig.then_wait, sig.then_value, hipStreamWaitValueGte, 0xffffffffu));
         return GPRN_OK;
     }
+    // (ACC: the L part of a panel never runs as a product -- k_tile_panel<true>, same grid, same flags)
+    if (c->acc_now && shape == TS_64x128_BTRI && tag == TG_PANEL)
+        return launch_panel(c, d_tasks, ntasks, 0, d_ptrs, nbatch, ld, stream, sig, aw, c->start_flag_now, c->start_value_now);
     prof_begin(c, fam, stream);
     // Bulk launches on the look-ahead stream (the K = 512 trailing updates, the X^T X product) ask for 16 KiB of unused
     // dynamic LDS on top of their image: two 64 x 64 workgroups per CU instead of three (one 128 x 128 instead of two).

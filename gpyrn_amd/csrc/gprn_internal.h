@@ -197,6 +197,11 @@ struct gprn_ctx {
     // memory (stream memory operations + in-kernel waits), 0 = HIP events, -1 = not decided yet.  Decided per
     // context from the device and the environment; latched to 0 after an in-kernel wait timed out.
     int use_flags = -1;
+    // Panel steps by substitution instead of products with explicit inverses (diag_tile.h ACC): acc_now is what the running
+    // factor_invert uses; option "accurate_factor": -1 every factorisation of a PRIOR matrix (set-up, prediction, prior draws),
+    // 0 never, 1 always (the sweeps' B too: diagnostics)
+    bool acc_now = false;
+    int acc_opt = -1;
     int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
@@ -392,8 +397,9 @@ __device__ __forceinline__ void signal_done(unsigned* slot, unsigned value, cons
     }
 }
 #endif
-// factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots
-int factor_invert(gprn_ctx* c, int nbatch);
+// factor B (slot buffers BUF_B) into L and X = L^-1 (BUF_X) for nbatch slots; prior: the matrices are prior covariances
+// (cond ~ 1e8 under the reference's nugget): panel steps by substitution (gprn_ctx::acc_opt)
+int factor_invert(gprn_ctx* c, int nbatch, bool prior = false);
 int lauum_lower(gprn_ctx* c, int nbatch, hipStream_t stream = nullptr);   // BUF_B = lower(X^T X), X in BUF_X
 int ensure_tasks(gprn_ctx* c);
 // internal status: an in-kernel dependency wait gave up; the entry points of api.hip re-run the call on events

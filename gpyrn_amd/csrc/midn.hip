@@ -377,7 +377,7 @@ static int mid_chunk(gprn_ctx* c, MidBatch* m, const MidIo& io)
     w->d_ptrs = m->d_ptr_block + m->o_setup;
     w->slot0 = 0;
     w->d_info_cur = w->d_info;
-    MB_TRY(factor_invert(w, B * G));
+    MB_TRY(factor_invert(w, B * G, true));
     MB_TRY(vec_logdet(w, BUF_B, m->d_int_block + m->i_gp_setup, B * G, w->d_logdetK));
     if (q > 1) {
         w->d_ptrs = m->d_ptr_block + m->o_kinv;
@@ -497,6 +497,7 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
     w->use_flags = c->use_flags;
     w->wait_budget_ms = c->wait_budget_ms;
     w->overlap_opt = c->overlap_opt;
+    w->acc_opt = c->acc_opt;
     w->pad_kb_opt = c->pad_kb_opt; w->pad_small_kb_opt = c->pad_small_kb_opt;
     w->prof.on = false;
     const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;

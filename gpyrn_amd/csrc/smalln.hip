@@ -116,14 +116,21 @@ __device__ __forceinline__ void small_lower_matvec(const double* M, int ld, int 
 // B = L L^T, X = L^-1 for T in {1, 2} tiles by one workgroup; tiles at Bm / Xm (leading dimension ld)
 // N: rows that hold data -- the 16-column phases of a diagonal tile beyond them are identity padding and are not run
 // (diag_tile's nph: at the reference's own N = 25 and 45 two and three of eight phases hold everything)
-template <int T>
+// ACC: a prior matrix -- panel steps by substitution (diag_tile.h)
+template <int T, bool ACC = false>
 __device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm, int ld, int* info, int slot, int N)
 {
-    diag_tile(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0, T == 1 ? (N + 15) / 16 : NSB);
+    diag_tile<ACC>(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0, T == 1 ? (N + 15) / 16 : NSB);
     if (T == 1) return;
     sm_publish();
     const size_t t10 = (size_t)GPRN_TILE * ld, t11 = t10 + GPRN_TILE;
     // L_10 = B_10 X_00^T (in place: the tile is written when all of it has been read)
+    if constexpr (ACC) {
+        // (a prior matrix: by substitution against L_00, 16 rows at a time per wave -- diag_tile.h trsm_rows16)
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (int rb = wave; rb < NSB; rb += 4)
+            trsm_rows16(lds + wave * TRSM_SCRATCH, (gptr_t)(Bm + t10) + (size_t)(16 * rb) * ld, (gcptr_t)Bm, (gcptr_t)Xm, ld);
+    } else
     tile_mma<128, 128, 2, 2, 1>(lds, Bm + t10, Xm, (gptr_t)(Bm + t10), ld, 0, 0, CM_SET, GPRN_TILE, 0, 0);
     sm_publish();
     // B_11 -= L_10 L_10^T;  R_10 = -L_10 X_00 (first touch of the inverse's row)
@@ -132,7 +139,7 @@ __device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm
     __syncthreads();
     tile_mma<128, 128, 2, 2, 0>(lds, Bm + t10, Xm, (gptr_t)(Xm + t10), ld, 0, 1, CM_SETNEG, GPRN_TILE, 0, 0);
     sm_publish();
-    diag_tile(lds, (gptr_t)(Bm + t11), (gptr_t)(Xm + t11), ld, info, slot, GPRN_TILE, (N - GPRN_TILE + 15) / 16);
+    diag_tile<ACC>(lds, (gptr_t)(Bm + t11), (gptr_t)(Xm + t11), ld, info, slot, GPRN_TILE, (N - GPRN_TILE + 15) / 16);
     sm_publish();
     // X_10 = X_11 R_10 (in place)
     tile_mma<128, 128, 2, 2, 2>(lds, Xm + t11, Xm + t10, (gptr_t)(Xm + t10), ld, 0, 1, CM_SET, GPRN_TILE, 0, 0);
@@ -513,7 +520,7 @@ struct SmallPriorArgs {
 };
 
 // chol(K) and its inverse for one latent GP per workgroup; log det K; K^-1 where asked
-template <int T>
+template <int T, bool ACC>
 __device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
 {
     __shared__ __attribute__((aligned(16))) double lds[SMALL_LDS_DOUBLES];
@@ -527,7 +534,7 @@ __device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
             *reinterpret_cast<double2*>(Bm + i) = *reinterpret_cast<const double2*>(Km + i);
         sm_publish();
     }
-    small_factor<T>(lds, Bm, Xm, ld, a.info, job, N);
+    small_factor<T, ACC>(lds, Bm, Xm, ld, a.info, job, N);
     sm_publish();
     double acc = 0.0;
     for (int n = tid; n < N; n += 256) acc += log(Bm[(size_t)n * ld + n]);
@@ -566,12 +573,12 @@ void k_small_tail_b(const SmallTailArgs* __restrict__ lanes, int sweep, int hist
     small_tail_body<T>(a);
 }
 
-template <int T>
+template <int T, bool ACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_small_prior(SmallPriorArgs a) { small_prior_body<T>(a); }
-template <int T>
+void k_small_prior(SmallPriorArgs a) { small_prior_body<T, ACC>(a); }
+template <int T, bool ACC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void k_small_prior_b(const SmallPriorArgs* __restrict__ lanes) { small_prior_body<T>(lanes[blockIdx.y]); }
+void k_small_prior_b(const SmallPriorArgs* __restrict__ lanes) { small_prior_body<T, ACC>(lanes[blockIdx.y]); }
 
 // ------------------------------------------------------------------ launchers
 // One tile (N <= 128) by default.  Two tiles work too (option "small_path" = 2; same tests) but do not pay: the four
@@ -625,8 +632,12 @@ int small_prior(gprn_ctx* c, double** d_tab, const int* d_job_gp, double** d_kin
     if (!njobs) return GPRN_OK;
     prof_begin(c, GPRN_T_DIAG);
     SmallPriorArgs a{(double* const*)d_tab, d_job_gp, (double* const*)d_kinv_out, c->N, c->ld, c->d_logdetK, d_info};
-    if (c->T == 1) hipLaunchKernelGGL(k_small_prior<1>, dim3(njobs), dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_small_prior<2>, dim3(njobs), dim3(256), 0, c->stream, a);
+    // (prior matrices: panel steps by substitution unless option "accurate_factor" = 0)
+    const bool acc = c->acc_opt != 0;
+#define GO_SP(TT, ACC) hipLaunchKernelGGL((k_small_prior<TT, ACC>), dim3(njobs), dim3(256), 0, c->stream, a)
+    if (c->T == 1) { if (acc) GO_SP(1, true); else GO_SP(1, false); }
+    else { if (acc) GO_SP(2, true); else GO_SP(2, false); }
+#undef GO_SP
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     return GPRN_OK;
@@ -859,7 +870,8 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
     // ---- set-up: every evaluation's G covariance matrices in one launch, their factors in another
     SB_TRY(launch_fill_batch(c, m->programs, (double* const*)m->kptr_dense, B * G));
     prof_begin(c, GPRN_T_DIAG);
-    hipLaunchKernelGGL(k_small_prior_b<1>, dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
+    if (c->acc_opt != 0) hipLaunchKernelGGL((k_small_prior_b<1, true>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
+    else hipLaunchKernelGGL((k_small_prior_b<1, false>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     // ---- the loop, SB_K sweeps per synchronisation

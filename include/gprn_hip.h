@@ -274,7 +274,12 @@ int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, 
  * at most; when the device cannot give that much in one piece the chunk is halved until it can); "batch_chunk" (read-only:
  * evaluations per chunk in the last gprn_elbocalc_batch call); "comm_budget_s" (sharded contexts: seconds an entry point may stay inside its collective section -- a rank that
  * died leaves the others there -- before the library's watchdog names the entry point, the collective and the rank on
- * stderr and ends the process with status 86; default 600, or GPRN_COMM_BUDGET_S).  value == -1 only reads; *old (may be
+ * stderr and ends the process with status 86; default 600, or GPRN_COMM_BUDGET_S); "accurate_factor" (the panel steps of
+ * a blocked factorisation as triangular SOLVES -- what LAPACK's potrf does -- instead of products with the explicit inverse
+ * of the diagonal block: by default (-2 returns to it) in every factorisation of a PRIOR matrix, i.e. the set-up
+ * (meanfield.py:71-89, 621-622), prediction and prior draws, where cond(K) ~ 1e8 under the reference's 1e-6 nugget and a
+ * product costs eps cond(K) on m^T K^-1 m (meanfield.py:1032, 1050); 0: never; 1: in the sweeps of the launch path as well).
+ * value == -1 only reads; *old (may be
  * NULL) receives the previous value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);
 
