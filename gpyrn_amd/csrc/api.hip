@@ -118,6 +118,9 @@ static int bad(gprn_ctx* c, const char* msg) { if (c) c->err = msg; return GPRN_
 // its broadcasts and its all-reduce a second time while the others have moved on.
 static int comm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max);
 static bool comm_active(const gprn_ctx* c);
+// (the collective watchdog, below: EVERY stream synchronisation of this file that returns tells it the device has made
+// progress -- the budget bounds a stall, not the length of a call: ADVICE r5, gprn_elbocalc at N = 16384 runs for minutes)
+static inline void watch_progress(gprn_ctx* c);
 
 static int agree_on_timeout(gprn_ctx* c, int rc, bool* any)
 {
@@ -131,7 +134,7 @@ static int agree_on_timeout(gprn_ctx* c, int rc, bool* any)
     int r = comm_allreduce(c, c->d_agree, 1, true);
     if (r) return r;
     HIP_TRY(c, hipMemcpyAsync(&all, c->d_agree, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     *any = all > 0.0;
     return GPRN_OK;
 }
@@ -150,7 +153,7 @@ static int agree_to_start(gprn_ctx* c, int local_rc, const char* what)
     const int r = comm_allreduce(c, c->d_agree, 1, true);
     if (r) return local_rc ? local_rc : r;
     HIP_TRY(c, hipMemcpyAsync(&all, c->d_agree, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     if (local_rc) return local_rc;
     if (all > 0.0) {
         c->err = std::string(what) + ": another rank did not pass its checks; no rank started the call";
@@ -300,6 +303,7 @@ static inline void watch_progress(gprn_ctx* c)
 //   "accurate_factor" panel steps of a factorisation by substitution instead of products with explicit inverses (diag_tile.h
 //                    ACC): 0 never, 1 always (the launch path's sweeps too), -2 back to the default = every factorisation of a
 //                    PRIOR matrix (the set-up, prediction, prior draws)
+//   "fenced_finalize" test hook: 1 = k_reduce_finalize hands its terms over with release / acquire fences (vecops.hip)
 //   "fallbacks"      read-only: calls re-run on the event schedule after a time-out
 //   "batch_chunk"    read-only: evaluations per chunk in the last gprn_elbocalc_batch call
 extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* old)
@@ -317,6 +321,7 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "batch_mem_mb")) field = &c->batch_mem_mb;
     else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
     else if (!strcmp(name, "accurate_factor")) field = &c->acc_opt;
+    else if (!strcmp(name, "fenced_finalize")) field = &c->fenced_finalize;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else if (!strcmp(name, "batch_chunk")) { if (old) *old = c->last_batch_chunk; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
@@ -517,7 +522,7 @@ extern "C" int gprn_set_data(gprn_ctx* c, int N, int p, int q, const double* tim
     DeviceLock lock_(c);
     if (!c || N <= 0 || p <= 0 || q <= 0 || !time || !y || !yerr) return bad(c, "set_data: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     free_problem(c);
     c->N = N; c->p = p; c->q = q; c->G = q + q * p;
     c->ld = ((N + GPRN_TILE - 1) / GPRN_TILE) * GPRN_TILE;
@@ -628,7 +633,7 @@ extern "C" int gprn_set_y_resid(gprn_ctx* c, const double* y)
     DeviceLock lock_(c);
     if (!c || !c->N || !y) return bad(c, "set_y_resid: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy(c->d_yres, y, (size_t)c->p * c->N * sizeof(double), hipMemcpyHostToDevice));
     c->have_yres = true;
     return GPRN_OK;
@@ -639,7 +644,7 @@ extern "C" int gprn_set_jitters(gprn_ctx* c, const double* jit)
     DeviceLock lock_(c);
     if (!c || !c->N || !jit) return bad(c, "set_jitters: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     std::vector<double> v((size_t)c->p * c->N);
     for (int i = 0; i < c->p; ++i)
         for (int n = 0; n < c->N; ++n)
@@ -654,7 +659,7 @@ extern "C" int gprn_set_muvar(gprn_ctx* c, const double* mu, const double* var)
     DeviceLock lock_(c);
     if (!c || !c->N || !mu || !var) return bad(c, "set_muvar: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
     HIP_TRY(c, hipMemcpy(c->d_mu, mu, dn, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_var, var, dn, hipMemcpyHostToDevice));
@@ -667,7 +672,7 @@ extern "C" int gprn_get_muvar(gprn_ctx* c, double* mu, double* var)
     DeviceLock lock_(c);
     if (!c || !c->N || !mu || !var) return bad(c, "get_muvar: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     const size_t dn = (size_t)(c->p + 1) * c->q * c->N * sizeof(double);
     HIP_TRY(c, hipMemcpy(mu, c->d_mu, dn, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(var, c->d_var, dn, hipMemcpyDeviceToHost));
@@ -800,7 +805,7 @@ static int shm_broadcast(gprn_ctx* c, double* buf, size_t n, int root)
 {
     ShmComm* sc = (ShmComm*)c->shm;
     if (n * sizeof(double) > ShmComm::kSlot) { c->err = "shm transport: message too large"; return GPRN_E_COMM; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     if (sc->rank == root) HIP_TRY(c, hipMemcpy(sc->slots, buf, n * sizeof(double), hipMemcpyDeviceToHost));
     TRY(shm_barrier(c, sc));
     if (sc->rank != root) HIP_TRY(c, hipMemcpy(buf, sc->slots, n * sizeof(double), hipMemcpyHostToDevice));
@@ -812,7 +817,7 @@ static int shm_allreduce(gprn_ctx* c, double* buf, size_t n, bool is_max)
 {
     ShmComm* sc = (ShmComm*)c->shm;
     if (n * sizeof(double) > ShmComm::kSlot) { c->err = "shm transport: message too large"; return GPRN_E_COMM; }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy(sc->slots + (size_t)sc->rank * ShmComm::kSlot, buf, n * sizeof(double), hipMemcpyDeviceToHost));
     TRY(shm_barrier(c, sc));
     std::vector<double> acc(n);
@@ -923,10 +928,10 @@ extern "C" int gprn_comm_barrier_max(gprn_ctx* c, double* value)
         HIP_TRY(c, hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
         TRY(comm_allreduce(c, d, 1, true));
         HIP_TRY(c, hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
         hipFree(d);
     } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     }
     return GPRN_OK;
 }
@@ -983,7 +988,7 @@ static int upload_table(gprn_ctx* c, double** d_tab, const std::vector<double*>&
 {
     HIP_TRY(c, hipMemcpyAsync(d_tab, rows.data(), rows.size() * sizeof(double*),
                               hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     tab_note(c, d_tab, rows.data(), rows.size());
     return GPRN_OK;
 }
@@ -1146,7 +1151,7 @@ static int factor_priors_small(gprn_ctx* c, bool sync = true)
     c->factored = true;
     if (!sync) return GPRN_OK;                             // gprn_elbocalc reads the pivot verdicts with its own results
     int first_info = 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (the library's streams do not synchronise with the null stream's copies)
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);          // (the library's streams do not synchronise with the null stream's copies)
     TRY(check_info(c, c->d_info, gps, &first_info));
     return first_info;
 }
@@ -1208,7 +1213,7 @@ static int factor_priors_single(gprn_ctx* c)
         c->d_ptrs = c->tab_setup;
     }
     int first_info = 0;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (the one wait of the call; the null stream's copy below does not
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);          // (the one wait of the call; the null stream's copy below does not
     TRY(check_info(c, c->d_info, gps, &first_info));      // wait for the library's non-blocking streams by itself)
     TRY(factor_check_waits(c));
     c->factored = true;
@@ -1272,7 +1277,7 @@ static int factor_priors_impl(gprn_ctx* c)
         TRY(factor_invert(c, nb, true));
         // log det K: non-owned helper entries are dropped below, before the all-reduce
         TRY(vec_logdet(c, BUF_B, c->d_slotgp_setup, nb, c->d_logdetK));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));      // (the verdicts are read through the null stream, which does not wait
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);      // (the verdicts are read through the null stream, which does not wait
         TRY(check_info(c, c->d_info, gps, &first_info));  // for the library's non-blocking streams by itself)
         // K_j^-1 = X^T X for the nodes that need it (one at a time: output goes to Kinv[j])
         for (int s = 0; s < nb; ++s) {
@@ -1282,13 +1287,13 @@ static int factor_priors_impl(gprn_ctx* c)
             std::vector<double*> one((size_t)c->nslot * GPRN_NBUF, nullptr);
             one[BUF_B] = c->Kinv[g];
             one[BUF_X] = rows[s * GPRN_NBUF + BUF_X];
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
             TRY(upload_table(c, c->tab_setup, one));
             TRY(lauum_lower(c, 1));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
             TRY(upload_table(c, c->tab_setup, rows));
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     }
     // non-owned helper factorizations wrote logdetK[j] too: keep only owned entries, then share
     {
@@ -1297,7 +1302,7 @@ static int factor_priors_impl(gprn_ctx* c)
         for (int g = 0; g < c->G; ++g) if (c->owner[g] != c->rank) h[g] = 0.0;
         HIP_TRY(c, hipMemcpy(c->d_logdetK, h.data(), c->G * sizeof(double), hipMemcpyHostToDevice));
         if (comm_active(c)) TRY(comm_allreduce(c, c->d_logdetK, c->G, false));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     }
     TRY(factor_check_waits(c));
     c->factored = true;
@@ -1531,8 +1536,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         if (comm_active(c) && it > 0 && (it & 63) == 0) {
             // a long call on a sharded context: let the host see the device's progress now and then, so that the collective
             // watchdog's budget bounds a STALL (a rank that died) and not the legitimate length of the call
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            watch_progress(c);
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
         }
         TRY(run_phase(c, false));
         TRY(run_phase(c, true));
@@ -1571,7 +1575,7 @@ static int sweep_impl(gprn_ctx* c, int n_sweeps, int commit, double* elbo_out, d
         HIP_TRY(c, hipMemcpyAsync(h_info.data(), c->d_info, h_info.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_out, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     for (int it = 0; it < n_sweeps; ++it) {
         elbo_out[it] = h[4 * it];
         if (parts_out) for (int k = 0; k < 3; ++k) parts_out[3 * it + k] = h[4 * it + 1 + k];
@@ -1698,7 +1702,7 @@ static int elbocalc_small(gprn_ctx* c, const ElboIo& io, int max_iter, std::vect
             HIP_TRY(c, hipMemcpyAsync(po + 2 * d, B, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipMemcpyAsync(po + 3 * d, Bv, d * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
         done = ctl[0];
         iter = ctl[1];
         *conv = ctl[2];
@@ -1902,7 +1906,7 @@ extern "C" int gprn_get_matrix(gprn_ctx* c, int which, int gp, double* out)
             }
     }
     if (!src) return bad(c, "get_matrix: not available on this rank (or keep_sigma was off)");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy2D(out, (size_t)c->N * sizeof(double), src, (size_t)c->ld * sizeof(double),
                            (size_t)c->N * sizeof(double), c->N, hipMemcpyDeviceToHost));
     if (which == GPRN_M_KLINV || which == GPRN_M_BX || which == GPRN_M_BL)      // strictly-upper tiles are scratch: report a clean lower factor
@@ -1919,7 +1923,7 @@ extern "C" int gprn_get_scalars(gprn_ctx* c, double* out)
     DeviceLock lock_(c);
     if (!c || !c->N || !out) return bad(c, "get_scalars: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy(out, c->d_scal, (3 * (size_t)c->G + (size_t)c->q * c->q) * sizeof(double), hipMemcpyDeviceToHost));
     return GPRN_OK;
 }
@@ -1929,7 +1933,7 @@ extern "C" int gprn_get_logdet_K(gprn_ctx* c, double* out)
     DeviceLock lock_(c);
     if (!c || !c->N || !out) return bad(c, "get_logdet_K: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy(out, c->d_logdetK, c->G * sizeof(double), hipMemcpyDeviceToHost));
     return GPRN_OK;
 }
@@ -2010,7 +2014,7 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
     const int ld = c->ld, N = c->N, T = c->T;
     const int ns_pad = ((ns + GPRN_TILE - 1) / GPRN_TILE) * GPRN_TILE;
     const size_t need = (size_t)ns_pad * ld;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     if (nloc && (c->predKs.size() != (size_t)c->nslot || c->pred_cap < need)) {
         for (auto& p : c->predKs) dev_free(p);
         for (auto& p : c->predWT) dev_free(p);
@@ -2117,12 +2121,12 @@ static int predict_impl(gprn_ctx* c, int ns, const double* tstar, double* mean_o
         if (rc) goto done;
         PHIP(hipMemcpyAsync(mean_out, d_all, (size_t)c->G * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PHIP(hipMemcpyAsync(var_out, d_all + (size_t)c->G * ns, (size_t)c->G * ns * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        PHIP(hipStreamSynchronize(c->stream));
+        PHIP(hipStreamSynchronize(c->stream)); watch_progress(c);
     } else if (nloc) {
         hm.resize((size_t)nloc * ns_pad); hv.resize((size_t)nloc * ns_pad);
         PHIP(hipMemcpyAsync(hm.data(), d_mean, hm.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         PHIP(hipMemcpyAsync(hv.data(), d_pvar, hv.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        PHIP(hipStreamSynchronize(c->stream));
+        PHIP(hipStreamSynchronize(c->stream)); watch_progress(c);
         for (int s = 0; s < nloc; ++s) {
             memcpy(mean_out + (size_t)gps[s] * ns, &hm[(size_t)s * ns_pad], ns * sizeof(double));
             memcpy(var_out + (size_t)gps[s] * ns, &hv[(size_t)s * ns_pad], ns * sizeof(double));
@@ -2178,7 +2182,7 @@ extern "C" int gprn_eval_kernel(gprn_ctx* c, const int32_t* ops, int n_ops, cons
     TRY(spec_from_args(c, ks, ops, n_ops, params, n_params, nugget != 0.0));
     TRY(test_setup(c, c->ld, 1, 1));
     TRY(launch_fill(c, ks, c->d_test[0], nugget));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipMemcpy2D(K_out, (size_t)c->N * sizeof(double), c->d_test[0], (size_t)c->ld * sizeof(double),
                            (size_t)c->N * sizeof(double), c->N, hipMemcpyDeviceToHost));
     return GPRN_OK;
@@ -2266,7 +2270,7 @@ static int grad_impl(gprn_ctx* c, int gp, double* Kinv_out, double* P_out, const
         if (!c->Sig[gp < c->q ? k : gp]) return bad(c, "grad_matrices: no Sigma yet (run a sweep with keep_sigma on)");
     if (c->nslot < 2) return bad(c, "grad_matrices: needs two workspace slots");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream2));
     const int ld = c->ld, N = c->N, T = c->T;
     const size_t nn = (size_t)ld * ld;
@@ -2389,7 +2393,7 @@ extern "C" int gprn_expected_loglike(gprn_ctx* c, double* logl_out)
     TRY(vec_elbo(c, c->d_out, c->d_scal_base, part));
     double h[GPRN_ELBO_PART_DOUBLES];
     HIP_TRY(c, hipMemcpyAsync(h, part, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;
     for (int b = 0; b < GPRN_ELBO_PART_DOUBLES / 3; ++b) { t1 += h[3 * b]; t2 += h[3 * b + 1]; t3 += h[3 * b + 2]; }
     *logl_out = -0.5 * t1 - 0.5 * t2 - 0.5 * t3;
@@ -2423,7 +2427,7 @@ extern "C" int gprn_prior_terms(gprn_ctx* c, int gp, const double* S, const doub
     if (!c->factored) return bad(c, "prior_terms: needs factor_priors first");
     HIP_TRY(c, hipSetDevice(c->device));
     TRY(build_tables(c));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     HIP_TRY(c, hipStreamSynchronize(c->stream2));
     const int ld = c->ld, N = c->N, T = c->T;
     // the latent GP's own row of the phase tables: BUF_B <- S (zero padding), BUF_X <- W = L_K^-1 S, BUF_KLINV = L_K^-1
@@ -2495,7 +2499,7 @@ extern "C" int gprn_prior_terms(gprn_ctx* c, int gp, const double* S, const doub
 static int test_setup(gprn_ctx* c, int ld, int nbuf_needed, int batch)
 {
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); watch_progress(c);
     const size_t nn = (size_t)ld * ld * batch;
     for (int b = 0; b < 3; ++b) {
         if (b < nbuf_needed && c->test_cap[b] < nn) {

@@ -23,6 +23,14 @@
 #endif
 #define GPRN_XCD_CHUNK_LOG2 4  // consecutive task-list entries that meet in one XCD's L2 (k_tile_gemm): 16
 
+// The hand-over of k_reduce_finalize (vecops.hip) without fences relies on what gfx942 / gfx950 do with agent-scope
+// stores and on vmcnt counting store acknowledgements; any other target gets the release / acquire form.
+#if defined(__gfx942__) || defined(__gfx950__) || !defined(__HIP_DEVICE_COMPILE__)
+#define GPRN_RELAXED_HANDOVER 1
+#else
+#define GPRN_RELAXED_HANDOVER 0
+#endif
+
 // Pointers fetched from a device pointer table are generic to the compiler, which then emits
 // FLAT loads; those also tick the LDS counter (lgkmcnt), so the wait before the first MFMA of
 // a K-chunk would drain the global prefetch of the next chunk.  Casting to the global
@@ -202,6 +210,7 @@ struct gprn_ctx {
     // 0 never, 1 always (the sweeps' B too: diagnostics)
     bool acc_now = false;
     int acc_opt = -1;
+    int fenced_finalize = 0;         // gprn_set_option "fenced_finalize" (tests): k_reduce_finalize's release / acquire form
     int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out

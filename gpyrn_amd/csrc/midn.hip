@@ -477,7 +477,9 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
                        const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
                        double* mu_out, double* var_out)
 {
-    if (c->T < 2) { c->err = "elbocalc_batch: internal (one-tile problems take the small path)"; return GPRN_E_ARG; }
+    // (a one-tile problem with the small path switched off -- option "small_path" = 0, or gprn_keep_sigma on: there is no
+    // batched form for it, as include/gprn_hip.h promises; inference.nELBO_batch then evaluates one by one -- ADVICE r5)
+    if (c->T < 2) { c->err = "elbocalc_batch: one-tile problems run side by side on the small path only"; return GPRN_E_UNSUPPORTED; }
     if (c->comm || c->shm || c->world != 1) { c->err = "elbocalc_batch: one rank only"; return GPRN_E_UNSUPPORTED; }
     int kp_total = 0;
     for (int g = 0; g < c->G; ++g) {
@@ -498,6 +500,7 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
     w->wait_budget_ms = c->wait_budget_ms;
     w->overlap_opt = c->overlap_opt;
     w->acc_opt = c->acc_opt;
+    w->fenced_finalize = c->fenced_finalize;
     w->pad_kb_opt = c->pad_kb_opt; w->pad_small_kb_opt = c->pad_small_kb_opt;
     w->prof.on = false;
     const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;

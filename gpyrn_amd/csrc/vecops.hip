@@ -311,6 +311,22 @@ void k_finalize(const int* __restrict__ slot_gp, int N, int ld, int p, int q,
 // tr B^-1 and log det B go to `terms`; the LAST workgroup of a GP to finish (ticket counter, reset by it) adds them up
 // exactly as k_finalize's threads did -- thread t: n = t, t + 256, ... in turn, then block_sum -- so both scalars keep
 // their bits.
+// The hand-over of the terms to that last workgroup, FENCED = false (the default on gfx942 / gfx950, GPRN_RELAXED_HANDOVER):
+// relaxed agent-scope stores, s_waitcnt vmcnt(0), a relaxed ticket, relaxed agent-scope loads -- no release / acquire pair,
+// so by the letter of the HIP memory model nothing orders the terms before the ticket.  What does, on this hardware:
+//   1. an agent-scope atomic store is issued with sc1: it is WRITTEN THROUGH this XCD's L2 to memory (the L2s of the eight
+//      XCDs are not coherent with each other; agent scope is the scope that crosses them), and the store's acknowledgement
+//      -- which s_waitcnt vmcnt(0) waits for: stores count in vmcnt on gfx9 -- comes back only after that;
+//   2. the ticket's read-modify-write is issued after the barrier behind that wait (a wave issues its memory instructions
+//      in order, and the asm statement is a compiler barrier), and is performed AT memory (device-scope atomics execute in
+//      the memory-side L2 / fabric, not in an XCD-local line);
+//   3. the last workgroup's loads are issued after the ticket's value has returned (the branch depends on it) and, being
+//      agent-scope atomic loads (sc1), bypass its own XCD's L2 lines: they read what 1. wrote.
+// The release / acquire form (FENCED; what any other --offload-arch gets) costs an L2 write-back per workgroup: 84 us for
+// the 192 matrices of a batch's weight phase against 9.  tests/test_parity_gpu.py::
+// test_reduce_finalize_relaxed_handover_keeps_the_bits runs both forms 200 times over more workgroups per slot than an
+// XCD holds and compares tr B^-1 and log det B bit for bit.
+template <bool FENCED>
 __global__ __launch_bounds__(256)
 void k_reduce_finalize(const int* __restrict__ slot_gp, int N, int ld, int T, int p, int q,
                        const double* __restrict__ part, const double* __restrict__ d, const double* __restrict__ s,
@@ -349,11 +365,18 @@ void k_reduce_finalize(const int* __restrict__ slot_gp, int N, int ld, int T, in
             if (Lm) __hip_atomic_store(tt + ld + n, log(Lm[(size_t)n * ld + n]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    constexpr bool fenced = FENCED || !GPRN_RELAXED_HANDOVER;
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread's stores acknowledged, then the workgroup's ticket
     __syncthreads();
-    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(tickets + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gridDim.x ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        const unsigned got = fenced ? __hip_atomic_fetch_add(tickets + slot, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                    : __hip_atomic_fetch_add(tickets + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = got + 1 == gridDim.x ? 1u : 0u;
+    }
     __syncthreads();
     if (!last) return;                              // (uniform)
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     double tr = 0.0, ld_acc = 0.0;
     for (int m = threadIdx.x; m < N; m += 256) {
         tr += __hip_atomic_load(tt + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -601,10 +624,12 @@ int vec_reduce_finalize(gprn_ctx* c, const int* d_slot_gp, int nslots, bool with
     }
     prof_begin(c, GPRN_T_VEC);
     const size_t o = (size_t)c->slot0 * c->ld, po = (size_t)c->slot0 * c->T * 2 * c->ld;
-    hipLaunchKernelGGL(k_reduce_finalize, dim3((c->ld + 255) / 256, nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld, c->T,
-                       c->p, c->q, c->d_part + po, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var,
-                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB,
-                       c->d_fin_terms + (size_t)c->slot0 * 2 * c->ld, c->d_fin_tickets + c->slot0, c->ev);
+#define GO_RF(F) hipLaunchKernelGGL(k_reduce_finalize<F>, dim3((c->ld + 255) / 256, nslots), dim3(256), 0, c->stream, d_slot_gp, c->N, c->ld, c->T, \
+                       c->p, c->q, c->d_part + po, c->d_d + o, c->d_s + o, c->d_z + o, c->d_cs + o, c->d_ct + o, c->d_mu, c->d_var, \
+                       c->d_trBinv, with_logdet ? (double* const*)c->d_ptrs : (double* const*)nullptr, c->d_logdetB, \
+                       c->d_fin_terms + (size_t)c->slot0 * 2 * c->ld, c->d_fin_tickets + c->slot0, c->ev)
+    if (c->fenced_finalize) GO_RF(true); else GO_RF(false);
+#undef GO_RF
     LAUNCH_END(c);
 }
 

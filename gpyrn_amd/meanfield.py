@@ -811,8 +811,15 @@ class inference:
         def share(xs):
             out = self._nELBO_batch_device(xs, max_iter)
             if out is None:                                    # (vectors that change a kernel expression's shape)
-                out = [float(self.nELBO(x, max_iter=max_iter)) for x in xs]
-                last['key'] = mine[-1]
+                # one by one: the state to hand round is that of the last evaluation whose loop CONVERGED -- ELBOcalc
+                # stores a state only then (a new array object) -- and only such a state is offered: with nothing stored
+                # the ranks would meet in the collective with buffers of different sizes
+                out = []
+                for i, x in enumerate(xs):
+                    before = self._mu
+                    out.append(float(self.nELBO(x, max_iter=max_iter)))
+                    if self._mu is not None and self._mu is not before:
+                        last['key'] = mine[i]
             elif self._batch_last_done >= 0:
                 last['key'] = mine[self._batch_last_done]
             return out
@@ -820,7 +827,7 @@ class inference:
         mu0, var0 = self._mu, self._var
         vals = pool.map_lists(share, sets)
         shape = (self.p + 1, self.q, self.N)
-        offer = [self._mu, self._var] if last['key'] >= 0 else [np.zeros(shape), np.zeros(shape)]
+        offer = [np.reshape(self._mu, shape), np.reshape(self._var, shape)] if last['key'] >= 0 else [np.zeros(shape), np.zeros(shape)]
         got = pool.take_from_highest(last['key'], offer)
         if got is not None:
             self._mu, self._var = got

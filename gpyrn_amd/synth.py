@@ -48,6 +48,11 @@ def component_spec(p, q, node_kind='QP'):
 def build_components(covfunc, meanfunc, spec):
     """Instantiate a spec against a covfunc/meanfunc module pair."""
     nodes, weights, means, jitters = spec
-    mk = lambda mod, item: None if item is None else getattr(mod, item[0])(*item[1])
+
+    def mk(mod, item):           # (name, [parameters]); a parameter that is itself such a pair is built first (Sum, Multiplication)
+        if item is None:
+            return None
+        return getattr(mod, item[0])(*[mk(mod, a) if isinstance(a, (list, tuple)) and a and isinstance(a[0], str) else a
+                                       for a in item[1]])
     return ([mk(covfunc, n) for n in nodes], [mk(covfunc, w) for w in weights],
             [mk(meanfunc, m) for m in means], list(jitters))

@@ -279,6 +279,8 @@ int gprn_elbocalc_batch(gprn_ctx* ctx, int n_eval, const double* kernel_params, 
  * of the diagonal block: by default (-2 returns to it) in every factorisation of a PRIOR matrix, i.e. the set-up
  * (meanfield.py:71-89, 621-622), prediction and prior draws, where cond(K) ~ 1e8 under the reference's 1e-6 nugget and a
  * product costs eps cond(K) on m^T K^-1 m (meanfield.py:1032, 1050); 0: never; 1: in the sweeps of the launch path as well).
+ * "fenced_finalize" (test hook: the finalising kernel of a phase hands its partial terms to its last workgroup with
+ * release / acquire fences instead of the gfx942 / gfx950 shortcut documented in csrc/vecops.hip; same bits).
  * value == -1 only reads; *old (may be
  * NULL) receives the previous value. */
 int gprn_set_option(gprn_ctx* ctx, const char* name, int value, int* old);

@@ -19,7 +19,11 @@ def available(tag):
 
 
 def components(meta, covfunc, meanfunc):
-    mk = lambda mod, item: None if item is None else getattr(mod, item[0])(*item[1])
+    def mk(mod, item):           # (composite kernels: a parameter that is itself (name, [parameters]) is built first)
+        if item is None:
+            return None
+        return getattr(mod, item[0])(*[mk(mod, a) if isinstance(a, (list, tuple)) and a and isinstance(a[0], str) else a
+                                       for a in item[1]])
     nodes = [mk(covfunc, n) for n in meta['nodes']]
     weights = [mk(covfunc, w) for w in meta['weights']]
     means = [mk(meanfunc, m) for m in meta['means']]

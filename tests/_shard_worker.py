@@ -62,6 +62,15 @@ def main(tag, out, uid_tag):
         np.savez(out, rank=comm.rank, world=comm.world, message='ran to the end')
         comm.cleanup()
         return
+    if os.environ.get('GPRN_TEST_LONG_ELBOCALC'):
+        # ONE gprn_elbocalc call that legitimately outlasts the watchdog's budget (q = 3: the reference's iteration
+        # diverges, the stop rule never fires, the loop runs to max_iter) -- the budget bounds a stall, not a call's length
+        import time
+        t0 = time.time()
+        E, mu, var, it = g.ELBOcalc(max_iter=int(os.environ['GPRN_TEST_LONG_ELBOCALC']))
+        np.savez(out, rank=comm.rank, world=comm.world, seconds=time.time() - t0, iters=it)
+        comm.cleanup()
+        return
     hook_rank = int(os.environ.get('GPRN_TEST_WITHHOLD_RANK', -1))
     if hook_rank == comm.rank:
         # this rank only: a producer flag that never goes up, so that its in-kernel wait gives up after 20 ms

@@ -7,8 +7,10 @@ from oracle import cpu_ref
 from gpyrn_amd import covfunc, meanfunc
 from tests import _cases
 
-SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3']
-MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1']
+# illc_*: an ill-conditioned prior under a diverging state (a pure Periodic weight, q = 3); kmix_*: a converging problem on
+# Periodic / Multiplication / Matern / RationalQuadratic / Sum kernels (oracle/gen_golden.py, round 6)
+SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3', 'illc_N100_p2q3']
+MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1', 'illc_N300_p2q3', 'kmix_N200_p2q2']
 
 
 def _problem(tag):
@@ -71,7 +73,7 @@ def test_forced_sweeps_at_config_5_shape():
 
 
 @pytest.mark.parametrize('form', ['ref', 'B'])
-@pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'cfg1_N200', 'mid_N300_p3q2'])
+@pytest.mark.parametrize('tag', ['step_p1q1', 'step_p3q2', 'cfg1_N200', 'mid_N300_p3q2', 'kmix_N200_p2q2'])
 def test_elbo_calc_trajectory(tag, form):
     meta, d, *_, args = _problem(tag)
     if 'calc_elbo' not in d:

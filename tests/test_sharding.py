@@ -279,16 +279,25 @@ def test_pooled_side_by_side_evaluations_keep_one_state_on_every_rank():
     t = np.linspace(0.0, 10.0, 12)
     sets = [np.array([1.0 + 0.1 * k, 2.0, 0.5, 3.0, 0.0, 0.1]) for k in range(7)]
 
-    def run(converging):
+    def run(converging, one_by_one=False, stored=True):
         wire, out = Wire(), [None] * world
 
         def rank_main(r):
             g = gpyrn.inference(1, t, np.sin(t), 0.1 * np.ones(t.size))
             g.set_components(covfunc.SquaredExponential(1.0, 2.0), covfunc.SquaredExponential(0.5, 3.0),
                              meanfunc.Constant(0.0), 0.1)
-            g._mu = np.full((2, 1, t.size), -1.0)
-            g._var = np.full((2, 1, t.size), -2.0)
+            if stored:
+                g._mu = np.full((2, 1, t.size), -1.0)
+                g._var = np.full((2, 1, t.size), -2.0)
             seen = []
+
+            def fake_nelbo(x, max_iter=None):                  # what nELBO does to the object: a state only when it converged
+                seen.append(float(x[0]))
+                g.set_parameters(x)
+                if round((x[0] - 1.0) * 10) in converging:
+                    g._mu = np.full((2, 1, t.size), x[0])
+                    g._var = np.full((2, 1, t.size), 10.0 * x[0])
+                return float(np.sum(x))
 
             def fake_device(xs, max_iter):                     # what _nELBO_batch_device does to the object
                 seen.extend(float(x[0]) for x in xs)
@@ -299,10 +308,12 @@ def test_pooled_side_by_side_evaluations_keep_one_state_on_every_rank():
                     g._var = np.full((2, 1, t.size), 10.0 * xs[done[-1]][0])
                 return [float(np.sum(x)) for x in xs]
 
-            g._nELBO_batch_device = fake_device
+            g._nELBO_batch_device = (lambda xs, max_iter: None) if one_by_one else fake_device
+            g.nELBO = fake_nelbo
             g._batchable = lambda: True
             vals = g.nELBO_batch(sets, pool=pool_for(wire, r))
-            out[r] = (vals, g._mu.copy(), g._var.copy(), seen, np.array(g.get_parameters()))
+            out[r] = (vals, None if g._mu is None else g._mu.copy(), None if g._var is None else g._var.copy(), seen,
+                      np.array(g.get_parameters()))
 
         threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
         for th in threads:
@@ -321,6 +332,18 @@ def test_pooled_side_by_side_evaluations_keep_one_state_on_every_rank():
     out = run(set())                                           # nothing converged: every rank keeps the state it had
     for vals, mu, var, seen, pars in out:
         assert np.all(mu == -1.0) and np.all(var == -2.0)
+    # a share that cannot run side by side is evaluated one by one.  The state handed round is again that of the
+    # last evaluation of the whole list that CONVERGED (vector 3: rank 0's second, not its last), and a rank on which
+    # nothing converged and nothing was stored (no state at all) offers nothing -- the collective's buffers stay the same
+    # size on every rank
+    out = run({1, 3}, one_by_one=True, stored=False)
+    for r, (vals, mu, var, seen, pars) in enumerate(out):
+        np.testing.assert_allclose(vals, [float(np.sum(x)) for x in sets], rtol=1e-15)
+        assert seen == [sets[i][0] for i in range(r, 7, world)]
+        assert np.all(mu == sets[3][0]) and np.all(var == 10.0 * sets[3][0])
+    out = run(set(), one_by_one=True, stored=False)            # nothing converged, nothing stored: still nothing
+    for vals, mu, var, seen, pars in out:
+        assert mu is None and var is None
 
 
 # ---------------------------------------------------------------- bench.py --gpus N without a launcher
