@@ -164,8 +164,9 @@ def cpu_baseline(N, p, q, kind):
            'sample': f'{n_all} consecutive reference-formulation sweeps of the configuration (N={N}, p={p}, q={q}: all {G} '
                      f'latent GPs, {dt_all:.1f} s) with NumPy/SciPy LAPACK on all host cores',
            'blas': _blas_build(),
-           'note': 'the BLAS picks its own thread count (OpenBLAS builds cap it, e.g. 64 on a 256-core box): a stated baseline, '
-                   'not a tuned one'}
+           'note': 'value: the BLAS picks its own thread count (OpenBLAS builds cap it, e.g. 64 on a 256-core box, where the '
+                   'LU / Cholesky of a 4096 matrix scales badly); by_threads / best_threads: the same formulation with the BLAS held '
+                   'to 8, 16, 32 threads and its default -- divide by best_threads.value, not by value'}
     try:
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=1):
@@ -173,6 +174,19 @@ def cpu_baseline(N, p, q, kind):
         out['one_thread'] = {'value': 1.0 / (dt_1 * G / 2), 'unit': 'sweeps/s', 'cores': 1,
                              'sample': f'one sweep at N={N}, p=1, q=1 (2 of {G} latent GPs, {dt_1:.1f} s) on one '
                                        f'BLAS thread, scaled by {G}/2'}
+        # a baseline a reader can divide by -- the p = q = 1 sweep of the same N with the BLAS held to 8, 16
+        # and 32 threads and at its default, each scaled by G / 2 (every latent GP costs the same in that formulation)
+        by = {}
+        for nt in (8, 16, 32, None):
+            if nt is not None and nt > (os.cpu_count() or 1):
+                continue
+            with threadpool_limits(limits=nt):
+                dt = sweeps(1, 1, 1)
+            by['default' if nt is None else str(nt)] = {'value': 1.0 / (dt * G / 2), 'seconds_p1q1': dt}
+        best = max(by, key=lambda k: by[k]['value'])
+        out['by_threads'] = by
+        out['best_threads'] = {'threads': best, 'value': by[best]['value'], 'unit': 'sweeps/s',
+                               'sample': f'one sweep at N={N}, p=1, q=1 ({by[best]["seconds_p1q1"]:.1f} s) scaled by {G}/2'}
     except ImportError:
         out['one_thread'] = None
     return out

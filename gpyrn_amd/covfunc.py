@@ -187,9 +187,9 @@ class Multiplication(_operator):
         return f'{self.k1} * {self.k2}'
 
 
-class Derivative(covFunction):
-    """d^2 k / dx_i dx_j of a twice-differentiable kernel (covfunc.py:83-104)."""
-    _derivative_ids = {}       # filled below: kernel class -> KID of its derivative
+class _unary_operator(covFunction):
+    """Base of the operators on ONE kernel (covfunc.py:83-95): takes a twice-differentiable kernel, shares its parameter
+    array and names.  Private in the reference too; kept so that ``isinstance(k, covfunc._unary_operator)`` holds."""
 
     def __init__(self, k):
         if not getattr(k, '_twice_differentiable', False):
@@ -199,6 +199,11 @@ class Derivative(covFunction):
         self.pars = k.pars
         self._param_names = k._param_names
         self._tag = 'd' + k._tag
+
+
+class Derivative(_unary_operator):
+    """d^2 k / dx_i dx_j of a twice-differentiable kernel (covfunc.py:98-104)."""
+    _derivative_ids = {}       # filled below: kernel class -> KID of its derivative
 
     def __call__(self, r):
         return self.k._dkdxidj(r)

@@ -176,6 +176,9 @@ def test_kernel_protocol_quirks():
     assert c.pars.size == 2                        # amplitude never enters pars
     with pytest.raises(ValueError):
         covfunc.Derivative(covfunc.Matern32(1, 1))
+    # the operators' private bases, as in covfunc.py:56, 83 (an isinstance against them is all that could tell)
+    assert isinstance(covfunc.Derivative(covfunc.SquaredExponential(1, 2)), covfunc._unary_operator)
+    assert isinstance(s, covfunc._operator) and issubclass(covfunc._unary_operator, covfunc.covFunction)
     with pytest.raises(AttributeError):
         covfunc.NewRQP(1, 1, 1, 1, 1, 1)(np.zeros((2, 2)))
     assert repr(covfunc.SquaredExponential(1, 2)) == 'SquaredExponential(theta=1.0, ell=2.0)'
