@@ -1,5 +1,5 @@
 // potrf + inverse of one 128 x 128 diagonal tile by one workgroup (device code; included by factor.hip, smalln.hip and
-// the probes under _probe/).  Replaces jnp.linalg.cholesky on a tile (/root/reference/gpyrn/meanfield.py:71-89) and the
+// the probes under profiles/probes/).  Replaces jnp.linalg.cholesky on a tile (/root/reference/gpyrn/meanfield.py:71-89) and the
 // triangular solve against it.
 #pragma once
 #include "gprn_internal.h"
@@ -39,7 +39,7 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     const double hx = -0.5 * x;
     y = y * fma(hx * y, y, 1.5);
     y = y * fma(hx * y, y, 1.5);      // second step: seed accuracy is not documented for gfx950 (and dropping
-                                      // it does not shorten base16: 7537 vs 7701 cycles, _probe/base16_bench.hip)
+                                      // it does not shorten base16: 7537 vs 7701 cycles, profiles/probes/base16_bench.hip)
     return y;
 }
 
@@ -77,7 +77,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane /* wave-un
 // W is final: it goes straight to St (L) resp. xd / Xg (X); the block's own L entries are stored by lane 0.
 // The single wave that runs this is issue-bound, not latency-bound: the lane-owned form below (base16_lanes, rounds
 // 1-2) needs ~1500 instructions per block, 3.4 us; this one ~600.
-#ifdef BASE16_STAMPS     // _probe/base16_bench.hip: shader-clock stamps inside one call, after `dep` is available
+#ifdef BASE16_STAMPS     // profiles/probes/base16_bench.hip: shader-clock stamps inside one call, after `dep` is available
 __device__ long long b16_stamps[4][8];
 #define B16_STAMP(R, i, dep) do { asm volatile("" :: "v"(dep)); b16_stamps[R][i] = clock64(); } while (0)
 #else
@@ -230,7 +230,7 @@ __device__ __forceinline__ v4d get16(const double* __restrict__ T)
 // -- round 2 measured the branchy form (one basic block per 16x16 product, operands re-read for each) at 600 clocks
 // per product where the four dependent MFMAs need 256.  Column kb of the result is stored during phase kb instead of
 // in an epilogue of its own (5 us of 38 for one tile).
-#ifdef DIAG_STAMPS        // _probe/diag_bench.hip: shader-clock stamps per wave, phase and point
+#ifdef DIAG_STAMPS        // profiles/probes/diag_bench.hip: shader-clock stamps per wave, phase and point
 __device__ long long diag_stamps[4][NSB + 1][6];
 #define DG_STAMP(kb, i) do { if ((threadIdx.x & 63) == 0) diag_stamps[threadIdx.x >> 6][kb][i] = clock64(); } while (0)
 #else

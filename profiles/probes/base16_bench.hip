@@ -1,5 +1,5 @@
 // standalone: cycles of one base16() call (the 16-pivot chain) -- hipcc --offload-arch=gfx950 base16_bench.hip -o base16_bench
-#include "../diag_tile.h"
+#include "../../gpyrn_amd/csrc/diag_tile.h"
 #include <stdio.h>
 
 template <int OLD>

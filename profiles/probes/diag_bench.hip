@@ -1,7 +1,7 @@
 // standalone: shader-clock timeline of one diag_tile() call (potrf + inverse of a 128x128 tile), per wave and phase
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 diag_bench.hip -o diag_bench
 #define DIAG_STAMPS
-#include "../diag_tile.h"
+#include "../../gpyrn_amd/csrc/diag_tile.h"
 #include <stdio.h>
 #include <vector>
 

@@ -1,6 +1,6 @@
 """Do small / odd tile counts ever hit the wait budget on the flag schedule?  Prints the fallback count per shape."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import numpy as np
 from gpyrn_amd import _hip
 

@@ -1,6 +1,6 @@
 """Which factor_priors call of a small model hits the wait budget on the flag schedule?"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import numpy as np
 import gpyrn_amd as gpyrn
 from gpyrn_amd import covfunc

@@ -1,6 +1,6 @@
 # one K=512 bulk-shaped launch set (run under rocprofv3 --pmc ...; GPRN_PAD_ALL=1 for one workgroup per CU)
 import sys, numpy as np
-import os; sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..', '..')))
+import os; sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 from gpyrn_amd import _hip
 c=_hip.Context(0)
 rng=np.random.RandomState(0)

@@ -1,7 +1,7 @@
 """grad_ELBO against central differences of the CONVERGED ELBO (many forced sweeps): the envelope-theorem gap."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import gpyrn_amd as gpyrn
 from gpyrn_amd import covfunc, meanfunc
 from tests import _cases

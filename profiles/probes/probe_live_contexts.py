@@ -1,6 +1,6 @@
 """How many live contexts (4 streams each) until the flag schedule's in-kernel waits start timing out?"""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import numpy as np
 from gpyrn_amd import _hip
 

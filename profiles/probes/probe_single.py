@@ -1,6 +1,6 @@
 # latency of ONE 128x128 task (as on the factorisation's chain) per workgroup shape and K
 import sys, os, numpy as np
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..', '..')))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..')))
 from gpyrn_amd import _hip
 c=_hip.Context(0)
 rng=np.random.RandomState(0)

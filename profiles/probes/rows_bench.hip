@@ -1,7 +1,7 @@
 // standalone: 100 MHz timeline of k_tile_rows (the chain's two products), last workgroup, wave 0
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 rows_bench.hip -o rows_bench
 #define ROWS_STAMPS
-#include "../gemm_tile.hip"
+#include "../../gpyrn_amd/csrc/gemm_tile.hip"
 #include <stdio.h>
 #include <vector>
 void prof_begin(gprn_ctx*, int, hipStream_t) {}
