@@ -322,7 +322,6 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
     else if (!strcmp(name, "accurate_factor")) field = &c->acc_opt;
     else if (!strcmp(name, "fenced_finalize")) field = &c->fenced_finalize;
-    else if (!strcmp(name, "bulk_shape")) field = &c->bulk_shape_opt;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else if (!strcmp(name, "batch_chunk")) { if (old) *old = c->last_batch_chunk; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
@@ -449,7 +448,6 @@ extern "C" int gprn_create(gprn_ctx** out, int device_id)
     if (device_id < 0 || device_id >= n) return GPRN_E_ARG;
     if (hipSetDevice(device_id) != hipSuccess) return GPRN_E_HIP;
     gprn_ctx* c = new gprn_ctx();
-    if (const char* e = getenv("GPRN_BULK_SHAPE")) c->bulk_shape_opt = atoi(e);     // (round-6 experiment: bench.py A/B runs)
     c->device = device_id;
     c->shared = device_streams_acquire(device_id);
     if (!c->shared) { delete c; return GPRN_E_HIP; }
@@ -2558,7 +2556,7 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
     double* hp[GPRN_NBUF] = {c->d_test[0], c->d_test[1], c->d_test[2], nullptr};
     HIP_TRY(c, hipMemcpy(d_t, tasks.data(), tasks.size() * sizeof(TileTask), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d_p, hp, sizeof(hp), hipMemcpyHostToDevice));
-    int rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, ((c_mode >> 4) & 7) == 4 ? TS_128x128_W4 : ((c_mode >> 4) & 3));
+    int rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, (c_mode >> 4) & 3);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (!rc && e == hipSuccess)
         e = hipMemcpy(hc.data(), c->d_test[2], nn * sizeof(double), hipMemcpyDeviceToHost);
@@ -2575,7 +2573,7 @@ extern "C" int gprn_test_gemm(gprn_ctx* c, int M, int N, int K, int a_mode, int 
 extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, int reps, double* ms)
 {
     DeviceLock lock_(c);
-    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || reps < 1 || !ms || how < 0 || how > 2)
+    if (!c || M <= 0 || N <= 0 || K <= 0 || M % GPRN_TILE || N % GPRN_TILE || K % GPRN_KC || reps < 1 || !ms || how < 0 || how > 1)
         return bad(c, "test_gemm_rate: bad argument");
     const int ld = std::max(std::max(M, N), K);
     TRY(test_setup(c, ld, 3, 1));
@@ -2606,7 +2604,7 @@ extern "C" int gprn_test_gemm_rate(gprn_ctx* c, int M, int N, int K, int how, in
         float total = 0.f;
         for (int r = 0; r < reps + 1 && !rc; ++r) {
             hipEventRecord(e0, c->stream);
-            rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, how == 0 ? TS_64x64 : (how == 1 ? TS_128x128 : TS_128x128_W4));
+            rc = launch_tiles(c, d_t, tasks.size(), d_p, 1, ld, GPRN_T_UPDATE, nullptr, how == 0 ? TS_64x64 : TS_128x128);
             hipEventRecord(e1, c->stream);
             hipEventSynchronize(e1);
             float tt = 0.f;

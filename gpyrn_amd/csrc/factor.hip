@@ -476,7 +476,6 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
     // (as tile tasks 49 + 31-72 us; N = 512, 32 evaluations 3 960 -> 4 090 /s, N = 497 5 930 -> 6 070; the diagonal blocks of
     // the next step, 4-5 x slower beside the step's updates than alone, are what such a step waits for now)
     const bool wide_chain = nbatch >= GPRN_WIDE_CHAIN;
-    const int bulk_shape = c->bulk_shape_opt == 1 ? TS_128x128_W4 : TS_64x64;      // (option "bulk_shape": round-6 experiment)
 
     // stream3 at the start of step k: raise F_INNER of the step before, then wait for diag(k)
     auto side_sync = [&](int k) -> int {
@@ -581,15 +580,15 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             // 8-wave 128 x 128 form (109.0 vs 105.9 sweeps/s at config 3)
             if (sr) {
                 HIP_TRY(c, await(s2, J, F_PANEL));
-                if ((rc = tiles(o.rest0, o.nrestA, s2, bulk_shape, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
+                if ((rc = tiles(o.rest0, o.nrestA, s2, TS_64x64, GPRN_T_UPDATE_AHEAD, nosig, noaw, TG_AHEAD))) return rc;
                 // F_RESTA: by the first workgroup of the "bulk" launch behind it (gprn_ctx::start_flag_now) when there is one
                 const bool resta_by_bulk = use_flags && o.nrest > o.nrestA;
                 if (resta_by_bulk) { c->start_flag_now = slot(J, F_RESTA) + 1; c->start_value_now = epoch; }
                 else HIP_TRY(c, raise(s2, J, F_RESTA));
-                rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK);
+                rc = tiles(o.rest0 + o.nrestA, o.nrest - o.nrestA, s2, TS_64x64, GPRN_T_UPDATE, nosig, noaw, TG_BULK);
                 c->start_flag_now = nullptr;
                 if (rc) return rc;
-            } else if ((rc = tiles(o.rest0, o.nrest, s2, bulk_shape, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
+            } else if ((rc = tiles(o.rest0, o.nrest, s2, TS_64x64, GPRN_T_UPDATE, nosig, noaw, TG_BULK))) return rc;
             HIP_TRY(c, raise(s2, J, F_REST));
             rest_J = J;
         }

@@ -100,15 +100,13 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     // diagonal-block kernel, the chain's update), so the 64 x 64 quarter above the diagonal is not computed at all and
     // the two quarters on it skip their upper 16 x 16 blocks -- 40 of 64 block products instead of 64 (the exact
     // triangle would be 36).  Round 2 measured 13 % more MFMAs in the bulk launches than the algorithm needs.
-    // (W4: the 4-wave 128 x 128 form -- 64 x 64 accumulators per wave -- has the registers for both, too)
-    constexpr bool W4 = BM == 128 && BN == 128 && NW == 4;
-    constexpr bool CAN_LOWER = ((BM == 64 && BN == 64) || W4) && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
+    constexpr bool CAN_LOWER = BM == 64 && BN == 64 && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
     const bool lower = CAN_LOWER && ((t.modes >> 4) & 1);
     // First touch (modes bit 5, the first outer panel's K = 512 update when the caller hands over s = sqrt(d)): the tile
     // of B = I + D^1/2 K D^1/2 is formed from K on the way in instead of being read -- k_build_B then writes only what the
     // first panel's tile steps touch, a quarter of the matrix (run_phase, api.hip).
     // (64 x 64 workgroups only: the 8-wave 128 x 128 form sits at its 128-register budget and would spill)
-    constexpr bool CAN_FT = ((BM == 64 && BN == 64) || W4) && TRI == 0 && (TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
+    constexpr bool CAN_FT = BM == 64 && BN == 64 && TRI == 0 && (TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
     const double* ft_K = nullptr;
     const double* ft_sv = nullptr;
     int ft_row = 0, ft_col = 0;
@@ -120,7 +118,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     }
     // ... and in the 8-wave 128 x 128 form (launches of thousands of tasks: T = 128) the same tasks take the instantiation
     // whose diagonal 16 x 16 blocks accumulate from zero (tile_mma SYM: the accuracy of the pivots), all blocks computed
-    constexpr bool CAN_SYM128 = BM == 128 && BN == 128 && NW == 8 && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT);
+    constexpr bool CAN_SYM128 = BM == 128 && BN == 128 && TRI == 0 && (TAG == TG_INNER || TAG == TG_NEXT);
     if (lower && sr < sc) { /* nothing of this quarter is ever read */ }
     else if (CAN_LOWER && lower && sr == sc)
         tile_mma<BM, BN, WM, WN, TRI, CAN_LOWER, true>(lds, A, B, C, ld, a_mode, b_mode, c_mode, t.klen,
@@ -380,7 +378,7 @@ size_t lds_limit(int device)
     return lim;
 }
 
-template <int BM, int BN, int TRI, int TAG, int NW_ = 0>
+template <int BM, int BN, int TRI, int TAG>
 static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double* const* tab, int nbatch, int ld,
                        size_t dyn, hipStream_t stream, const Signal& sig, const Await& aw)
 {
@@ -392,7 +390,7 @@ static bool launch_one(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, doub
         return false;
     }
     constexpr int per_task = (GPRN_TILE / BM) * (GPRN_TILE / BN);
-    constexpr int NW = NW_ ? NW_ : ((BM == 128 && BN == 128) ? 8 : 4);       // the throughput shape runs on 8 waves
+    constexpr int NW = (BM == 128 && BN == 128) ? 8 : 4;       // the throughput shape runs on 8 waves
     hipLaunchKernelGGL((k_tile_gemm<BM, BN, NW, TRI, TAG>), dim3((unsigned)ntasks * per_task, (unsigned)nbatch),
                        dim3(64 * NW), dyn, stream, d_tasks, tab, ld, sig.slot, sig.value, sig.then_wait,
                        sig.then_value, aw.flag, aw.value, aw.timed_out ? aw.timed_out : sig.timed_out, GPRN_XCD_CHUNK_LOG2,
@@ -448,10 +446,6 @@ int launch_tiles(gprn_ctx* c, const TileTask* d_tasks, size_t ntasks, double** d
     // ... its look-ahead part (what the next panel's outer update writes again), a launch of its own
     case TS_64x64 * 8 + TG_AHEAD: GO(64, 64, 0, TG_AHEAD); break;
     case TS_128x128 * 8 + TG_AHEAD: GO(128, 128, 0, TG_AHEAD); break;
-    // round-6 experiment: 128 x 128 on four waves (bulk and look-ahead launches, diagnostics)
-    case TS_128x128_W4 * 8 + TG_BULK: fits = launch_one<128, 128, 0, TG_BULK, 4>(c, d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw); break;
-    case TS_128x128_W4 * 8 + TG_AHEAD: fits = launch_one<128, 128, 0, TG_AHEAD, 4>(c, d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw); break;
-    case TS_128x128_W4 * 8 + TG_MISC: fits = launch_one<128, 128, 0, TG_MISC, 4>(c, d_tasks, ntasks, tab, nbatch, ld, dyn, stream, sig, aw); break;
     // X^T X, prediction products, diagnostics
     case TS_128x128 * 8 + TG_MISC: GO(128, 128, 0, TG_MISC); break;
     case TS_64x64 * 8 + TG_MISC: GO(64, 64, 0, TG_MISC); break;

@@ -211,7 +211,6 @@ struct gprn_ctx {
     bool acc_now = false;
     int acc_opt = -1;
     int fenced_finalize = 0;         // gprn_set_option "fenced_finalize" (tests): k_reduce_finalize's release / acquire form
-    int bulk_shape_opt = 0;          // gprn_set_option "bulk_shape": 1 = the K = 512 bulk / look-ahead launches as TS_128x128_W4
     int wait_budget_ms = 2000;       // wall-clock budget of one in-kernel wait (gprn_set_option "wait_budget_ms")
     int withhold_inner = 0;          // test hook: the n-th F_INNER raise of the next call is skipped (0 = none)
     int fallbacks = 0;               // calls that were re-run on the event schedule after a time-out
@@ -296,8 +295,7 @@ int launch_fill_rect(gprn_ctx* c, const KernelSpec& ks, double nugget_val, const
                      int ns, int ns_pad, double* Ks, double* kss);
 // workgroup output shape of a tile launch (csrc/gemm_tile.hip)
 enum { TS_128x128 = 0, TS_64x64 = 1, TS_64x128 = 2, TS_128x64 = 3,
-       TS_64x128_BTRI = 4, TS_128x64_ATRI = 5,     // panel products with the triangular X_kk (gemm_tile.hip TRI)
-       TS_128x128_W4 = 6 };                        // 128 x 128 on FOUR waves, 64 x 64 accumulators per wave (round-6 experiment)
+       TS_64x128_BTRI = 4, TS_128x64_ATRI = 5 };   // panel products with the triangular X_kk (gemm_tile.hip TRI)
 // launch family of a tile launch: a template tag of k_tile_gemm, so that a kernel trace reports every
 // family under its own kernel name (panel products, in-panel K=128 updates, next-panel K=512 updates,
 // bulk K=512 updates, everything else)
