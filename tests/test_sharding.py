@@ -163,6 +163,35 @@ def test_two_ranks_gloo_match_unsharded(tag, tmp_path):
     np.testing.assert_allclose(r0['var'], var, rtol=1e-10, atol=1e-14)
 
 
+def test_eight_ranks_gloo_config5_partition(tmp_path):
+    """BASELINE config 5's stated topology -- 15 latent GPs (q = 3 nodes, p = 4 outputs) over EIGHT ranks -- which no GPU box
+    of the build can host (its process guard admits six processes on the card; tests/test_parity_gpu.py runs the library
+    itself at five and bench.py's shm rehearsal at six, profiles/r06_bench_6ranks_shm_one_gpu.json): the partition that the
+    library executes (sharding.owners / local_gps / helper_inverses are what csrc/api.hip is fed) with eight gloo processes and
+    the oracle's per-GP arithmetic, at the size the reference itself was run (cfg5shape_N1024).  Five ranks own no node,
+    seven ranks own two latent GPs and one a single weight, only ranks 0 and 1 refactor a later node's K_j (quirk Q1); every rank must end
+    with the reference's two sweeps."""
+    import torch.multiprocessing as mp
+    tag, world = 'cfg5shape_N1024', 8
+    meta, d = _cases.load(tag)
+    p, q = meta['p'], meta['q']
+    assert (p, q) == (4, 3)
+    parts = [sharding.local_gps(p, q, world, r) for r in range(world)]
+    assert [len(n) for n, _ in parts] == [1, 1, 1, 0, 0, 0, 0, 0]
+    assert [len(n) + len(w) for n, w in parts] == [2, 2, 2, 2, 2, 2, 2, 1]
+    assert [bool(sharding.helper_inverses(p, q, world, r)) for r in range(world)] == [True, True] + [False] * 6
+    os.environ['OMP_NUM_THREADS'] = os.environ['OPENBLAS_NUM_THREADS'] = '1'     # (eight processes on the container's eight cores)
+    try:
+        mp.spawn(_worker, args=(world, _free_port(), tag, str(tmp_path)), nprocs=world, join=True)
+    finally:
+        os.environ.pop('OMP_NUM_THREADS', None); os.environ.pop('OPENBLAS_NUM_THREADS', None)
+    res = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+    for r in res[1:]:
+        assert np.array_equal(res[0]['elbo'], r['elbo']) and np.array_equal(res[0]['mu'], r['mu'])
+    np.testing.assert_allclose(res[0]['elbo'], d['elbo_sweeps'][:2], rtol=1e-8)
+    _cases.assert_state('eight gloo ranks, ' + tag, res[0]['mu'], d['mu_final'], res[0]['var'], d['var_final'])
+
+
 def test_eval_pool_map_logic_without_a_gpu(monkeypatch):
     """EvalPool.map: rank r evaluates items r::world, a sum over ranks with zeros elsewhere
     rebuilds the full list (scalars, tuples, -inf, nan).  The library context is replaced by a
