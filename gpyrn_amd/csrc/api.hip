@@ -322,13 +322,12 @@ extern "C" int gprn_set_option(gprn_ctx* c, const char* name, int value, int* ol
     else if (!strcmp(name, "comm_budget_s")) field = &c->comm_budget_s;
     else if (!strcmp(name, "accurate_factor")) field = &c->acc_opt;
     else if (!strcmp(name, "fenced_finalize")) field = &c->fenced_finalize;
-    else if (!strcmp(name, "batch_resident")) field = &c->batch_resident;
     else if (!strcmp(name, "fallbacks")) { if (old) *old = c->fallbacks; return GPRN_OK; }
     else if (!strcmp(name, "batch_chunk")) { if (old) *old = c->last_batch_chunk; return GPRN_OK; }
     else return bad(c, "set_option: unknown option");
     if (old) *old = *field;
     const bool is_pad = field == &c->pad_kb_opt || field == &c->pad_small_kb_opt;
-    if ((is_pad || field == &c->acc_opt || field == &c->batch_resident) && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
+    if ((is_pad || field == &c->acc_opt) && value == -2) { *field = -1; return GPRN_OK; }      // -2: back to the environment / default
     if (value >= 0) {
         if (field == &c->use_flags && value) {
             int can = 0;
@@ -1852,14 +1851,7 @@ extern "C" int gprn_elbocalc_batch(gprn_ctx* c, int n_eval, const double* kernel
     if (c->owner.empty()) return bad(c, "elbocalc_batch: call set_owners first");
     if (comm_active(c) || c->world != 1) { c->err = "elbocalc_batch: one rank only (a pool of ranks splits the list itself)"; return GPRN_E_UNSUPPORTED; }
     TRY(build_tables(c));
-    // Above one tile (up to four) the resident form -- one workgroup per matrix walks its own tile steps, one launch per
-    // half-sweep for ALL evaluations (smalln.hip) -- against the launch schedule with batch = evaluations x latent GPs
-    // (midn.hip): a workgroup needs ~0.7 ms for a 512^2 matrix whatever else runs, the lock-step schedule spreads a phase's
-    // tiles over the device but pays its chain per tile step; the resident form wins once a phase holds about as many
-    // matrices as the device has CUs (profiles/r06_batch_resident.txt).  Option "batch_resident": 1 / 0 force it on / off.
-    bool small = c->T == 1 && small_applies(c);
-    if (c->T > 1 && small_batch_applies(c) && c->batch_resident != 0)
-        small = c->batch_resident > 0 || (size_t)n_eval * (size_t)(c->G - c->q) >= GPRN_RESIDENT_MIN;
+    const bool small = c->T == 1 && small_applies(c);
     const size_t d = (size_t)(c->p + 1) * c->q * c->N, pn = (size_t)c->p * c->N;
     int chunk = small ? small_batch_chunk(c) : n_eval;             // (midn.hip sizes its own chunks: it knows what a matrix costs)
     if (small) c->last_batch_chunk = std::min(chunk, n_eval);

@@ -21,7 +21,6 @@
 #ifndef GPRN_WIDE_CHAIN
 #define GPRN_WIDE_CHAIN 48     // matrices in lock-step from which the chain's two products per tile step run on the tile kernel
 #endif
-#define GPRN_RESIDENT_MIN 256   // weight-phase matrices of a batch (evaluations x q p) from which problems of 2-4 tiles run as resident workgroups
 #define GPRN_XCD_CHUNK_LOG2 4  // consecutive task-list entries that meet in one XCD's L2 (k_tile_gemm): 16
 
 // The hand-over of k_reduce_finalize (vecops.hip) without fences relies on what gfx942 / gfx950 do with agent-scope
@@ -271,7 +270,6 @@ struct gprn_ctx {
     // chunk of evaluations; its kernels find an evaluation's arrays through `ev`
     EvalMap ev = {nullptr, 0, 0, 0, 0};
     void* mid_batch = nullptr;       // MidBatch (midn.hip): the worker context and its slabs, owned by the PARENT context
-    int batch_resident = -1;         // gprn_set_option "batch_resident": above one tile, a batch's evaluations as resident workgroups (smalln.hip) -- 1 always, 0 never, -1: when a phase holds enough matrices (gprn_elbocalc_batch)
     int batch_mem_mb = -1;           // gprn_set_option "batch_mem_mb": device memory one chunk of evaluations may take; -1: a share of what is free
     int last_batch_chunk = 0;        // read-only option "batch_chunk": evaluations per chunk in the last gprn_elbocalc_batch call
 };
@@ -419,7 +417,6 @@ int factor_check_waits(gprn_ctx* c);   // GPRN_E_WAIT_TIMEOUT if an in-kernel de
 int factor_use_flags(gprn_ctx* c);
 // smalln.hip
 bool small_applies(const gprn_ctx* c);
-bool small_batch_applies(const gprn_ctx* c);   // the resident form of gprn_elbocalc_batch: up to four tiles
 // one half-sweep against c->d_ptrs / slot0: reads the state (mu_in, var_in), writes this phase's rows of (mu_out, var_out);
 // the weight phase takes the node rows from the new state.  done: device word that makes the launch a no-op when set, or null
 int small_phase(gprn_ctx* c, bool weights, const int* d_slot_gp, int nslots, const double* mu_in, const double* var_in,

@@ -28,7 +28,7 @@
 #include <chrono>
 #include <vector>
 
-#define SMALL_MAXLD 512              // four tiles: the resident form of a batch (option "small_path" >= T)
+#define SMALL_MAXLD 256
 // LDS: the diagonal-block kernel's buffers and the tile contraction's stages are used in turn
 #define SMALL_MMA_DOUBLES (2 * 16 * (128 + 128 + 32))
 #define SMALL_LDS_DOUBLES (SMALL_MMA_DOUBLES > DIAG_LDS_DOUBLES ? SMALL_MMA_DOUBLES : DIAG_LDS_DOUBLES)
@@ -113,81 +113,36 @@ __device__ __forceinline__ void small_lower_matvec(const double* M, int ld, int 
     }
 }
 
-// The stages of the multi-tile forms as functions of their own (not inlined: the diagonal-block code holds a tile in ~270
-// registers, the tile contraction 16 accumulators per lane in ~240 -- inlined side by side into one kernel body the
-// allocator ran out of the 512 a lane has and spilled into the contraction's inner loop).
-template <int TRI, bool SYM>
-__device__ __forceinline__ void sm_tile(double* lds, const double* A, const double* B, double* C, int ld, int a_mode, int b_mode, int c_mode, int klen)
-{
-    tile_mma<128, 128, 2, 2, TRI, false, false, SYM>(lds, A, B, (gptr_t)C, ld, a_mode, b_mode, c_mode, klen, 0, 0);
-}
-template <bool ACC>
-__device__ __noinline__ void sm_diag(double* lds, double* Bt, double* Xt, int ld, int* info, int slot, int pivot0, int nph)
-{
-    diag_tile<ACC>(lds, (gptr_t)Bt, (gptr_t)Xt, ld, info, slot, pivot0, nph);
-}
-__device__ __forceinline__ void sm_trsm_tile(double* lds, double* rows, const double* Lkk, const double* Xkk, int ld)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int rb = wave; rb < NSB; rb += 4)
-        trsm_rows16(lds + wave * TRSM_SCRATCH, (gptr_t)rows + (size_t)(16 * rb) * ld, (gcptr_t)Lkk, (gcptr_t)Xkk, ld);
-}
-
-// B = L L^T, X = L^-1 for a matrix of T tiles per edge by ONE workgroup; tiles at Bm / Xm (leading dimension ld): the
-// right-looking schedule of factor.hip step by step -- diagonal block, panel (L_ik = B_ik X_kk^T in place, X_kc = X_kk R_kc
-// in place), updates (B_ij -= L_ik L_jk^T, R_ic -= L_ik X_kc with first touch at c == k) -- every product a 128 x 128 tile
-// contraction on the workgroup's four waves (64 x 64 accumulators each), operands from L2.  Products of one stage are
-// independent of each other (a barrier between them: they share the LDS image); the stages are separated by sm_publish.
-// N: rows that hold data -- the 16-column phases of the last diagonal tile beyond them are identity padding and are not run
+// B = L L^T, X = L^-1 for T in {1, 2} tiles by one workgroup; tiles at Bm / Xm (leading dimension ld)
+// N: rows that hold data -- the 16-column phases of a diagonal tile beyond them are identity padding and are not run
 // (diag_tile's nph: at the reference's own N = 25 and 45 two and three of eight phases hold everything)
 // ACC: a prior matrix -- panel steps by substitution (diag_tile.h)
 template <int T, bool ACC = false>
 __device__ __forceinline__ void small_factor(double* lds, double* Bm, double* Xm, int ld, int* info, int slot, int N)
 {
-    auto at = [&](int ti, int tj) { return (size_t)ti * GPRN_TILE * ld + (size_t)tj * GPRN_TILE; };
-#pragma unroll 1
-    for (int k = 0; k < T; ++k) {
-        const int rows_here = N - k * GPRN_TILE < GPRN_TILE ? N - k * GPRN_TILE : GPRN_TILE;
-        if constexpr (T == 1) {
-            diag_tile<ACC>(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0, (rows_here + 15) / 16);
-            return;
-        }
-        sm_diag<ACC>(lds, Bm + at(k, k), Xm + at(k, k), ld, info, slot, k * GPRN_TILE, k == T - 1 ? (rows_here + 15) / 16 : NSB);
-        sm_publish();
-        // ---- panel
-#pragma unroll 1
-        for (int i = k + 1; i < T; ++i) {             // L_ik = B_ik X_kk^T (in place: the tile is written when all of it has been read)
-            // (a prior matrix: by substitution against L_kk, 16 rows at a time per wave -- diag_tile.h trsm_rows16)
-            if constexpr (ACC) sm_trsm_tile(lds, Bm + at(i, k), Bm + at(k, k), Xm + at(k, k), ld);
-            else sm_tile<1, false>(lds, Bm + at(i, k), Xm + at(k, k), Bm + at(i, k), ld, 0, 0, CM_SET, GPRN_TILE);
-            __syncthreads();
-        }
-#pragma unroll 1
-        for (int cc = 0; cc < k; ++cc) {              // X_kc = X_kk R_kc (in place)
-            sm_tile<2, false>(lds, Xm + at(k, k), Xm + at(k, cc), Xm + at(k, cc), ld, 0, 1, CM_SET, GPRN_TILE);
-            __syncthreads();
-        }
-        if (k == T - 1) break;
-        sm_publish();
-        // ---- updates
-#pragma unroll 1
-        for (int j = k + 1; j < T; ++j)
-#pragma unroll 1
-            for (int i = j; i < T; ++i) {             // B_ij -= L_ik L_jk^T
-                // (SYM on the diagonal tiles: their diagonal 16 x 16 blocks accumulate from zero -- the pivots' accuracy, tile_mma.h)
-                if (i == j) sm_tile<0, true>(lds, Bm + at(i, k), Bm + at(j, k), Bm + at(i, j), ld, 0, 0, CM_SUB, GPRN_TILE);
-                else sm_tile<0, false>(lds, Bm + at(i, k), Bm + at(j, k), Bm + at(i, j), ld, 0, 0, CM_SUB, GPRN_TILE);
-                __syncthreads();
-            }
-#pragma unroll 1
-        for (int i = k + 1; i < T; ++i)
-#pragma unroll 1
-            for (int cc = 0; cc <= k; ++cc) {         // R_ic -= L_ik X_kc;  R_ik = -L_ik X_kk (first touch of the inverse's tile)
-                sm_tile<0, false>(lds, Bm + at(i, k), Xm + at(k, cc), Xm + at(i, cc), ld, 0, 1, cc == k ? CM_SETNEG : CM_SUB, GPRN_TILE);
-                __syncthreads();
-            }
-        sm_publish();
-    }
+    diag_tile<ACC>(lds, (gptr_t)Bm, (gptr_t)Xm, ld, info, slot, 0, T == 1 ? (N + 15) / 16 : NSB);
+    if (T == 1) return;
+    sm_publish();
+    const size_t t10 = (size_t)GPRN_TILE * ld, t11 = t10 + GPRN_TILE;
+    // L_10 = B_10 X_00^T (in place: the tile is written when all of it has been read)
+    if constexpr (ACC) {
+        // (a prior matrix: by substitution against L_00, 16 rows at a time per wave -- diag_tile.h trsm_rows16)
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (int rb = wave; rb < NSB; rb += 4)
+            trsm_rows16(lds + wave * TRSM_SCRATCH, (gptr_t)(Bm + t10) + (size_t)(16 * rb) * ld, (gcptr_t)Bm, (gcptr_t)Xm, ld);
+    } else
+    tile_mma<128, 128, 2, 2, 1>(lds, Bm + t10, Xm, (gptr_t)(Bm + t10), ld, 0, 0, CM_SET, GPRN_TILE, 0, 0);
+    sm_publish();
+    // B_11 -= L_10 L_10^T;  R_10 = -L_10 X_00 (first touch of the inverse's row)
+    // (SYM: the diagonal 16 x 16 blocks accumulate from zero -- the pivots' accuracy, tile_mma.h)
+    tile_mma<128, 128, 2, 2, 0, false, false, true>(lds, Bm + t10, Bm + t10, (gptr_t)(Bm + t11), ld, 0, 0, CM_SUB, GPRN_TILE, 0, 0);
+    __syncthreads();
+    tile_mma<128, 128, 2, 2, 0>(lds, Bm + t10, Xm, (gptr_t)(Xm + t10), ld, 0, 1, CM_SETNEG, GPRN_TILE, 0, 0);
+    sm_publish();
+    diag_tile<ACC>(lds, (gptr_t)(Bm + t11), (gptr_t)(Xm + t11), ld, info, slot, GPRN_TILE, (N - GPRN_TILE + 15) / 16);
+    sm_publish();
+    // X_10 = X_11 R_10 (in place)
+    tile_mma<128, 128, 2, 2, 2>(lds, Xm + t11, Xm + t10, (gptr_t)(Xm + t10), ld, 0, 1, CM_SET, GPRN_TILE, 0, 0);
 }
 
 // the entries of B = I + D^1/2 K D^1/2 formed from K and s = sqrt(d) (LDS) on their way into the diagonal-block kernel's
@@ -230,8 +185,7 @@ __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
     // (one tile: the diagonal-block kernel's 46.6 KB only -- with the vectors 59 KB, two workgroups per CU when many
     // evaluations run side by side)
     __shared__ __attribute__((aligned(16))) double lds[T == 1 ? DIAG_LDS_DOUBLES : SMALL_LDS_DOUBLES];
-    constexpr int VL = T * GPRN_TILE;                // (T <= SMALL_MAXLD / 128)
-    __shared__ double sS[VL], sZ[VL], sD[VL], sU[VL], sCS[VL], sCT[VL];
+    __shared__ double sS[SMALL_MAXLD], sZ[SMALL_MAXLD], sD[SMALL_MAXLD], sU[SMALL_MAXLD];
     __shared__ double shs[4][64], sht[4][64], sh4[4];
     if (a.done && *a.done) return;                   // (uniform)
     const int slot = blockIdx.x, gp = a.slot_gp[slot];
@@ -316,7 +270,7 @@ __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
     SM_STAMP(5);
     // ---- column sums over the rows of X: cs = sum x^2 (= diag B^-1), ct = sum x u (= X^T X z); per tile row the four
     // row classes in k_colops_partial's order, the tile rows added up in k_colops_reduce's
-    // (the column sums land in sD / sZ's neighbours sCS / sCT: one thread does not own one column beyond 256)
+    double my_cs = 0.0, my_ct = 0.0;                 // of column `tid` (threads < ld)
     for (int c0 = 0; c0 < ld; c0 += 64) {
         const int cl = tid & 63, rl = tid >> 6;
         double acc_s = 0.0, acc_t = 0.0;             // running sums over the tile rows (thread rl == 0 holds them)
@@ -343,24 +297,26 @@ __device__ __forceinline__ void small_phase_body(const SmallPhaseArgs& a)
                 acc_t += (sht[0][cl] + sht[1][cl]) + (sht[2][cl] + sht[3][cl]);
             }
         }
-        if (rl == 0) { sCS[c0 + cl] = acc_s; sCT[c0 + cl] = acc_t; }
+        __syncthreads();
+        if (rl == 0) { shs[0][cl] = acc_s; sht[0][cl] = acc_t; }
+        __syncthreads();
+        if (tid >= c0 && tid < c0 + 64) { my_cs = shs[0][tid - c0]; my_ct = sht[0][tid - c0]; }
+        __syncthreads();
     }
-    __syncthreads();
     SM_STAMP(6);
-    // ---- the new state of this latent GP, tr B^-1 and log det B (k_reduce_finalize: thread t owns elements t, t + 256, ...)
+    // ---- the new state of this latent GP, tr B^-1 and log det B (k_reduce_finalize: thread t owns element t)
     size_t row;
     if (gp < q) row = gp;
     else { const int kk = gp - q, j = kk / p, i = kk % p; row = (size_t)(1 + i) * q + j; }
     double tr = 0.0, ld_acc = 0.0;
-    for (int n = tid; n < ld; n += 256) {
-        const double my_cs = sCS[n], my_ct = sCT[n];
-        a.cs[vo + n] = my_cs;
-        a.ct[vo + n] = my_ct;
-        if (n < N) {
-            a.mu_out[row * N + n] = (sZ[n] - my_ct) / sS[n];
-            a.var_out[row * N + n] = (1.0 - my_cs) / sD[n];
-            tr += my_cs;
-            ld_acc += log(Bm[(size_t)n * ld + n]);
+    if (tid < ld) {
+        a.cs[vo + tid] = my_cs;
+        a.ct[vo + tid] = my_ct;
+        if (tid < N) {
+            a.mu_out[row * N + tid] = (sZ[tid] - my_ct) / sS[tid];
+            a.var_out[row * N + tid] = (1.0 - my_cs) / sD[tid];
+            tr = my_cs;
+            ld_acc = log(Bm[(size_t)tid * ld + tid]);
         }
     }
     tr = sm_block_sum(tr, sh4);
@@ -394,37 +350,33 @@ struct SmallTailArgs {
     int n_info;
 };
 
-// log-likelihood terms of k_loglike_partial + k_elbo_final's sum over its blocks: block b of that kernel holds the elements
-// b * 256 + t (N <= 8192: one per thread), its three block sums are added up in block order starting from zero (the empty
-// blocks contribute exact zeros).  Result valid in thread 0.
+// log-likelihood terms of k_loglike_partial for block 0 (with N <= 256 the other 31 blocks of that kernel are empty
+// and contribute exact zeros); result valid in thread 0
 __device__ __forceinline__ void small_loglike(const SmallTailArgs& a, double* sh4, double& t1, double& t2, double& t3)
 {
     const double TWO_PI = 6.283185307179586;
     t1 = t2 = t3 = 0.0;
-    for (int n0 = 0; n0 < a.N || n0 == 0; n0 += 256) {
-        const int n = n0 + threadIdx.x;
-        double u1 = 0.0, u2 = 0.0, u3 = 0.0;
-        if (n < a.N) {
-            for (int i = 0; i < a.p; ++i) {
-                const double vi = a.variance[(size_t)i * a.N + n];
-                const size_t wrow = (size_t)(1 + i) * a.q;
-                u1 += log(TWO_PI * vi);
-                double fit = 0.0, cross = 0.0;
-                for (int j = 0; j < a.q; ++j) {
-                    const double mf = a.mu[(size_t)j * a.N + n], vf = a.var[(size_t)j * a.N + n];
-                    const double mw = a.mu[(wrow + j) * a.N + n], vw = a.var[(wrow + j) * a.N + n];
-                    fit += mw * mf;
-                    cross += vf * (mw * mw) + vw * (mf * mf) + vf * vw;
-                }
-                const double resid = a.yraw[(size_t)i * a.N + n] - fit;
-                u2 += resid * resid / vi;
-                u3 += cross / vi;
+    const int n = threadIdx.x;
+    if (n < a.N) {
+        for (int i = 0; i < a.p; ++i) {
+            const double vi = a.variance[(size_t)i * a.N + n];
+            const size_t wrow = (size_t)(1 + i) * a.q;
+            t1 += log(TWO_PI * vi);
+            double fit = 0.0, cross = 0.0;
+            for (int j = 0; j < a.q; ++j) {
+                const double mf = a.mu[(size_t)j * a.N + n], vf = a.var[(size_t)j * a.N + n];
+                const double mw = a.mu[(wrow + j) * a.N + n], vw = a.var[(wrow + j) * a.N + n];
+                fit += mw * mf;
+                cross += vf * (mw * mw) + vw * (mf * mf) + vf * vw;
             }
+            const double resid = a.yraw[(size_t)i * a.N + n] - fit;
+            t2 += resid * resid / vi;
+            t3 += cross / vi;
         }
-        t1 += sm_block_sum(u1, sh4);
-        t2 += sm_block_sum(u2, sh4);
-        t3 += sm_block_sum(u3, sh4);
     }
+    t1 = sm_block_sum(t1, sh4);
+    t2 = sm_block_sum(t2, sh4);
+    t3 = sm_block_sum(t3, sh4);
 }
 
 template <int T>
@@ -462,7 +414,7 @@ __device__ __forceinline__ void small_tail_body(const SmallTailArgs& a)
             for (int tb = 0; tb <= ta; ++tb) {
                 const size_t oa = (size_t)ta * GPRN_TILE * ld + (size_t)ta * GPRN_TILE, ob = (size_t)ta * GPRN_TILE * ld + (size_t)tb * GPRN_TILE;
                 __syncthreads();
-                sm_tile<0, false>(lds, Xm + oa, Xm + ob, Bm + ob, ld, 1, 1, CM_SET, ld - ta * GPRN_TILE);
+                tile_mma<128, 128, 2, 2, 0>(lds, Xm + oa, Xm + ob, (gptr_t)(Bm + ob), ld, 1, 1, CM_SET, ld - ta * GPRN_TILE, 0, 0);
             }
         sm_publish();
         const double* sv = a.s_node + (size_t)slot * ld;
@@ -594,7 +546,7 @@ __device__ __forceinline__ void small_prior_body(const SmallPriorArgs& a)
             for (int tb = 0; tb <= ta; ++tb) {
                 const size_t oa = (size_t)ta * GPRN_TILE * ld + (size_t)ta * GPRN_TILE, ob = (size_t)ta * GPRN_TILE * ld + (size_t)tb * GPRN_TILE;
                 __syncthreads();
-                sm_tile<0, false>(lds, Xm + oa, Xm + ob, Ki + ob, ld, 1, 1, CM_SET, ld - ta * GPRN_TILE);
+                tile_mma<128, 128, 2, 2, 0>(lds, Xm + oa, Xm + ob, (gptr_t)(Ki + ob), ld, 1, 1, CM_SET, ld - ta * GPRN_TILE, 0, 0);
             }
     }
 }
@@ -605,9 +557,9 @@ template <bool WEIGHTS, int T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_small_phase(SmallPhaseArgs a) { small_phase_body<WEIGHTS, T>(a); }
 // (one tile, many evaluations: up to two workgroups per CU -- 222 registers per lane fit twice)
-template <bool WEIGHTS, int T>
+template <bool WEIGHTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
-void k_small_phase_b(const SmallPhaseArgs* __restrict__ lanes) { small_phase_body<WEIGHTS, T>(lanes[blockIdx.y]); }
+void k_small_phase_b(const SmallPhaseArgs* __restrict__ lanes) { small_phase_body<WEIGHTS, 1>(lanes[blockIdx.y]); }
 
 template <int T>
 __global__ __launch_bounds__(256)
@@ -632,13 +584,6 @@ void k_small_prior_b(const SmallPriorArgs* __restrict__ lanes) { small_prior_bod
 // One tile (N <= 128) by default.  Two tiles work too (option "small_path" = 2; same tests) but do not pay: the four
 // 128^3 products of the 2 x 2 blocked form on ONE workgroup's four waves make a half-sweep 170 us, where the launch
 // schedule spreads them over the device (N = 200, p = q = 1: 2.14 ms per nELBO evaluation against 1.88).
-// ... and the batch of evaluations (gprn_elbocalc_batch): up to four tiles -- whether it pays above one tile depends on how
-// many matrices a phase holds (gprn_elbocalc_batch decides, api.hip)
-bool small_batch_applies(const gprn_ctx* c)
-{
-    return c->small_opt != 0 && c->T >= 1 && c->T <= SMALL_MAXLD / GPRN_TILE && !c->comm && !c->shm && !c->keep_sigma && c->world == 1;
-}
-
 bool small_applies(const gprn_ctx* c)
 {
     const int max_T = c->small_opt == 2 ? 2 : 1;
@@ -871,7 +816,7 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
                          const double* mu, const double* var, int max_iter, double* elbo, int* iters, int* conv, int* info,
                          double* mu_out, double* var_out)
 {
-    if (!small_batch_applies(c)) { c->err = "elbocalc_batch: the resident form takes problems of up to four tiles on one rank"; return GPRN_E_UNSUPPORTED; }
+    if (c->T != 1 || !small_applies(c)) { c->err = "elbocalc_batch: one-tile problems on one rank only"; return GPRN_E_UNSUPPORTED; }
     const int G = c->G, p = c->p, N = c->N, B = n_eval;
     int kp_total = 0;
     for (int g = 0; g < G; ++g) {
@@ -925,12 +870,8 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
     // ---- set-up: every evaluation's G covariance matrices in one launch, their factors in another
     SB_TRY(launch_fill_batch(c, m->programs, (double* const*)m->kptr_dense, B * G));
     prof_begin(c, GPRN_T_DIAG);
-    // (T tiles per matrix edge: one instantiation each; prior matrices factor with substitution panels unless "accurate_factor" = 0)
-#define SB_BY_T(GO) do { switch (c->T) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); } } while (0)
-#define GO_PR(TT) do { if (c->acc_opt != 0) hipLaunchKernelGGL((k_small_prior_b<TT, true>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args); \
-                      else hipLaunchKernelGGL((k_small_prior_b<TT, false>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args); } while (0)
-    SB_BY_T(GO_PR);
-#undef GO_PR
+    if (c->acc_opt != 0) hipLaunchKernelGGL((k_small_prior_b<1, true>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
+    else hipLaunchKernelGGL((k_small_prior_b<1, false>), dim3(G, B), dim3(256), 0, st, (const SmallPriorArgs*)m->prior_args);
     prof_end(c);
     HIP_TRY(c, hipGetLastError());
     // ---- the loop, SB_K sweeps per synchronisation
@@ -953,16 +894,11 @@ int small_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_k
         for (; nb < nb_max && s <= max_iter; ++nb, ++s) {
             const int par = (s <= 1 || (s & 1)) ? 0 : 1;          // sweep 0 and trip 1 start from copy A, then they alternate
             prof_begin(c, GPRN_T_DIAG);
-#define GO_PH(TT) do { \
-            hipLaunchKernelGGL((k_small_phase_b<false, TT>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap)); \
-            hipLaunchKernelGGL((k_small_phase_b<true, TT>), dim3(G - q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 1) * cap)); } while (0)
-            SB_BY_T(GO_PH);
-#undef GO_PH
+            hipLaunchKernelGGL((k_small_phase_b<false>), dim3(q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 0) * cap));
+            hipLaunchKernelGGL((k_small_phase_b<true>), dim3(G - q, B), dim3(256), 0, st, (const SmallPhaseArgs*)(m->phase_args + ((size_t)par * 2 + 1) * cap));
             prof_end(c);
             prof_begin(c, GPRN_T_VEC);
-#define GO_TL(TT) hipLaunchKernelGGL(k_small_tail_b<TT>, dim3(G, B), dim3(256), 0, st, (const SmallTailArgs*)(m->tail_args + (size_t)par * cap), s, nb, max_iter)
-            SB_BY_T(GO_TL);
-#undef GO_TL
+            hipLaunchKernelGGL(k_small_tail_b<1>, dim3(G, B), dim3(256), 0, st, (const SmallTailArgs*)(m->tail_args + (size_t)par * cap), s, nb, max_iter);
             prof_end(c);
         }
         HIP_TRY(c, hipGetLastError());

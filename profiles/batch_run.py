@@ -1,5 +1,4 @@
-"""Side-by-side evaluations for a profiler: `python profiles/batch_run.py N p q B [calls [resident]]` (resident: the
-library's option "batch_resident": 1 / 0 force the resident-workgroup form of a batch above one tile on / off) runs inference.nELBO_batch on the
+"""Side-by-side evaluations for a profiler: `python profiles/batch_run.py N p q B [calls]` runs inference.nELBO_batch on the
 synthetic problem of bench.py --latency (perturbed hyper-parameters, warm start) `calls` times after one warm-up call and
 prints evaluations/s of the best call.  Used under rocprofv3 --kernel-trace --stats (profiles/r05_batch_*)."""
 import contextlib
@@ -15,7 +14,6 @@ from gpyrn_amd import covfunc, meanfunc, synth               # noqa: E402
 
 N, p, q, B = (int(v) for v in sys.argv[1:5])
 calls = int(sys.argv[5]) if len(sys.argv) > 5 else 3
-resident = int(sys.argv[6]) if len(sys.argv) > 6 else None
 kind = 'SE' if (p, q) == (1, 1) and N <= 200 else 'QP'
 t, ys, es = synth.rv_series(N, p)
 spec = synth.component_spec(p, q, kind)
@@ -27,8 +25,6 @@ rng = np.random.RandomState(1)
 xb = [x0 * (1.0 + 0.01 * rng.standard_normal(x0.size)) for _ in range(B)]
 best = None
 ctx = g._backend()
-if resident is not None:
-    ctx.option('batch_resident', resident)
 lib_s = []
 inner = ctx.elbocalc_batch
 
@@ -51,5 +47,5 @@ with contextlib.redirect_stdout(io.StringIO()):
         if best is None or dt < best:
             best, best_lib = dt, lib_s[-1]
 print('python side of the best call: %.0f us around %.0f us in gprn_elbocalc_batch' % (1e6 * (best - best_lib), 1e6 * best_lib))
-print('N=%d p=%d q=%d B=%d%s: %.3f ms per call, %.0f evaluations/s; flags %d fallbacks %d' % (
-    N, p, q, B, '' if resident is None else ' resident=%d' % resident, 1e3 * best, B / best, ctx.option('flags'), ctx.option('fallbacks')))
+print('N=%d p=%d q=%d B=%d: %.3f ms per call, %.0f evaluations/s; flags %d fallbacks %d' % (
+    N, p, q, B, 1e3 * best, B / best, ctx.option('flags'), ctx.option('fallbacks')))

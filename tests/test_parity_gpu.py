@@ -525,14 +525,8 @@ def _batch_inputs(g, sets):
 
 @pytest.mark.parametrize('tag,B', [('mid_N300_p3q2', 7), ('mid_N512_p3q2', 32), ('cfg1_N200', 5), ('mid_N1024_p1q1', 6),
                                    ('illc_N300_p2q3', 4), ('kmix_N200_p2q2', 6)])
-@pytest.mark.parametrize('resident', [0, 1])
-def test_every_slot_of_a_batch_above_one_tile_reproduces_the_reference(tag, B, resident):
-    """resident = 0: the launch schedule with batch = evaluations x latent GPs (csrc/midn.hip); 1: problems of up to four
-    tiles as resident workgroups -- one per matrix, one launch per half-sweep for all evaluations (csrc/smalln.hip, round 6;
-    the library picks it by itself once a phase holds about as many matrices as the device has CUs)."""
-    if resident and _cases.load(tag)[0]['N'] > 512:
-        pytest.skip('the resident form takes up to four tiles')
-    _every_slot_reproduces_the_reference(tag, B, resident)
+def test_every_slot_of_a_batch_above_one_tile_reproduces_the_reference(tag, B):
+    _every_slot_reproduces_the_reference(tag, B)
 
 
 @pytest.mark.parametrize('tag,B', [('step_p3q2', 9), ('step_p2q3', 5), ('illc_N100_p2q3', 6)])
@@ -542,7 +536,7 @@ def test_every_slot_of_a_one_tile_batch_reproduces_the_reference(tag, B):
     _every_slot_reproduces_the_reference(tag, B)
 
 
-def _every_slot_reproduces_the_reference(tag, B, resident=None):
+def _every_slot_reproduces_the_reference(tag, B):
     """gprn_elbocalc_batch above one tile (csrc/midn.hip): B evaluations go through the launch schedule with its batch
     dimension = evaluations x latent GPs.  Every slot of a batch run AT THE FIXTURE'S PARAMETERS must reproduce what the
     reference itself printed for them: the forced sweeps (max_iter = their number: the loop's trip i is forced sweep i - 1,
@@ -551,8 +545,6 @@ def _every_slot_reproduces_the_reference(tag, B, resident=None):
     meta, d, g = _model(tag)
     x = np.array(g.get_parameters(), dtype=float)
     ctx, kp, yr, jt, m0, v0 = _batch_inputs(g, [x] * B)
-    if resident is not None:
-        ctx.option('batch_resident', resident)
     assert np.array_equal(m0[0], np.ravel(d['mu_init']))
     k = int(meta['nsweeps'])                                   # (no fixture's loop stops before its forced sweeps end)
     res = ctx.elbocalc_batch(kp, yr, jt, m0, v0, k, want_state=True)
@@ -584,13 +576,9 @@ def _every_slot_reproduces_the_reference(tag, B, resident=None):
     _assert_default_schedule(ctx)
 
 
-@pytest.mark.parametrize('n,p,q,kind,B,budget_mb,resident', [
-    (200, 1, 1, 'SE', 6, 0, 0), (300, 3, 2, 'QP', 9, 0, 0), (512, 3, 2, 'QP', 32, 0, 0), (260, 2, 3, 'QP', 5, 0, 0),
-    (300, 2, 2, 'QP', 11, 80, 0), (1024, 1, 1, 'QP', 4, 0, 0),
-    # ... and as resident workgroups (up to four tiles): two, three, four tiles, q = 3 (Q1 traces), chunks, the automatic choice
-    (200, 1, 1, 'SE', 6, 0, 1), (300, 3, 2, 'QP', 9, 0, 1), (512, 3, 2, 'QP', 32, 0, 1), (260, 2, 3, 'QP', 5, 0, 1),
-    (300, 2, 2, 'QP', 20, 250, 1), (497, 4, 1, 'QP', 70, 0, -2)])
-def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb, resident, capsys):
+@pytest.mark.parametrize('n,p,q,kind,B,budget_mb', [(200, 1, 1, 'SE', 6, 0), (300, 3, 2, 'QP', 9, 0), (512, 3, 2, 'QP', 32, 0),
+                                                    (260, 2, 3, 'QP', 5, 0), (300, 2, 2, 'QP', 11, 80), (1024, 1, 1, 'QP', 4, 0)])
+def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb, capsys):
     """inference.nELBO_batch above one tile: B PERTURBED parameter vectors side by side against the same evaluations one by
     one from the same starting state, cold (each from its own _initMuVar state) and warm (all from one converged state) --
     values to 1e-9 and, through them, trip counts; evaluations that stop at different trips leave the launches one by one
@@ -607,7 +595,6 @@ def test_nelbo_batch_side_by_side_above_one_tile(n, p, q, kind, B, budget_mb, re
         return g
 
     g = fresh()
-    g._backend().option('batch_resident', resident)          # (-2: the library's own choice -- 70 x 4 weight matrices: resident)
     if budget_mb:
         g._backend().option('batch_mem_mb', budget_mb)        # (a chunk then holds fewer evaluations than the list has)
     max_iter = 6 if q >= 3 else None                           # (the reference's Jacobi iteration diverges at q = 3: DESIGN.md 3)
