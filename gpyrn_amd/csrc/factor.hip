@@ -593,7 +593,7 @@ static int factor_invert_launches(gprn_ctx* c, int nbatch, int set)
             rest_J = J;
         }
         // rows [k0, k1) of X are final once stream3 is through with the panel: their share of the phase's O(N^2)
-        // reductions goes behind the panel's bulk update on the bulk stream (run_phase, api.hip)
+        // reductions goes behind the panel's bulk update on the bulk stream (run_phase, api_sweep.hip)
         if (c->rows_final) {
             if (!(o.nrest && sr) && sn != s2) HIP_TRY(c, await(s2, J, F_PANEL));
             if ((rc = c->rows_final(o.k0, o.k1, s2))) return rc;

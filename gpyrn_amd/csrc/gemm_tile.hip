@@ -104,7 +104,7 @@ void k_tile_gemm(const TileTask* __restrict__ tasks, double* const* __restrict__
     const bool lower = CAN_LOWER && ((t.modes >> 4) & 1);
     // First touch (modes bit 5, the first outer panel's K = 512 update when the caller hands over s = sqrt(d)): the tile
     // of B = I + D^1/2 K D^1/2 is formed from K on the way in instead of being read -- k_build_B then writes only what the
-    // first panel's tile steps touch, a quarter of the matrix (run_phase, api.hip).
+    // first panel's tile steps touch, a quarter of the matrix (run_phase, api_sweep.hip).
     // (64 x 64 workgroups only: the 8-wave 128 x 128 form sits at its 128-register budget and would spill)
     constexpr bool CAN_FT = BM == 64 && BN == 64 && TRI == 0 && (TAG == TG_NEXT || TAG == TG_BULK || TAG == TG_AHEAD);
     const double* ft_K = nullptr;

@@ -114,7 +114,7 @@ struct gprn_ctx {
     hipStream_t stream4 = nullptr;   // the next panel's share of an outer update ("next"), beside the previous panel's "rest"
     hipEvent_t ev_panel = nullptr, ev_rest = nullptr, ev_next = nullptr, ev_nodes = nullptr, ev_q1 = nullptr, ev_resta = nullptr;
     hipEvent_t ev_diag = nullptr, ev_minil = nullptr, ev_inner = nullptr, ev_first = nullptr;
-    // head / tail of a phase beside its factorisation (run_phase, api.hip; factor_invert_split, factor.hip)
+    // head / tail of a phase beside its factorisation (run_phase, api_sweep.hip; factor_invert_split, factor.hip)
     hipEvent_t ev_tail = nullptr;
     bool node_term_done = false;     // the node phase's mu^T K^-1 mu went to the bulk stream beside the weight phase (run_phase)
     // run_phase: called (by schedules that know) once tile rows [r0, r1) of X are final in `stream` order -- the O(N^2)
@@ -144,7 +144,7 @@ struct gprn_ctx {
     std::vector<int> loc_nodes, loc_weights;   // latent GPs of this rank, ascending = slot order
     void* comm = nullptr;            // ncclComm_t
     void* shm = nullptr;             // ShmComm: rehearsal transport of one-GPU boxes (api.hip)
-    double* d_agree = nullptr;       // one word: did any rank's call time out (with_event_fallback, api.hip)
+    double* d_agree = nullptr;       // one word: did any rank's call time out (with_event_fallback, api_internal.h)
     void* watch = nullptr;           // WatchEntry (api.hip): this context's slot of the collective watchdog, while it has a communicator
     int comm_budget_s = -1;          // gprn_set_option "comm_budget_s"; -1: GPRN_COMM_BUDGET_S or 600
 
@@ -249,7 +249,7 @@ struct gprn_ctx {
     int build_pending = 0;           // run_phase: B of this many slots is still to be built by the next factor_invert
     const double* ft_s_phase = nullptr;
     const double* ft_s_now = nullptr;
-    int overlap_opt = -1;            // gprn_set_option "overlap" (api.hip overlap_mask); -1: the default
+    int overlap_opt = -1;            // gprn_set_option "overlap" (api_sweep.hip overlap_mask); -1: the default
     // ---- small-N path (smalln.hip): problems of one or two tiles run a half-sweep as ONE launch, one workgroup per latent GP
     int small_opt = -1;              // gprn_set_option "small_path": 0 never, else wherever it applies (small_applies)
     double** d_kinv_tab = nullptr;   // [q] device pointers K_j^-1 (quirk Q1), for k_small_tail
@@ -439,7 +439,7 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
                        double* mu_out, double* var_out);
 void mid_batch_free(gprn_ctx* c);
 size_t batch_budget_bytes(gprn_ctx* c);        // device memory a chunk of evaluations may take (option "batch_mem_mb")
-// api.hip: one half-sweep's factorisation with its head and tail against c->d_ptrs / slot0 / d_info_cur (run_phase, midn.hip)
+// api_sweep.hip: one half-sweep's factorisation with its head and tail against c->d_ptrs / slot0 / d_info_cur (run_phase, midn.hip)
 int phase_core(gprn_ctx* c, bool weights, const int* d_slot_gp, int ns);
 
 // meanfield.py:640-643: np.std / np.mean of the last three values, operation by operation (one rounding each)

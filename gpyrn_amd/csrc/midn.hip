@@ -12,7 +12,7 @@
 // evaluation and latent GP the prior matrix K, chol(K)^-1, the sweep's workspaces B and X, K_j^-1 for nodes j >= 1
 // (quirk Q1), and per evaluation the state, y - mean, the variances, the per-GP scalars -- the kernels of vecops.hip find
 // an evaluation's copy through gprn_ctx::ev (slot -> evaluation, strides).  The parent's own state and factors are not
-// touched.  Per sweep: node phase (phase_core, api.hip), the Q1 products, weight phase, the prior terms, the ELBO of
+// touched.  Per sweep: node phase (phase_core, api_sweep.hip), the Q1 products, weight phase, the prior terms, the ELBO of
 // every evaluation still running, ONE read-back (4 doubles per evaluation + the pivot verdicts); the stop rule of
 // meanfield.py:640-643 is applied per evaluation on the host, and an evaluation that has stopped leaves the tables of the
 // next sweep (its slots are compacted away: the launches shrink with the number of evaluations still running).
@@ -511,7 +511,7 @@ int mid_batch_elbocalc(gprn_ctx* c, int n_eval, const double* kparams, int n_kpa
         int rc = mid_chunk(c, m, io);
         if (rc == GPRN_E_WAIT_TIMEOUT) {
             // an in-kernel dependency wait gave up (a serialising tool, a starved device): both contexts go to the event
-            // schedule and the chunk runs again from the caller's inputs (with_event_fallback's rule, api.hip)
+            // schedule and the chunk runs again from the caller's inputs (with_event_fallback's rule, api_internal.h)
             hipStreamSynchronize(w->stream); hipStreamSynchronize(w->stream2); hipStreamSynchronize(w->stream3);
             if (w->stream4) hipStreamSynchronize(w->stream4);
             w->use_flags = 0; c->use_flags = 0;

@@ -1,5 +1,5 @@
 """Multi-rank path on CPU (gloo, world_size 2): the sharding schedule of
-csrc/api.hip -- who owns which latent GP, what is broadcast after each
+csrc/api.hip / api_sweep.hip -- who owns which latent GP, what is broadcast after each
 half-sweep, which scalars are all-reduced -- executed with the oracle's per-GP
 arithmetic in place of the HIP kernels, and compared with the unsharded sweep."""
 import os
@@ -45,7 +45,7 @@ def _row(g, p, q):
 
 def sharded_sweep(rank, world, dist, torch, Kf, Kw, Lf, Lw, y, y_raw, yerr2, jitt2, mu, var):
     """One sweep with the latent GPs sharded over `world` ranks (schedule of
-    gprn_sweep in csrc/api.hip; arithmetic of oracle/cpu_ref.sweep_B)."""
+    gprn_sweep in csrc/api_sweep.hip; arithmetic of oracle/cpu_ref.sweep_B)."""
     q, N = Kf.shape[0], Kf.shape[-1]
     p = Kw.shape[0] // q
     G = q * (p + 1)
