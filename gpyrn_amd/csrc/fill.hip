@@ -59,28 +59,44 @@ __device__ __forceinline__ double exp_neg(double x)
     return x_in != x_in ? x_in : ldexp(p, (int)n);
 }
 
-// sin^2(pi x), x >= 0, the only form the periodic kernels use the sine in: the distance f of x to the nearest integer is
-// exact, so is g = min(f, 1/2 - f) <= 1/4, and sin(pi g) = g P(g^2) with the Taylor polynomial of degree 8 (pi g <= pi / 4:
-// the next term is 8e-20); beyond 1/4 the square is 1 - sin^2(pi g).  One polynomial instead of the library sinpi's two
-// (sine and cosine, selected by octant) and no sign logic.
-__device__ __forceinline__ double sinpi_sq(double x)
+// a / b correctly rounded (but for a sliver of near-halfway cases) from rb = RN(1 / b): one residual, one correction -- two
+// FMAs where the IEEE division sequence is ~10 quarter-rate instructions.  The reference divides (NumPy: x / ell**2), and on
+// a prior matrix with cond(K) ~ 1e9 the last bits of K's entries are worth 1e-8 on m^T K^-1 m (profiles/r06_fill_rounding.txt).
+__device__ __forceinline__ double div_rn(double a, double b, double rb)
 {
-    const double f = fabs(x - rint(x));
-    const bool hi = f > 0.25;
-    const double g = hi ? 0.5 - f : f;
-    const double z = g * g;
-    double p = 7.952054001475508e-07;
-    p = fma(p, z, -2.1915353447830204e-05);
-    p = fma(p, z, 0.00046630280576761234);
-    p = fma(p, z, -0.007370430945714348);
-    p = fma(p, z, 0.08214588661112819);
-    p = fma(p, z, -0.5992645293207919);
-    p = fma(p, z, 2.550164039877345);
-    p = fma(p, z, -5.167712780049969);
-    p = fma(p, z, 3.141592653589793);
-    const double sn = p * g;
-    const double u = sn * sn;
-    return hi ? 1.0 - u : u;
+    const double q = a * rb;
+    return fma(fma(-q, b, a), rb, q);
+}
+
+// sin^2(x), x >= 0 in RADIANS -- the periodic kernels as the reference writes them, np.sin(np.pi * np.abs(r) / P)**2: the
+// argument is the ROUNDED product / quotient, several hundred periods out, so its rounding error (|x| 1.1e-16 absolute) is part
+// of the reference's value: sinpi_sq of the exact fraction |r| / P is closer to the mathematical kernel but differs from
+// NumPy's by tens to hundreds of ulp of K (mean 34, max 589 at |x| ~ 110), which the Cholesky of an ill-conditioned prior
+// amplifies.  Reduction by pi in three words (Cody-Waite: the first two have 33 bits, n pi_A and n pi_B are exact for
+// n < 2^19 -- |x| < 1.6e6, i.e. 5e5 periods), then sin on [0, pi/4] by its Taylor polynomial of degree 19 (next term 8e-20)
+// and, beyond pi/4, 1 - sin^2(pi/2 - g).
+__device__ __forceinline__ double sin_sq_rad(double x)
+{
+    const double n = rint(x * 0.318309886183790671538);
+    double g = fma(-n, 3.14159265346825122833e+00, x);
+    g = fma(-n, 1.21542010126079319532e-10, g);
+    g = fma(-n, 4.04453249742233291160e-21, g);
+    g = fabs(g);
+    const bool hi = g > 0.78539816339744830962;
+    const double u = hi ? (1.57079632679489655800e+00 - g) + 6.12323399573676603587e-17 : g;
+    const double z = u * u;
+    double p = -1.0 / 121645100408832000.0;
+    p = fma(p, z, 1.0 / 355687428096000.0);
+    p = fma(p, z, -1.0 / 1307674368000.0);
+    p = fma(p, z, 1.0 / 6227020800.0);
+    p = fma(p, z, -1.0 / 39916800.0);
+    p = fma(p, z, 1.0 / 362880.0);
+    p = fma(p, z, -1.0 / 5040.0);
+    p = fma(p, z, 1.0 / 120.0);
+    p = fma(p, z, -1.0 / 6.0);
+    const double sn = fma(p * z, u, u);
+    const double s2 = sn * sn;
+    return hi ? 1.0 - s2 : s2;
 }
 
 __device__ __forceinline__ void harmonic_terms(double Nh, double P, double t, double& s, double& u)
@@ -99,36 +115,37 @@ __device__ __forceinline__ double eval_kernel(int kid, const double* __restrict_
     switch (kid) {
     case GPRN_K_CONSTANT: return q[0] * q[0];
     case GPRN_K_WHITENOISE: return diag ? q[0] * q[0] : 0.0;
-    // SE, Periodic, QP (the kernels of the BASELINE configs): the per-element divisions by parameter
-    // expressions become multiplications by reciprocals, which depend on the parameters only and are hoisted
-    // out of the element loop -- an IEEE fp64 division is ~10 quarter-rate instructions.  The argument of
-    // exp / sin moves by <= 1 ulp: <= 1e-13 relative on K against NumPy's order of operations (test tolerance 1e-12).
-    // (aux: the same reciprocals formed once on the host, make_program -- an IEEE division is the same number on either
-    // side; a thread of k_fill_sym evaluates 8 elements, and QP's three divisions were a quarter of its instructions)
-    case GPRN_K_SE: {
-        const double inv = aux ? aux[0] : 1.0 / (q[1] * q[1]);
-        const double x = -0.5 * (r * r) * inv;
+    // SE, Periodic, QP (the kernels of the BASELINE configs): the per-element divisions by parameter expressions run as
+    // multiplications by reciprocals -- which depend on the parameters only, are formed once on the host (aux, make_program)
+    // and hoisted out of the element loop: an IEEE fp64 division is ~10 quarter-rate instructions, and QP's three were a
+    // quarter of a thread's instructions -- plus ONE correction step each (div_rn), so that the quotients round as NumPy's
+    // divisions do; the sine takes the reference's ROUNDED radian argument (sin_sq_rad).  Rounds 1-5 multiplied by the
+    // reciprocal alone and took sin^2(pi frac(|r| / P)): closer to the mathematical kernel, tens to hundreds of ulp away
+    // from the reference's K -- which a prior with cond(K) ~ 1e9 turns into 1e-8 on the ELBO (profiles/r06_fill_rounding.txt).
+    case GPRN_K_SE: {                 // theta**2 * exp(-0.5 * r**2 / ell**2)
+        const double l2 = q[1] * q[1];
+        const double x = GPRN_FILL_FAST ? div_rn(-0.5 * (r * r), l2, aux ? aux[0] : 1.0 / l2) : -0.5 * (r * r) / l2;
         return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(x) : exp(x));
     }
     // (sin(pi |r| / P) through the fraction of |r| / P, not through sin on an argument of several hundred periods, whose
     // reduction is a multi-word product)
-    case GPRN_K_PERIODIC: {
-        const double inv = aux ? aux[0] : 1.0 / (q[2] * q[2]);
-        const double a = fabs(r) * (aux ? aux[1] : 1.0 / q[1]);
-        double s2;
-        if (GPRN_FILL_FAST) s2 = sinpi_sq(a);
-        else { const double s = sinpi(a); s2 = s * s; }
-        const double x = -2 * s2 * inv;
+    case GPRN_K_PERIODIC: {           // theta**2 * exp(-2 * sin(pi * |r| / P)**2 / ell**2)
+        const double l2 = q[2] * q[2];
+        double x;
+        if (GPRN_FILL_FAST) {
+            const double s2 = sin_sq_rad(div_rn(PI_D * fabs(r), q[1], aux ? aux[1] : 1.0 / q[1]));
+            x = div_rn(-2 * s2, l2, aux ? aux[0] : 1.0 / l2);
+        } else { const double sn = sin(PI_D * fabs(r) / q[1]); x = -2 * (sn * sn) / l2; }
         return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(x) : exp(x));
     }
-    case GPRN_K_QP: {
-        const double invp = aux ? aux[0] : 1.0 / (q[3] * q[3]), inve = aux ? aux[2] : 1.0 / (2 * (q[1] * q[1]));
-        const double a = fabs(r) * (aux ? aux[1] : 1.0 / q[2]);
-        double s2;
-        if (GPRN_FILL_FAST) s2 = sinpi_sq(a);
-        else { const double s = sinpi(a); s2 = s * s; }
-        const double per = -2 * s2 * invp;
-        const double dec = (r * r) * inve;
+    case GPRN_K_QP: {                 // theta**2 * exp(-2 * sin(pi * |r| / P)**2 / ellp**2 - r**2 / (2 * elle**2))
+        const double lp2 = q[3] * q[3], le2 = 2 * (q[1] * q[1]);
+        double per, dec;
+        if (GPRN_FILL_FAST) {
+            const double s2 = sin_sq_rad(div_rn(PI_D * fabs(r), q[2], aux ? aux[1] : 1.0 / q[2]));
+            per = div_rn(-2 * s2, lp2, aux ? aux[0] : 1.0 / lp2);
+            dec = div_rn(r * r, le2, aux ? aux[2] : 1.0 / le2);
+        } else { const double sn = sin(PI_D * fabs(r) / q[2]); per = -2 * (sn * sn) / lp2; dec = (r * r) / le2; }
         return q[0] * q[0] * (GPRN_FILL_FAST ? exp_neg(per - dec) : exp(per - dec));
     }
     case GPRN_K_RQ:

@@ -535,6 +535,8 @@ if __name__ == '__main__':
     # (tag, N, p, q, forced sweeps, full ELBOcalc, spec, span of the sampling)
     for tag, N, p, q, ns, full, spec, span in (('illc_N100_p2q3', 100, 2, 3, 3, False, ILLC_SPEC, 80.0),
                                                ('illc_N300_p2q3', 300, 2, 3, 3, False, ILLC_SPEC, 240.0),
+                                               # (eight tiles: the launch schedule's outer panels, K = 512 updates; cond(K) 4e8)
+                                               ('illc_N1000_p2q3', 1000, 2, 3, 2, False, ILLC_SPEC, 800.0),
                                                ('kmix_N200_p2q2', 200, 2, 2, 4, True, KMIX_SPEC, 160.0)):
         if want(tag):
             gen_step_case(tag, N, p, q, None, True, ns, full, False, 7, spec, span)

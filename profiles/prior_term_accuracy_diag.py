@@ -4,10 +4,20 @@ import gpyrn_amd as gpyrn
 from gpyrn_amd import _hip
 from tests.test_parity_gpu import _random_problem
 from scipy.linalg import solve_triangular
-seed = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-t, ys, es, nodes, weights, means, jit, p, q = _random_problem(seed)
-g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
-g.set_components(nodes, weights, means, jit)
+# argument: a seed of tests/test_parity_gpu.py::_random_problem (default 7), or the tag of a golden fixture (e.g. illc_N1000_p2q3)
+arg = sys.argv[1] if len(sys.argv) > 1 else '7'
+if arg.lstrip('-').isdigit():
+    t, ys, es, nodes, weights, means, jit, p, q = _random_problem(int(arg))
+    g = gpyrn.inference(q, t, *[a for pair in zip(ys, es) for a in pair])
+    g.set_components(nodes, weights, means, jit)
+else:
+    from tests import _cases
+    from gpyrn_amd import covfunc, meanfunc
+    meta, d_ = _cases.load(arg)
+    nodes, weights, means, jit = _cases.components(meta, covfunc, meanfunc)
+    p, q, t = meta['p'], meta['q'], np.array(d_['time'])
+    g = gpyrn.inference(q, t, *_cases.data_args(d_))
+    g.set_components(nodes, weights, means, jit)
 ctx = g._setup_device(nodes, weights, means, jit)
 mu0, var0 = g._initMuVar(nodes, weights, jit)
 ctx.set_muvar(mu0, var0)
@@ -23,8 +33,8 @@ def chol_ld(K):
     for j in range(N):
         s = A[j, j] - np.dot(L[j, :j], L[j, :j])
         L[j, j] = np.sqrt(s)
-        for i in range(j + 1, N):
-            L[i, j] = (A[i, j] - np.dot(L[i, :j], L[j, :j])) / L[j, j]
+        if j + 1 < N:
+            L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
     return L
 
 

@@ -10,7 +10,8 @@ from tests import _cases
 # illc_*: an ill-conditioned prior under a diverging state (a pure Periodic weight, q = 3); kmix_*: a converging problem on
 # Periodic / Multiplication / Matern / RationalQuadratic / Sum kernels (oracle/gen_golden.py, round 6)
 SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3', 'illc_N100_p2q3']
-MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1', 'illc_N300_p2q3', 'kmix_N200_p2q2']
+MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1', 'illc_N300_p2q3', 'kmix_N200_p2q2',
+       'illc_N1000_p2q3']
 
 
 def _problem(tag):

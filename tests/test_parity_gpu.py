@@ -125,7 +125,8 @@ def _assert_default_schedule(ctx):
 # steps of rounds 1-5 missed 1e-8); kmix_*: a converging problem on Periodic / Multiplication / Matern / RationalQuadratic /
 # Sum kernels -- both generated from the reference in round 6 (oracle/gen_golden.py)
 SMALL = ['step_p1q1', 'step_p2q1', 'step_p1q2', 'step_p3q2', 'step_p2q3', 'illc_N100_p2q3']
-MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1', 'illc_N300_p2q3', 'kmix_N200_p2q2']
+MID = ['cfg1_N200', 'mid_N300_p3q2', 'mid_N512_p3q2', 'mid_N1024_p1q1', 'illc_N300_p2q3', 'kmix_N200_p2q2',
+       'illc_N1000_p2q3']
 
 
 @pytest.mark.parametrize('tag', SMALL + MID + ['cfg2_N2048', 'cfg3_N4096', 'cfg4_N4096_q4',
@@ -524,7 +525,7 @@ def _batch_inputs(g, sets):
 
 
 @pytest.mark.parametrize('tag,B', [('mid_N300_p3q2', 7), ('mid_N512_p3q2', 32), ('cfg1_N200', 5), ('mid_N1024_p1q1', 6),
-                                   ('illc_N300_p2q3', 4), ('kmix_N200_p2q2', 6)])
+                                   ('illc_N300_p2q3', 4), ('kmix_N200_p2q2', 6), ('illc_N1000_p2q3', 3)])
 def test_every_slot_of_a_batch_above_one_tile_reproduces_the_reference(tag, B):
     _every_slot_reproduces_the_reference(tag, B)
 
