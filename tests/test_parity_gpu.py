@@ -63,6 +63,32 @@ def test_fill_sizes_around_the_block_edges(n):
         assert np.array_equal(K, K.T)
 
 
+def test_fill_keeps_the_references_rounding_sequence():
+    """Round 6: on a prior with cond(K) ~ 1e9 the LAST BITS of K's entries are worth 1e-8 on m^T K^-1 m
+    (profiles/r06_fill_rounding.txt).  The reference writes np.sin(np.pi * np.abs(r) / P)**2 and x / ell**2: the sine of a
+    ROUNDED argument hundreds of periods out, IEEE quotients.  The fill follows that sequence (csrc/fill.hip: div_rn,
+    sin_sq_rad), so its matrices differ from NumPy's evaluation of the same formula (gpyrn_amd.covfunc's __call__, pinned to
+    the reference's matrices by kernels.npz) by the last bit or two of exp / sin -- a fraction of an ulp on average, where
+    rounds 1-5 (sin^2 of the exact fraction, products with reciprocals) were 13-42 ulp away on average and 500-1000 at worst."""
+    rng = np.random.RandomState(3)
+    n = 1000
+    t = np.sort(rng.uniform(0.0, 800.0, n))
+    g = gpyrn.inference(1, t, np.zeros(n), np.ones(n))
+    r = t[:, None] - t[None, :]
+    for k, mean_bound in ((covfunc.SquaredExponential(0.97, 8.8), 0.25), (covfunc.Periodic(1.34, 22.7, 0.82), 1.5),
+                          (covfunc.QuasiPeriodic(1.2, 30.0, 22.0, 1.4), 1.0)):
+        K = g._KMatrix(k)
+        want = k(r) + 1e-6 * np.eye(n)
+        big = want > 1e-200                                   # (entries in the denormal tail of the exponential aside)
+        ulp = np.abs(K - want)[big] / np.spacing(want[big])
+        assert ulp.mean() <= mean_bound, '%s: %.2f ulp on average' % (type(k).__name__, ulp.mean())
+        # (exp(x) has condition number |x|: where the last bit of sin**2 flips the rounding of term1 - term2, an entry
+        # exp(-150) jumps by 150 / 2 ulp -- whichever libm computed the sine.  The entries that carry weight in a
+        # factorisation, those within 1e-6 of the largest, have |x| < 14.)
+        rel = want[big] > 1e-6 * want.max()
+        assert np.percentile(ulp[rel], 99.9) <= 16, '%s: 99.9th percentile %.0f ulp' % (type(k).__name__, np.percentile(ulp[rel], 99.9))
+
+
 def test_user_kernel_takes_host_path():
     class MySE(covfunc.covFunction):
         _param_names = ('a', 'l')
