@@ -19,7 +19,11 @@ def problem(N, p, q, kind):
     return g
 
 
-for shape in ([synth.CONFIGS[int(a)] for a in sys.argv[1:]] or [synth.CONFIGS[3], synth.CONFIGS[2], (512, 3, 2, 'QP')]):
+def parse(a):          # a BASELINE config number, or N,p,q,kind
+    return synth.CONFIGS[int(a)] if a.isdigit() else (int(a.split(',')[0]), int(a.split(',')[1]), int(a.split(',')[2]), a.split(',')[3])
+
+
+for shape in ([parse(a) for a in sys.argv[1:]] or [synth.CONFIGS[3], synth.CONFIGS[2], (512, 3, 2, 'QP')]):
     g = problem(*shape)
     ctx = g._setup_device(g.nodes, g.weights, g.means, g.jitters)
     for rep in range(2):
@@ -32,6 +36,16 @@ for shape in ([synth.CONFIGS[int(a)] for a in sys.argv[1:]] or [synth.CONFIGS[3]
                 info = ctx.factor_priors()
                 ts.append((time.perf_counter() - t0) * 1e3)
             assert info == 0
-            print('N %d p %d q %d  set-up with %-12s: median %.3f ms  (min %.3f, max %.3f)' % (
-                shape[0], shape[1], shape[2], name, np.median(ts), min(ts), max(ts)), flush=True)
+            # ... and a whole evaluation (set-up + the warm-started loop), as bench.py --latency times it
+            x0 = np.array(g.get_parameters(), dtype=float)
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                g.nELBO(x0 * 1.001)
+                te = []
+                for k in range(20):
+                    t0 = time.perf_counter()
+                    g.nELBO(x0 * (1.0 + 0.001 * (k % 5)))
+                    te.append((time.perf_counter() - t0) * 1e3)
+            print('N %d p %d q %d  set-up with %-12s: median %.3f ms  (min %.3f, max %.3f) | nELBO with new parameters: median %.3f ms' % (
+                shape[0], shape[1], shape[2], name, np.median(ts), min(ts), max(ts), np.median(te)), flush=True)
     assert ctx.option('fallbacks') == 0
