@@ -1221,9 +1221,9 @@ def test_a_long_elbocalc_outlives_the_watchdogs_budget(tmp_path):
     """the watchdog's timer was refreshed only by the shm barrier and every 64th sweep of ONE gprn_sweep
     call, so on the RCCL transport a gprn_elbocalc that legitimately ran longer than the budget (N = 16384; a NaN ELBO that
     runs to max_iter) would have been ended on every rank with a line blaming a dead rank.  Every stream synchronisation
-    the host observes now restarts the count.  Two ranks, a 2 s budget, one ELBOcalc call of several times that (q = 3: the
+    the host observes now restarts the count.  Two ranks, a 1 s budget, one ELBOcalc call of several times that (q = 3: the
     iteration diverges and never meets the stop rule): both ranks must come back, with status 0."""
-    budget, max_iter = 2, 12000
+    budget, max_iter = 1, 12000
     results = _run_ranks('tests._shard_worker', 'step_p2q3', 2, tmp_path,
                          extra_env={'GPRN_TEST_LONG_ELBOCALC': str(max_iter), 'GPRN_COMM_BUDGET_S': str(budget)})
     for res in results:
