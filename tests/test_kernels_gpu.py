@@ -86,6 +86,47 @@ def test_factor_invert_not_positive_definite(ctx):
     assert np.isnan(L[0][255, 255])            # jax semantics: NaN, no exception
 
 
+@pytest.mark.parametrize('n,batch,flags', [(128, 1, 1), (384, 3, 1), (384, 18, 1), (384, 50, 1), (1024, 5, 1), (1024, 5, 0)])
+def test_factor_invert_with_substitution_panels(ctx, n, batch, flags):
+    """Round 6: the factorisation of a PRIOR matrix solves its panel steps instead of multiplying by explicit inverses of
+    diagonal blocks (csrc/diag_tile.h ACC: base16_regs<true>, subst16_row, trsm_rows16; option accurate_factor).  Here on its
+    own, in every launch form -- pointers as kernel arguments or from the table (batch > 16), the chain's products on the
+    latency kernels or as tile tasks (batch >= 48), latency and throughput task lists (batch x tiles > 32: outer panels with
+    K = 512 updates), flags and events -- on a pure Periodic kernel under the reference's nugget (cond(K) ~ 1e8-1e9) with a
+    vector far outside its range: |X m|^2 agrees with LAPACK's cholesky + triangular solve to 2e-9 (each is a few 1e-10
+    from a long-double evaluation: profiles/r06_prior_term_accuracy.txt), where the product form is 1e-8 ... 1e-7 away."""
+    from scipy.linalg import solve_triangular
+    from gpyrn_amd import covfunc
+    if flags and not ctx.option('flags'):
+        pytest.skip('device-side flags are off for this context')
+    rng = np.random.RandomState(n + batch)
+    N = n - 24                                             # (a ragged last tile: identity padding)
+    t = np.sort(rng.uniform(0.0, 0.8 * N, N))
+    K = covfunc.Periodic(1.34, 22.7, 0.82)(t[:, None] - t[None, :]) + 1e-6 * np.eye(N)
+    A = np.eye(n)
+    A[:N, :N] = K
+    m = 10.0 * rng.standard_normal(N)
+    a = solve_triangular(np.linalg.cholesky(K), m, lower=True)
+    want = float(a @ a)
+    old_flags, devs = ctx.option('flags', flags), {}
+    try:
+        for acc in (1, 0):
+            ctx.option('accurate_factor', acc)
+            L, X, info = ctx.test_factor_invert(np.array([A] * batch))
+            assert info == 0
+            got = [float(np.sum((np.tril(X[b])[:N, :N] @ m) ** 2)) for b in range(batch)]
+            assert len(set(got)) == 1, 'the copies of one matrix in a batch differ'
+            devs[acc] = abs(got[0] - want) / want
+            if acc:
+                np.testing.assert_allclose(np.tril(L[0])[:N, :N] @ np.tril(L[0])[:N, :N].T, K, rtol=0, atol=1e-12 * np.abs(K).max())
+    finally:
+        ctx.option('accurate_factor', -2)
+        ctx.option('flags', old_flags)
+    assert devs[1] <= 2e-9, devs
+    assert devs[0] >= 5 * devs[1], 'the product form was expected to be visibly worse on this matrix: %r' % devs
+    assert ctx.option('fallbacks') == 0
+
+
 def test_lauum(ctx):
     rng = np.random.RandomState(9)
     X = np.tril(rng.standard_normal((384, 384)))
