@@ -48,7 +48,7 @@ def test_fill_matches_reference_kernels():
 def test_fill_sizes_around_the_block_edges(n):
     """k_fill_sym evaluates two adjacent columns per thread and mirrors 64 x 64 blocks: sizes that end inside a pair, a block
     and a tile, against the host formulas (gpyrn_amd.covfunc, themselves checked against the reference's matrices in
-    test_api.py) -- SE / Periodic / QP go through exp_neg and sinpi_sq on the device."""
+    test_api.py) -- SE / Periodic / QP go through exp_neg, div_rn and sin_sq_rad on the device."""
     rng = np.random.default_rng(n)
     t = np.sort(rng.uniform(0.0, 400.0, n))
     g = gpyrn.inference(1, t, np.zeros(n), np.ones(n))
