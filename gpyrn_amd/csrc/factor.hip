@@ -114,7 +114,7 @@ int launch_diag(gprn_ctx* c, double** d_ptrs, int nbatch, int ld, int kblk, int*
     // as the neighbours would have cost (config 3 with the pad in the node phase: 109.8 vs 110.1), hence the limit.
     size_t dyn = 0;
     if (nbatch * c->T <= GPRN_LAT_MAX)
-        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - DIAG_LDS_DOUBLES_ACC * sizeof(double));
+        dyn = std::min<size_t>((size_t)113 * 1024, lds_limit(c->device) - (c->acc_now ? DIAG_LDS_DOUBLES_ACC : DIAG_LDS_DOUBLES) * sizeof(double));
     pa.stamps = step_stamp_ptr(c, kblk, 0);
     // rows of data in this tile: all 128 but in the last tile of a ragged matrix (ld is the context's: the diagnostic entry
     // points factor whole tiles)
